@@ -1,0 +1,95 @@
+/*
+ * pdt_amd.h -- C ABI of libpdt_amd.so: MI355X (gfx950) kernels for the sequence-level
+ * hot path of pydrobert-pytorch.
+ *
+ * The reference (sdrobert/pydrobert-pytorch) is pure Python on stock ATen ops and has
+ * no FFI of its own; its boundary for this path is the Python functional API
+ * (src/pydrobert/torch/functional.py:24-58).  Each entry point below is what a binding
+ * for one of those functions calls; the citation names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no torch types; all pointers are DEVICE pointers that the
+ *     library borrows for the duration of the call (never frees, never retains);
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued, never synchronised;
+ *   - strides are in ELEMENTS: token (t, n) of a sequence tensor is tok[t*st + n*sn], so
+ *     batch_first inputs/outputs are expressed by swapping strides, not by copies;
+ *   - return value: 0 ok, <0 invalid argument (PDT_E_*), >0 a hipError_t;
+ *   - `status` (optional, device int32) is OR-ed with PDT_WARN_* data-irregularity bits
+ *     (the reference raises warnings.warn for them when warn=True).
+ */
+#ifndef PDT_AMD_H
+#define PDT_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDT_OK 0
+#define PDT_E_ARG -1      /* malformed argument (null pointer, negative size, bad mode) */
+#define PDT_E_TOO_LONG -2 /* a sequence dimension exceeds what the kernel supports */
+
+#define PDT_MODE_FINAL 0
+#define PDT_MODE_PREFIX 1
+
+#define PDT_WARN_REF_NO_EOS 1 /* _string.py:201-207 */
+#define PDT_WARN_HYP_NO_EOS 2 /* _string.py:211-217 */
+#define PDT_WARN_EMPTY_REF 4  /* _string.py:361-367, :398-404 */
+
+/* Library / build identification. */
+int pdt_amd_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Batched Levenshtein: error_rate, edit_distance, prefix_error_rates,
+ * prefix_edit_distances.  Replaces _string_matching (_string.py:146-406) for
+ * return_mask=False, including _lens_from_eos (_string.py:137-143), the include_eos
+ * fix-ups (:195-218), the uniform-cost shortcut (:168-174), normalisation and padding
+ * (:356-405).
+ *
+ *   ref (R, N), hyp (H, N) int64 tokens addressed through element strides.
+ *   mode FINAL : out[n * out_sn]                          (N,)      float32
+ *   mode PREFIX: out[h * out_sh + n * out_sn], h < Hout   (Hout, N) float32,
+ *                Hout = H + (exclude_last ? 0 : 1)
+ *   return_mistakes: 1 = error-count semantics (error_rate / prefix_error_rates),
+ *                    0 = cost semantics (edit_distance / prefix_edit_distances).
+ *   ref_lens_out / hyp_lens_out (optional, (N,) int64) receive the sequence lengths.
+ * ------------------------------------------------------------------------------------- */
+int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
+            const int64_t *hyp, int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N,
+            int has_eos, int64_t eos, int include_eos, float ins_cost, float del_cost,
+            float sub_cost, int norm, int mode, int exclude_last, float padding,
+            int return_mistakes, float *out, int64_t out_sh, int64_t out_sn,
+            int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optimal completion, two phases (optimal_completion, _string.py:464-517; the DP is
+ * _string_matching with return_mask=True, :271-278, :319-355).
+ *
+ * Phase 1, pdt_oc_mask: per utterance, ranks the distinct reference tokens
+ * (class k = k-th smallest distinct token of ref[:ref_len]), runs the DP and for each
+ * hypothesis prefix h records WHICH classes are optimal next tokens as a bitmask:
+ *     bitmask[(h * N + n) * W + w], W = pdt_oc_mask_words(R) 32-bit words, bit k of the
+ *     row set iff class k is in the completion set of prefix h.
+ *     class_tokens[n * R + k] = token value of class k            (N, R) int64
+ *     max_count (device int32, must be zeroed by the caller) = max set size = the
+ *     reference's `C = counts.max().item()` (:511).
+ * Phase 2, pdt_oc_expand (after the caller has read max_count and allocated targets):
+ *     targets[h * tgt_sh + n * tgt_sn + i], i < C, ascending tokens then `padding`.
+ * ------------------------------------------------------------------------------------- */
+int64_t pdt_oc_mask_words(int64_t R);
+
+int pdt_oc_mask(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
+                const int64_t *hyp, int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N,
+                int has_eos, int64_t eos, int include_eos, float ins_cost, float del_cost,
+                float sub_cost, int exclude_last, uint32_t *bitmask,
+                int64_t *class_tokens, int32_t *max_count, int32_t *status, void *stream);
+
+int pdt_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int64_t R,
+                  int64_t Hout, int64_t N, int64_t C, int64_t padding, int64_t *targets,
+                  int64_t tgt_sh, int64_t tgt_sn, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

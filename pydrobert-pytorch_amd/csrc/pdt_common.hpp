@@ -1,0 +1,90 @@
+// Shared device helpers for the gfx950 kernels (wave64, DPP cross-lane moves).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pdt_amd.h"
+
+#define PDT_WAVE 64
+#define PDT_INF __builtin_huge_valf()
+
+// DPP control words (GFX9 encoding; gfx950 keeps the wave_* and row_bcast forms).
+#define PDT_DPP_ROW_SHR(n) (0x110 + (n))
+#define PDT_DPP_WAVE_SHR1 0x138
+#define PDT_DPP_ROW_BCAST15 0x142
+#define PDT_DPP_ROW_BCAST31 0x143
+
+namespace pdt {
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// value of lane-1 (lane 0 receives `first`).  One v_mov_b32_dpp wave_shr:1.
+__device__ __forceinline__ float shr1(float v, float first) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(
+      __float_as_int(first), __float_as_int(v), PDT_DPP_WAVE_SHR1, 0xf, 0xf, false));
+}
+__device__ __forceinline__ int shr1(int v, int first) {
+  return __builtin_amdgcn_update_dpp(first, v, PDT_DPP_WAVE_SHR1, 0xf, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ float dpp_or(float v, float ident) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(ident), __float_as_int(v),
+                                                    CTRL, ROW_MASK, BANK_MASK, false));
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_or(int v, int ident) {
+  return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// inclusive wave-wide min scan (7 DPP steps, identity +inf)
+__device__ __forceinline__ float wave_incl_scan_min(float x) {
+  float v = x;
+  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(1)>(x, PDT_INF));
+  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(2)>(x, PDT_INF));
+  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(3)>(x, PDT_INF));
+  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(v, PDT_INF));
+  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(v, PDT_INF));
+  v = fminf(v, dpp_or<PDT_DPP_ROW_BCAST15, 0xa>(v, PDT_INF));
+  v = fminf(v, dpp_or<PDT_DPP_ROW_BCAST31, 0xc>(v, PDT_INF));
+  return v;
+}
+
+// inclusive wave-wide integer add scan
+__device__ __forceinline__ int wave_incl_scan_add(int x) {
+  int v = x;
+  v += dpp_or<PDT_DPP_ROW_SHR(1)>(x, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(2)>(x, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(3)>(x, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(v, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(v, 0);
+  v += dpp_or<PDT_DPP_ROW_BCAST15, 0xa>(v, 0);
+  v += dpp_or<PDT_DPP_ROW_BCAST31, 0xc>(v, 0);
+  return v;
+}
+
+__device__ __forceinline__ float wave_min(float x) {
+  const float s = wave_incl_scan_min(x);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
+}
+__device__ __forceinline__ int wave_sum(int x) {
+  return __builtin_amdgcn_readlane(wave_incl_scan_add(x), 63);
+}
+
+// order LDS traffic between lanes of ONE wave (no workgroup barrier: waves are independent)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Workgroup -> work-item remap so that the workgroups that land on one XCD (blockIdx % 8
+// under round-robin dispatch) own one contiguous range of items and share L2 lines.
+// Bijective for any grid size (cdna_hip_programming.md T1).
+__device__ __forceinline__ unsigned xcd_remap(unsigned b, unsigned nwg) {
+  const unsigned q = nwg >> 3, r = nwg & 7u, xcd = b & 7u, idx = b >> 3;
+  const unsigned base = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+  return base + idx;
+}
+
+}  // namespace pdt

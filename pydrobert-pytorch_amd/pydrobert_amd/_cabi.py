@@ -1,0 +1,102 @@
+"""ctypes binding of libpdt_amd.so -- the C ABI declared in include/pdt_amd.h.
+
+This is the only place the host package touches native code.  The library is built
+in-tree by ``csrc/Makefile`` (``__graft_entry__.build()``); if it is missing or fails
+to load, every operator raises -- there is no fallback path.
+"""
+
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libpdt_amd.so")
+
+PDT_OK = 0
+PDT_E_ARG = -1
+PDT_E_TOO_LONG = -2
+MODE_FINAL, MODE_PREFIX = 0, 1
+WARN_REF_NO_EOS, WARN_HYP_NO_EOS, WARN_EMPTY_REF = 1, 2, 4
+
+_c = ctypes
+_P = _c.c_void_p
+_I64 = _c.c_int64
+_INT = _c.c_int
+_F = _c.c_float
+
+# name -> (restype, argtypes); mirrors include/pdt_amd.h declaration by declaration
+SIGNATURES = {
+    "pdt_amd_abi_version": (_INT, []),
+    "pdt_lev": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
+        + [_INT, _INT, _INT, _F, _INT, _P, _I64, _I64, _P, _P, _P, _P],
+    ),
+    "pdt_oc_mask_words": (_I64, [_I64]),
+    "pdt_oc_mask": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
+        + [_INT, _P, _P, _P, _P, _P],
+    ),
+    "pdt_oc_expand": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the native library; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "pydrobert_amd: native library {} not found. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C pydrobert-pytorch_amd/csrc`; there is no fallback "
+                "implementation.".format(LIB_PATH)
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    """Map a C-ABI status to the reference's exception type (RuntimeError)."""
+    if rc == PDT_OK:
+        return
+    if rc == PDT_E_ARG:
+        raise RuntimeError("{}: invalid argument".format(what))
+    if rc == PDT_E_TOO_LONG:
+        raise RuntimeError("{}: sequence too long for the MI355X kernel".format(what))
+    raise RuntimeError("{}: HIP error {}".format(what, rc))
+
+
+def require_hip(*tensors):
+    """All tensors must sit on one ROCm device; returns that device."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise RuntimeError(
+                "pydrobert_amd operators run only on ROCm (HIP) device tensors; got a "
+                "tensor on '{}'. There is no CPU implementation in this package.".format(t.device)
+            )
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError("tensors are on different devices: {} and {}".format(dev, t.device))
+    return dev
+
+
+def stream_ptr(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,481 @@
+"""Batched edit-distance family on MI355X.
+
+Host-side mirror of the reference's ``_string.py``: same functions, argument order,
+defaults, output shapes/dtypes, exceptions and warnings; the dynamic programming itself
+runs in ``csrc/lev_skewed.hip`` / ``csrc/lev_rowsync.hip`` through ``pdt_lev``,
+``pdt_oc_mask`` and ``pdt_oc_expand`` (``include/pdt_amd.h``).
+"""
+
+import warnings
+from typing import Optional
+
+import torch
+
+from . import _cabi, argcheck, config
+
+__all__ = [
+    "EditDistance",
+    "ErrorRate",
+    "FillAfterEndOfSequence",
+    "OptimalCompletion",
+    "PrefixEditDistances",
+    "PrefixErrorRates",
+    "edit_distance",
+    "error_rate",
+    "fill_after_eos",
+    "optimal_completion",
+    "prefix_edit_distances",
+    "prefix_error_rates",
+]
+
+
+def fill_after_eos(
+    tokens: torch.Tensor,
+    eos: int,
+    dim: int = 0,
+    fill: Optional[float] = None,
+    value: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Fill everything after the first ``eos`` along ``dim`` (reference _string.py:30-42)."""
+    out = tokens if value is None else value
+    fill_ = float(eos) if fill is None else fill
+    is_eos = tokens == eos
+    # strictly after the first eos: an eos has been seen at an earlier index
+    seen = is_eos.long().cumsum(dim) - is_eos.long()
+    return out.masked_fill(seen > 0, fill_)
+
+
+def _seq_strides(t: torch.Tensor, batch_first: bool):
+    """(T, N, stride_t, stride_n) in elements for a (T, N) or (N, T) token tensor."""
+    if batch_first:
+        return t.shape[1], t.shape[0], t.stride(1), t.stride(0)
+    return t.shape[0], t.shape[1], t.stride(0), t.stride(1)
+
+
+def _prep(ref: torch.Tensor, hyp: torch.Tensor, batch_first: bool):
+    if ref.dim() != 2 or hyp.dim() != 2:
+        raise RuntimeError("ref and hyp must be 2 dimensional")  # _string.py:166-167
+    device = _cabi.require_hip(ref, hyp)
+    ref, hyp = ref.detach(), hyp.detach()  # _string.py:186-187
+    if ref.dtype != torch.long:
+        ref = ref.long()
+    if hyp.dtype != torch.long:
+        hyp = hyp.long()
+    R, N, rst, rsn = _seq_strides(ref, batch_first)
+    H, N2, hst, hsn = _seq_strides(hyp, batch_first)
+    if N != N2:
+        raise RuntimeError("ref has batch size {}, but hyp has {}".format(N, N2))  # :191-194
+    return device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N
+
+
+_NO_EOS_MSG = (
+    "include_eos=True, but a transcription in {} did not contain the eos symbol ({}). "
+    "To suppress this warning, set warn=False"
+)
+
+
+def _emit_warnings(flags: int, eos, prefix: bool):
+    if flags & _cabi.WARN_REF_NO_EOS:
+        warnings.warn(_NO_EOS_MSG.format("ref", eos))  # _string.py:202-207
+    if flags & _cabi.WARN_HYP_NO_EOS:
+        warnings.warn(_NO_EOS_MSG.format("hyp", eos))  # _string.py:212-217
+    if flags & _cabi.WARN_EMPTY_REF:
+        if prefix:  # _string.py:362-367
+            warnings.warn(
+                "ref contains empty transcripts. Error rates will be 0 for prefixes of "
+                "length 0, 1 otherwise. To suppress this warning, set warn=False"
+            )
+        else:  # _string.py:399-404
+            warnings.warn(
+                "ref contains empty transcripts. Error rates for entries will be 1 if "
+                "any insertion and 0 otherwise. To suppress this warning, set warn=False"
+            )
+
+
+def _string_matching(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int],
+    include_eos: bool,
+    batch_first: bool,
+    ins_cost: float,
+    del_cost: float,
+    sub_cost: float,
+    warn: bool,
+    norm: bool = False,
+    return_prf_dsts: bool = False,
+    exclude_last: bool = False,
+    padding: int = config.INDEX_PAD_VALUE,
+    return_mistakes: bool = False,
+) -> torch.Tensor:
+    """FINAL / PREFIX flavours of the reference's ``_string_matching`` (_string.py:146-406)."""
+    device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N = _prep(ref, hyp, batch_first)
+    uniform = ins_cost == del_cost == sub_cost > 0.0
+    if return_mistakes and not uniform and warn:  # _string.py:175-180
+        warnings.warn(
+            "The behaviour for non-uniform error rates has changed after v0.3.0. Please "
+            "switch to edit_distance functions for old behaviour. Set warn=False to "
+            "suppress this warning"
+        )
+    if return_prf_dsts:
+        Hout = H + (0 if exclude_last else 1)
+        if Hout == 0:
+            raise RuntimeError("hyp has no steps to compute prefixes of")
+        out = torch.empty((Hout, N), device=device, dtype=torch.float)
+        out_sh, out_sn = out.stride(0), out.stride(1)
+        mode = _cabi.MODE_PREFIX
+    else:
+        out = torch.empty((N,), device=device, dtype=torch.float)
+        out_sh, out_sn = 0, 1
+        mode = _cabi.MODE_FINAL
+    with torch.cuda.device(device):
+        status = torch.zeros(1, device=device, dtype=torch.int32) if warn else None
+        rc = _cabi.lib().pdt_lev(
+            _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
+            int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
+            float(ins_cost), float(del_cost), float(sub_cost), int(norm), mode,
+            int(exclude_last), float(padding), int(return_mistakes),
+            _cabi.ptr(out), out_sh, out_sn, 0, 0, _cabi.ptr(status),
+            _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_lev")
+    if warn:
+        flags = int(status.item())
+        if flags:
+            _emit_warnings(flags, eos, return_prf_dsts)
+    if return_prf_dsts and batch_first:
+        out = out.t()  # _string.py:387-388
+    return out
+
+
+def error_rate(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = False,
+    norm: bool = True,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`ErrorRate` (reference _string.py:409-434)."""
+    return _string_matching(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn,
+        norm=norm, return_mistakes=True,
+    )  # fmt: skip
+
+
+def edit_distance(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = False,
+    norm: bool = False,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`EditDistance` (reference _string.py:437-461)."""
+    return _string_matching(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn, norm=norm
+    )
+
+
+def prefix_error_rates(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = True,
+    norm: bool = True,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    padding: int = config.INDEX_PAD_VALUE,
+    exclude_last: bool = False,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`PrefixErrorRates` (reference _string.py:520-550)."""
+    return _string_matching(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn,
+        norm=norm, return_prf_dsts=True, exclude_last=exclude_last, padding=padding,
+        return_mistakes=True,
+    )  # fmt: skip
+
+
+def prefix_edit_distances(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = True,
+    norm: bool = False,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    padding: int = config.INDEX_PAD_VALUE,
+    exclude_last: bool = False,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`PrefixEditDistances` (reference _string.py:553-583)."""
+    return _string_matching(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn,
+        norm=norm, return_prf_dsts=True, exclude_last=exclude_last, padding=padding,
+        return_mistakes=False,
+    )  # fmt: skip
+
+
+def optimal_completion(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = True,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    padding: int = config.INDEX_PAD_VALUE,
+    exclude_last: bool = False,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`OptimalCompletion` (reference _string.py:464-517).
+
+    Two kernels with one host read-back in between, like the reference's
+    ``counts.max().item()`` (:511): the DP emits per-prefix class bitmasks plus the
+    maximum set size ``C``; the expansion writes the ``(H', N, C)`` int64 targets.
+    """
+    device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N = _prep(ref, hyp, batch_first)
+    Hout = H + (0 if exclude_last else 1)
+    if Hout == 0:
+        raise RuntimeError("hyp has no steps to compute prefixes of")
+    L = _cabi.lib()
+    W = int(L.pdt_oc_mask_words(R))
+    with torch.cuda.device(device):
+        bitmask = torch.empty((Hout, N, W), device=device, dtype=torch.int32)
+        class_tokens = torch.empty((N, max(R, 1)), device=device, dtype=torch.long)
+        scal = torch.zeros(2, device=device, dtype=torch.int32)  # [max_count, status]
+        stream = _cabi.stream_ptr(device)
+        rc = L.pdt_oc_mask(
+            _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
+            int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
+            float(ins_cost), float(del_cost), float(sub_cost), int(exclude_last),
+            _cabi.ptr(bitmask), _cabi.ptr(class_tokens), scal.data_ptr(),
+            scal.data_ptr() + 4, stream,
+        )  # fmt: skip
+        _cabi.check(rc, "pdt_oc_mask")
+        C, flags = (int(x) for x in scal.tolist())  # the one host sync (:511)
+        if warn and flags:
+            _emit_warnings(flags, eos, True)
+        targets = torch.empty((Hout, N, C), device=device, dtype=torch.long)
+        if C > 0 and N > 0:
+            rc = L.pdt_oc_expand(
+                _cabi.ptr(bitmask), _cabi.ptr(class_tokens), R, Hout, N,
+                C, int(padding), _cabi.ptr(targets), targets.stride(0), targets.stride(1), stream,
+            )  # fmt: skip
+            _cabi.check(rc, "pdt_oc_expand")
+    if batch_first:
+        targets = targets.transpose(0, 1)  # _string.py:515-516
+    return targets
+
+
+# ---------------------------------------------------------------------------------------
+# Modules (reference _string.py:45-134, :680-1166): constructor validation with argcheck,
+# plain attributes listed in __constants__, forward = the functional with those attributes.
+# ---------------------------------------------------------------------------------------
+
+
+class FillAfterEndOfSequence(torch.nn.Module):
+    """Fill after the first end-of-sequence token with a value (_string.py:45-134)."""
+
+    __constants__ = "eos", "dim", "fill"
+
+    def __init__(self, eos: int, dim: int = 0, fill: Optional[float] = None) -> None:
+        eos = argcheck.is_int(eos, "eos")
+        dim = argcheck.is_int(dim, "dim")
+        fill = float(eos) if fill is None else argcheck.is_float(fill, "fill")
+        super().__init__()
+        self.eos, self.dim, self.fill = eos, dim, fill
+
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+    def forward(self, tokens: torch.Tensor, value: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return fill_after_eos(tokens, self.eos, self.dim, self.fill, value)
+
+
+class _StringMatching(torch.nn.Module):
+    __constants__ = ("eos", "include_eos", "batch_first", "ins_cost", "del_cost", "sub_cost", "warn")
+
+    def __init__(self, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn):
+        eos = argcheck.is_int(eos, "eos", True)
+        include_eos = argcheck.is_bool(include_eos, "include_eos")
+        batch_first = argcheck.is_bool(batch_first, "batch_first")
+        ins_cost = argcheck.is_float(ins_cost, "ins_cost")
+        del_cost = argcheck.is_float(del_cost, "del_cost")
+        sub_cost = argcheck.is_float(sub_cost, "sub_cost")
+        warn = argcheck.is_bool(warn, "warn")
+        super().__init__()
+        self.eos, self.include_eos, self.batch_first = eos, include_eos, batch_first
+        self.ins_cost, self.del_cost, self.sub_cost, self.warn = ins_cost, del_cost, sub_cost, warn
+
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+
+class EditDistance(_StringMatching):
+    """Weighted Levenshtein distance between ref and hyp (_string.py:722-797)."""
+
+    __constants__ = (
+        "eos", "include_eos", "norm", "batch_first", "ins_cost", "del_cost", "sub_cost", "warn",
+    )  # fmt: skip
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = False,
+        norm: bool = False,
+        batch_first: bool = False,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        warn: bool = True,
+    ):
+        norm = argcheck.is_bool(norm, "norm")
+        super().__init__(eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn)
+        self.norm = norm
+
+    def forward(self, ref: torch.Tensor, hyp: torch.Tensor) -> torch.Tensor:
+        return edit_distance(
+            ref, hyp, self.eos, self.include_eos, self.norm, self.batch_first,
+            self.ins_cost, self.del_cost, self.sub_cost, self.warn,
+        )  # fmt: skip
+
+
+class ErrorRate(_StringMatching):
+    """Number of mistakes on the cheapest alignment, optionally / ref length (_string.py:888-967)."""
+
+    __constants__ = EditDistance.__constants__
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = False,
+        norm: bool = True,
+        batch_first: bool = False,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        warn: bool = True,
+    ):
+        norm = argcheck.is_bool(norm, "norm")
+        super().__init__(eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn)
+        self.norm = norm
+
+    def forward(self, ref: torch.Tensor, hyp: torch.Tensor) -> torch.Tensor:
+        return error_rate(
+            ref, hyp, self.eos, self.include_eos, self.norm, self.batch_first,
+            self.ins_cost, self.del_cost, self.sub_cost, self.warn,
+        )  # fmt: skip
+
+
+class _Prefix(_StringMatching):
+    __constants__ = (
+        "eos", "include_eos", "norm", "batch_first", "ins_cost", "del_cost", "sub_cost",
+        "padding", "exclude_last", "warn",
+    )  # fmt: skip
+
+    def __init__(self, eos, include_eos, norm, batch_first, ins_cost, del_cost, sub_cost,
+                 padding, exclude_last, warn):  # fmt: skip
+        norm = argcheck.is_bool(norm, "norm")
+        padding = argcheck.is_int(padding, "padding")
+        exclude_last = argcheck.is_bool(exclude_last, "exclude_last")
+        super().__init__(eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn)
+        self.norm, self.padding, self.exclude_last = norm, padding, exclude_last
+
+
+class PrefixEditDistances(_Prefix):
+    """Edit distance between ref and every prefix of hyp (_string.py:800-885)."""
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = True,
+        norm: bool = False,
+        batch_first: bool = False,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        padding: int = config.INDEX_PAD_VALUE,
+        exclude_last: bool = False,
+        warn: bool = True,
+    ):
+        super().__init__(eos, include_eos, norm, batch_first, ins_cost, del_cost, sub_cost,
+                         padding, exclude_last, warn)  # fmt: skip
+
+    def forward(self, ref: torch.Tensor, hyp: torch.Tensor) -> torch.Tensor:
+        return prefix_edit_distances(
+            ref, hyp, self.eos, self.include_eos, self.norm, self.batch_first, self.ins_cost,
+            self.del_cost, self.sub_cost, self.padding, self.exclude_last, self.warn,
+        )  # fmt: skip
+
+
+class PrefixErrorRates(_Prefix):
+    """Error rate between ref and every prefix of hyp (_string.py:970-1049)."""
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = True,
+        norm: bool = True,
+        batch_first: bool = False,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        padding: int = config.INDEX_PAD_VALUE,
+        exclude_last: bool = False,
+        warn: bool = True,
+    ):
+        super().__init__(eos, include_eos, norm, batch_first, ins_cost, del_cost, sub_cost,
+                         padding, exclude_last, warn)  # fmt: skip
+
+    def forward(self, ref: torch.Tensor, hyp: torch.Tensor) -> torch.Tensor:
+        return prefix_error_rates(
+            ref, hyp, self.eos, self.include_eos, self.norm, self.batch_first, self.ins_cost,
+            self.del_cost, self.sub_cost, self.padding, self.exclude_last, self.warn,
+        )  # fmt: skip
+
+
+class OptimalCompletion(_StringMatching):
+    """Optimal next tokens of every hyp prefix w.r.t. ref (_string.py:1052-1166)."""
+
+    __constants__ = (
+        "eos", "include_eos", "batch_first", "ins_cost", "del_cost", "sub_cost", "padding",
+        "exclude_last", "warn",
+    )  # fmt: skip
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = True,
+        batch_first: bool = False,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        padding: int = config.INDEX_PAD_VALUE,
+        exclude_last: bool = False,
+        warn: bool = True,
+    ):
+        padding = argcheck.is_int(padding, "padding")
+        exclude_last = argcheck.is_bool(exclude_last, "exclude_last")
+        super().__init__(eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn)
+        self.padding, self.exclude_last = padding, exclude_last
+
+    def forward(self, ref: torch.Tensor, hyp: torch.Tensor) -> torch.Tensor:
+        return optimal_completion(
+            ref, hyp, self.eos, self.include_eos, self.batch_first, self.ins_cost,
+            self.del_cost, self.sub_cost, self.padding, self.exclude_last, self.warn,
+        )  # fmt: skip

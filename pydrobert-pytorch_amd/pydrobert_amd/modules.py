@@ -1,0 +1,20 @@
+"""Module namespace -- mirrors ``pydrobert.torch.modules`` (modules.py:28-124) for the
+operators on the MI355X hot path."""
+
+from ._string import (
+    EditDistance,
+    ErrorRate,
+    FillAfterEndOfSequence,
+    OptimalCompletion,
+    PrefixEditDistances,
+    PrefixErrorRates,
+)
+
+__all__ = [
+    "EditDistance",
+    "ErrorRate",
+    "FillAfterEndOfSequence",
+    "OptimalCompletion",
+    "PrefixEditDistances",
+    "PrefixErrorRates",
+]

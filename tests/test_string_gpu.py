@@ -1,0 +1,265 @@
+"""GPU parity of the edit-distance family: HIP kernels (through the C ABI) vs the oracle.
+
+Bit-exact comparison (float32 ``==``) on seeded random inputs at sizes the oracle
+finishes in seconds; the structure follows the reference's tests/test_string.py.
+"""
+import warnings
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pydrobert_amd import functional as F
+from pydrobert_amd import modules as M
+
+pytestmark = pytest.mark.gpu
+
+COSTS = [
+    (1.0, 1.0, 1.0),
+    (2.0, 2.0, 2.0),
+    (3.0, 3.0, 4.0),  # NIST
+    (2.0, 0.5, 1.0),
+    (0.5, 1.0, 0.5),
+    (1.0, 2.0, 3.0),
+    (0.1, 0.7, 1.3),  # not exactly representable: exercises the exact-unroll path
+    (1.1, 1.1, 1.1),
+]
+
+NAMES = ["error_rate", "edit_distance", "prefix_error_rates", "prefix_edit_distances",
+         "optimal_completion"]  # fmt: skip
+
+
+def _call_both(name, ref, hyp, device, **kw):
+    exp = getattr(oracle, name)(ref, hyp, **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        act = getattr(F, name)(
+            torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device), warn=False, **kw
+        )
+    torch.cuda.synchronize()
+    return exp, act.cpu().numpy()
+
+
+def _assert_same(exp, act, what):
+    assert exp.shape == act.shape, (what, exp.shape, act.shape)
+    assert exp.dtype == act.dtype, (what, exp.dtype, act.dtype)
+    assert np.array_equal(exp, act), (what, np.argwhere(exp != act)[:5])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_random_small_all_options(device, name):
+    rng = np.random.default_rng(zlib.adler32(name.encode()))
+    for it in range(60):
+        N = int(rng.integers(1, 9))
+        R = int(rng.integers(1, 14))
+        H = int(rng.integers(1, 14))
+        V = int(rng.integers(2, 5))
+        eos = None if rng.random() < 0.3 else int(rng.integers(0, V))
+        bf = bool(rng.integers(0, 2))
+        shape_r, shape_h = ((N, R), (N, H)) if bf else ((R, N), (H, N))
+        ref = rng.integers(0, V, shape_r)
+        hyp = rng.integers(0, V, shape_h)
+        c = COSTS[int(rng.integers(0, len(COSTS)))]
+        kw = dict(eos=eos, include_eos=bool(rng.integers(0, 2)), batch_first=bf,
+                  ins_cost=c[0], del_cost=c[1], sub_cost=c[2])  # fmt: skip
+        if name in ("error_rate", "edit_distance"):
+            kw["norm"] = bool(rng.integers(0, 2))
+        elif name.startswith("prefix"):
+            kw["norm"] = bool(rng.integers(0, 2))
+            kw["exclude_last"] = bool(rng.integers(0, 2))
+            kw["padding"] = int(rng.integers(-5, 0))
+        else:
+            kw["exclude_last"] = bool(rng.integers(0, 2))
+            kw["padding"] = int(rng.integers(-5, 0))
+        exp, act = _call_both(name, ref, hyp, device, **kw)
+        _assert_same(exp, act, (name, it, kw))
+
+
+@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("costs", COSTS, ids=lambda c: "c{}_{}_{}".format(*c))
+def test_medium_ragged(device, name, costs):
+    """Ragged lengths around the 64-lane strip boundaries, tie-rich alphabet."""
+    rng = np.random.default_rng(1234)
+    N, R, H, V = 24, 150, 137, 5
+    if costs == (0.1, 0.7, 1.3) or name == "optimal_completion":
+        N = 8
+    eos = V
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    rl = rng.integers(0, R + 1, N)
+    hl = rng.integers(0, H + 1, N)
+    rl[:4] = [0, 64, 65, 128]
+    hl[:4] = [5, 0, 63, 64]
+    for n in range(N):
+        if rl[n] < R:
+            ref[rl[n], n] = eos
+        if hl[n] < H:
+            hyp[hl[n], n] = eos
+    kw = dict(eos=eos, ins_cost=costs[0], del_cost=costs[1], sub_cost=costs[2])
+    exp, act = _call_both(name, ref, hyp, device, **kw)
+    _assert_same(exp, act, (name, costs))
+
+
+@pytest.mark.parametrize("name", ["error_rate", "edit_distance", "prefix_error_rates"])
+def test_long_reference_chunks(device, name):
+    """R > 512 makes the skewed kernel sweep several 512-column chunks."""
+    rng = np.random.default_rng(7)
+    N, R, H, V = 6, 1100, 300, 6
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    ref[700, 1] = V
+    ref[512, 2] = V
+    ref[513, 3] = V
+    hyp[100, 4] = V
+    for costs in [(1.0, 1.0, 1.0), (3.0, 3.0, 4.0)]:
+        kw = dict(eos=V, ins_cost=costs[0], del_cost=costs[1], sub_cost=costs[2])
+        exp = getattr(oracle, name)(ref, hyp, faithful=False, **kw)
+        act = getattr(F, name)(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device),
+                               warn=False, **kw).cpu().numpy()  # fmt: skip
+        _assert_same(exp, act, (name, costs))
+
+
+def test_wide_tokens_and_negative_tokens(device):
+    """int64 tokens outside int32 take the first-occurrence remap path; negatives are fine."""
+    rng = np.random.default_rng(11)
+    N, R, H = 5, 70, 66
+    base = np.array([-(2**40), -2, -1, 0, 2**31, 2**33 + 7, 2**62], dtype=np.int64)
+    ref = base[rng.integers(0, len(base), (R, N))]
+    hyp = base[rng.integers(0, len(base), (H, N))]
+    for name in NAMES:
+        exp, act = _call_both(name, ref, hyp, device, eos=-1, ins_cost=3.0, del_cost=3.0, sub_cost=4.0)
+        _assert_same(exp, act, name)
+
+
+def test_config1_shape_bitexact(device):
+    """BASELINE config 1: N=64, T=128, V=32, unit costs, norm=True."""
+    rng = np.random.default_rng(0x5EED0001)
+    ref = rng.integers(0, 32, (128, 64))
+    hyp = rng.integers(0, 32, (128, 64))
+    for name in NAMES:
+        exp, act = _call_both(name, ref, hyp, device)
+        _assert_same(exp, act, name)
+
+
+def test_known_answers(device):
+    """The reference's hand-computed pairs (tests/test_string.py:171-221), restated."""
+    eos = 0
+    pairs = (
+        ((1, 2, 3), (1, 2, 3), 0), ((2, 3), (1, 2, 3), 1), ((1, 3), (1, 2, 3), 1),
+        ((3,), (1, 2, 3), 2), ((1, 2, 3), (1, 3), 1), ((1, 2, 3), (1, 2), 1),
+        ((1, 2, 3), (1,), 2), ((1, 3, 1, 2, 3), (1, 2, 3), 2), ((1, 2, 3), (4, 5, 6), 3),
+        ((2, 2, 2), (2,), 2), (tuple(), (1,), 1), (tuple(), tuple(), 0),
+    )  # fmt: skip
+    for include_eos in (0, 1):
+        for batch_first in (False, True):
+            seqs_r = [torch.tensor(x[0] + (eos,) * include_eos, dtype=torch.long) for x in pairs]
+            seqs_h = [torch.tensor(x[1] + (eos,) * include_eos, dtype=torch.long) for x in pairs]
+            ref = torch.nn.utils.rnn.pad_sequence(seqs_r, padding_value=eos, batch_first=batch_first)
+            hyp = torch.nn.utils.rnn.pad_sequence(seqs_h, padding_value=eos, batch_first=batch_first)
+            exp = torch.tensor([float(x[2]) for x in pairs])
+            ref_lens = torch.tensor([len(x[0]) + include_eos for x in pairs])
+            hyp_lens = torch.tensor([len(x[1]) + include_eos for x in pairs])
+            exp_n = torch.where(ref_lens == 0, hyp_lens.ne(0).float(), exp / ref_lens.float())
+            for cls in (M.EditDistance, M.ErrorRate):
+                for norm in (False, True):
+                    mod = cls(eos=eos, warn=False, norm=norm, include_eos=bool(include_eos),
+                              batch_first=batch_first)  # fmt: skip
+                    act = mod(ref.to(device), hyp.to(device)).cpu()
+                    assert torch.equal(exp_n if norm else exp, act)
+
+
+def test_optimal_completion_strings(device):
+    """OCD known answers (reference tests/test_string.py:115-168), restated."""
+    eos, padding = ord("#"), -1
+    triplets = (
+        ("sunday#", "saturday#", ["s", "u", "un", "und", "n", "nd", "a", "y", "#", ""]),
+        ("sunday#", "satrapy#", ["s", "u", "un", "und", "unda", "y", "y#", "#", ""]),
+        ("abc#", "abc#", ["a", "b", "c", "#", ""]),
+        ("foot#", "bot#", ["f", "fo", "o", "ot#", ""]),
+        ("abc#", "def#", ["a", "ab", "abc", "abc#", ""]),
+    )
+    for include_eos in (True, False):
+        for batch_first in (True, False):
+            for exclude_last in (True, False):
+                ref = torch.nn.utils.rnn.pad_sequence(
+                    [torch.tensor([ord(c) for c in w]) for (w, _, _) in triplets],
+                    batch_first=batch_first, padding_value=padding).to(device)  # fmt: skip
+                hyp = torch.nn.utils.rnn.pad_sequence(
+                    [torch.tensor([ord(c) for c in w]) for (_, w, _) in triplets],
+                    batch_first=batch_first, padding_value=eos).to(device)  # fmt: skip
+                oc = M.OptimalCompletion(eos=eos, padding=padding, batch_first=batch_first,
+                                         exclude_last=exclude_last, include_eos=include_eos)  # fmt: skip
+                act = oc(ref, hyp).cpu()
+                if not batch_first:
+                    act = act.transpose(0, 1)
+                assert act.shape[0] == len(triplets)
+                for act_bt, (_, _, exp_bt) in zip(act, triplets):
+                    if not include_eos:
+                        exp_bt = [nexts.replace("#", "") for nexts in exp_bt[:-1]]
+                    if exclude_last:
+                        exp_bt = exp_bt[:-1]
+                    assert act_bt.shape[0] >= len(exp_bt)
+                    assert torch.all(act_bt[len(exp_bt):].eq(padding))
+                    for a, e in zip(act_bt, exp_bt):
+                        a = a.masked_select(a.ne(padding))
+                        assert sorted(e) == sorted(chr(i) for i in a.tolist())
+
+
+def test_warnings_and_errors(device):
+    ref = torch.tensor([[1, 2, 3], [1, 2, 0]], device=device).t().contiguous()
+    hyp = torch.tensor([[1, 2, 3], [1, 0, 0]], device=device).t().contiguous()
+    with pytest.warns(UserWarning, match="did not contain the eos"):
+        F.error_rate(ref, hyp, eos=0, include_eos=True)
+    with pytest.warns(UserWarning, match="non-uniform"):
+        F.error_rate(ref, hyp, ins_cost=2.0)
+    empty = torch.zeros((3, 2), dtype=torch.long, device=device)
+    with pytest.warns(UserWarning, match="empty transcripts"):
+        F.error_rate(empty, hyp, eos=0)
+    with pytest.raises(RuntimeError, match="2 dimensional"):
+        F.error_rate(ref[0], hyp)
+    with pytest.raises(RuntimeError, match="batch size"):
+        F.error_rate(ref, hyp[:, :1])
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.error_rate(ref.cpu(), hyp.cpu())
+    with pytest.raises(ValueError):
+        M.ErrorRate(eos="a")
+
+
+def test_full_size_properties(device):
+    """BASELINE config 2 size (N=4096, T=512, V=256): size-independent properties.
+
+    * prefix row h equals error_rate of the hypothesis truncated to h tokens (spot rows);
+    * the last valid prefix entry equals error_rate;
+    * d(x, x) = 0; 0 <= d <= max(R, H); |d(ref,hyp) - d(hyp,ref)| = 0 for unit costs;
+    * every optimal-completion set at h=0 is {ref[0]}.
+    """
+    N, T, V = 4096, 512, 256
+    g = torch.Generator(device="cpu").manual_seed(0x5EED0002)
+    ref = torch.randint(0, V, (T, N), generator=g).to(device)
+    hyp = torch.randint(0, V, (T, N), generator=g).to(device)
+    d = F.edit_distance(ref, hyp, warn=False)
+    assert torch.equal(F.edit_distance(hyp, ref, warn=False), d)
+    assert torch.equal(F.edit_distance(ref, ref, warn=False), torch.zeros_like(d))
+    assert d.min() >= 0 and d.max() <= T
+    er = F.error_rate(ref, hyp, warn=False)
+    assert torch.equal(er, d / T)
+    pre = F.prefix_error_rates(ref, hyp, warn=False)
+    assert pre.shape == (T + 1, N)
+    assert torch.equal(pre[-1], er)
+    assert torch.equal(pre[0], torch.ones_like(er))
+    for h in (1, 63, 64, 65, 300):
+        assert torch.equal(F.error_rate(ref, hyp[:h], warn=False), pre[h])
+    # a sample of utterances against the oracle
+    idx = torch.arange(0, N, 512)
+    exp = oracle.prefix_error_rates(ref[:, idx].cpu().numpy(), hyp[:, idx].cpu().numpy(), faithful=False)
+    assert np.array_equal(exp, pre[:, idx].cpu().numpy())
+    oc = F.optimal_completion(ref[:, :256], hyp[:, :256], warn=False)
+    assert oc.shape[:2] == (T + 1, 256)
+    assert torch.equal(oc[0, :, 0], ref[0, :256])
+    assert (oc[0, :, 1:] == -100).all()
+    exp = oracle.optimal_completion(ref[:, :4].cpu().numpy(), hyp[:, :4].cpu().numpy(), faithful=False)
+    got = oc[:, :4].cpu().numpy()
+    C = exp.shape[2]
+    assert np.array_equal(exp, got[:, :, :C]) and (got[:, :, C:] == -100).all()
