@@ -43,6 +43,26 @@ int64_t pdt_oracle_optimal_completion_from_mask(const uint8_t *mask, const int64
                                                 int64_t padding, int64_t C,
                                                 int64_t *targets);
 
+/* ---- decoding (pdt_oracle_decoding.c; reference _decoding.py) ---- */
+int64_t pdt_oracle_beam_search_advance(const float *log_probs_t, int64_t N, int64_t Kp,
+                                       int64_t V, int64_t width, const float *log_probs_prev,
+                                       const int64_t *y_prev, int64_t S,
+                                       const int64_t *y_prev_lens, int64_t *y_next,
+                                       int64_t *y_next_lens, float *log_probs_next,
+                                       int64_t *next_src);
+
+int pdt_oracle_ctc_prefix_search_advance(
+    const float *ext_probs_t, int64_t ext_sn, int64_t ext_sk, const float *nonext_probs_t,
+    const float *blank_probs_t, int64_t N, int64_t Kp, int64_t V, int64_t width,
+    const float *nb_probs_prev, const float *b_probs_prev, const int64_t *y_prev, int64_t S,
+    const int64_t *y_prev_last, const int64_t *y_prev_lens, const uint8_t *prev_is_prefix,
+    int64_t *y_next, int64_t *y_next_last, int64_t *y_next_lens, float *nb_probs_next,
+    float *b_probs_next, uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext);
+
+int pdt_oracle_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t Vp1,
+                                 const int64_t *lens, int64_t width, int64_t *y,
+                                 int64_t *y_lens, float *y_probs);
+
 #ifdef __cplusplus
 }
 #endif
