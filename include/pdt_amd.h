@@ -89,6 +89,27 @@ int pdt_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int64_t 
                   int64_t Hout, int64_t N, int64_t C, int64_t padding, int64_t *targets,
                   int64_t tgt_sh, int64_t tgt_sn, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * CTC prefix beam search without a language model: CTCPrefixSearch(width)(logits, lens)
+ * (reference _decoding.py:1064-1202; the per-frame step is ctc_prefix_search_advance,
+ * :636-934; the softmax of :1093 is fused).
+ *
+ *   logits (T, N, V + 1) float32 through element strides, blank = index V.
+ *   lens   (N,) int64 or NULL (all T).  S = number of rows of y = max(lens) (T if NULL).
+ *   y      (S, N, width) int64 contiguous, MUST BE ZERO-FILLED by the caller: rows beyond a
+ *          prefix's length are left untouched (the reference leaves them undefined);
+ *   y_lens (N, width) int64, y_probs (N, width) float32 (probabilities, not logs).
+ *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, width) bytes of scratch
+ *          (the prefix trie: one (parent, token) record per frame and beam entry).
+ *   width <= 32.
+ * ------------------------------------------------------------------------------------- */
+int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t width);
+
+int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st,
+                          int64_t lg_sn, int64_t lg_sv, const int64_t *lens, int64_t width,
+                          int64_t S, int64_t *y, int64_t *y_lens, float *y_probs,
+                          void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,153 @@
+// Wave-level (64-lane) ordering primitives used by the beam-search kernels:
+// order-preserving float keys, bitonic sort of one key per lane, top-64 merge, and
+// "sorted top-M of a V-vector" selection.  No LDS traffic except the small survivor list.
+#pragma once
+#include "pdt_common.hpp"
+
+namespace pdt {
+
+typedef unsigned long long u64;
+
+// monotone float -> uint map (any finite value, +-inf): a < b  <=>  fkey(a) < fkey(b).
+// fkey(x) > 0 for every x, so 0 can serve as "no candidate".
+__device__ __forceinline__ unsigned fkey(float f) {
+  const unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float fkey_inv(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+// (value key, index) -> one u64 whose max is "largest value, then lowest index"
+__device__ __forceinline__ u64 pack_key(unsigned key, unsigned idx) {
+  return ((u64)key << 32) | (u64)(0xffffffffu - idx);
+}
+__device__ __forceinline__ unsigned key_of(u64 k) { return (unsigned)(k >> 32); }
+__device__ __forceinline__ unsigned idx_of(u64 k) { return 0xffffffffu - (unsigned)k; }
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int j) {
+  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, j);
+  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), j);
+  return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+  return ((u64)hi << 32) | lo;
+}
+
+template <typename T>
+__device__ __forceinline__ T shfl_xor_any(T v, int j);
+template <>
+__device__ __forceinline__ u64 shfl_xor_any<u64>(u64 v, int j) { return shfl_xor_u64(v, j); }
+template <>
+__device__ __forceinline__ unsigned shfl_xor_any<unsigned>(unsigned v, int j) {
+  return (unsigned)__shfl_xor((int)v, j);
+}
+
+// bitonic sort of one key per lane, DESCENDING (lane 0 ends with the maximum)
+template <typename T>
+__device__ __forceinline__ T wave_sort_desc(T key) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int k = 2; k <= PDT_WAVE; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const T other = shfl_xor_any<T>(key, j);
+      const bool up = (lane & k) == 0;  // k == 64: always true -> overall descending
+      const bool take_max = ((lane & j) == 0) == up;
+      const T mx = key > other ? key : other, mn = key > other ? other : key;
+      key = take_max ? mx : mn;
+    }
+  }
+  return key;
+}
+
+// cur: sorted descending; add: arbitrary.  Returns the 64 largest of the union, sorted descending.
+__device__ __forceinline__ u64 wave_merge_top64(u64 cur, u64 add) {
+  const int lane = lane_id();
+  add = wave_sort_desc<u64>(add);
+  const u64 rev = shfl_u64(add, PDT_WAVE - 1 - lane);
+  u64 key = cur > rev ? cur : rev;  // bitonic
+#pragma unroll
+  for (int j = PDT_WAVE >> 1; j > 0; j >>= 1) {
+    const u64 other = shfl_xor_u64(key, j);
+    const bool take_max = (lane & j) == 0;
+    const u64 mx = key > other ? key : other, mn = key > other ? other : key;
+    key = take_max ? mx : mn;
+  }
+  return key;
+}
+
+__device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
+  unsigned v = x;
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(1)>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(2)>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_BCAST15, 0xa>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_BCAST31, 0xc>((int)v, 0));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float wave_max_f(float x) { return fkey_inv(wave_max_u32(fkey(x))); }
+__device__ __forceinline__ float wave_sum_f(float x) {
+  float v = x;
+  v += dpp_or<PDT_DPP_ROW_SHR(1)>(v, 0.0f);
+  v += dpp_or<PDT_DPP_ROW_SHR(2)>(v, 0.0f);
+  v += dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(v, 0.0f);
+  v += dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(v, 0.0f);
+  v += dpp_or<PDT_DPP_ROW_BCAST15, 0xa>(v, 0.0f);
+  v += dpp_or<PDT_DPP_ROW_BCAST31, 0xc>(v, 0.0f);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// Sorted (descending by value, ascending by index on ties) top-64 of x[0..V): lane i returns
+// the i-th largest as pack_key(fkey(x[v]), v); lanes beyond V return 0.  x may live in LDS or
+// global memory.  Only the first M <= 64 entries are guaranteed exact (M = how many the
+// caller will consume); smaller M prunes harder.
+//   1. per-lane maximum over a strided slice; the M-th largest lane maximum tau is a lower
+//      bound of the M-th largest element;
+//   2. survivors (>= tau) are compacted into `surv` (LDS, capacity PDT_SURV_CAP);
+//   3. <= 64 survivors: one bitonic sort.  Otherwise (heavy ties / clustered values) a
+//      chunked top-64 merge over the whole vector.
+#define PDT_SURV_CAP 64
+__device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
+                                                       int M, u64 *surv) {
+  const int lane = lane_id();
+  auto X = [&](int v) { return xb[(int64_t)v * sx]; };
+  if (V <= PDT_WAVE) {
+    const u64 k = lane < V ? pack_key(fkey(X(lane)), (unsigned)lane) : 0ull;
+    return wave_sort_desc<u64>(k);
+  }
+  unsigned lmax = 0u;
+  for (int v = lane; v < V; v += PDT_WAVE) lmax = max(lmax, fkey(X(v)));
+  const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
+  const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+  int count = 0;
+  for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
+    const int v = v0 + lane;
+    const unsigned key = v < V ? fkey(X(v)) : 0u;
+    const bool pred = v < V && key >= tau;
+    const u64 b = __ballot(pred);
+    if (b) {
+      const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      if (pred && pos < PDT_SURV_CAP) surv[pos] = pack_key(key, (unsigned)v);
+      count += __popcll(b);
+    }
+  }
+  wave_sync();
+  if (count <= PDT_SURV_CAP) return wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
+  // slow path: too many survivors
+  u64 cur = 0ull;
+  for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
+    const int v = v0 + lane;
+    const unsigned key = v < V ? fkey(X(v)) : 0u;
+    const bool pred = v < V && key >= tau;
+    if (__ballot(pred)) cur = wave_merge_top64(cur, pred ? pack_key(key, (unsigned)v) : 0ull);
+  }
+  return cur;
+}
+__device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv) {
+  return wave_top_sorted_strided(x, 1, V, M, surv);
+}
+
+}  // namespace pdt

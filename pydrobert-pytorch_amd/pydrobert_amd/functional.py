@@ -1,6 +1,7 @@
 """Functional namespace -- mirrors ``pydrobert.torch.functional`` (functional.py:17-95)
 for the operators on the MI355X hot path."""
 
+from ._decoding import ctc_prefix_search
 from ._string import (
     edit_distance,
     error_rate,
@@ -11,6 +12,7 @@ from ._string import (
 )
 
 __all__ = [
+    "ctc_prefix_search",
     "edit_distance",
     "error_rate",
     "fill_after_eos",

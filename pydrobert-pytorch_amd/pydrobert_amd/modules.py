@@ -1,6 +1,7 @@
 """Module namespace -- mirrors ``pydrobert.torch.modules`` (modules.py:28-124) for the
 operators on the MI355X hot path."""
 
+from ._decoding import CTCPrefixSearch
 from ._string import (
     EditDistance,
     ErrorRate,
@@ -11,6 +12,7 @@ from ._string import (
 )
 
 __all__ = [
+    "CTCPrefixSearch",
     "EditDistance",
     "ErrorRate",
     "FillAfterEndOfSequence",
