@@ -110,6 +110,46 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
                           int64_t S, int64_t *y, int64_t *y_lens, float *y_probs,
                           void *workspace, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * ctc_prefix_search_advance (reference _decoding.py:636-934): one CTC prefix-search step with
+ * per-prefix extension probabilities (shallow fusion) and dense histories.
+ * Inputs through element strides (a stride of 0 expresses a broadcast):
+ *   ext (N, Kp, V), nonext (N, V), blank (N,) float32 probabilities;
+ *   nb_prev, b_prev (N, Kp) float32; y_prev (S, N, Kp) int64; y_prev_last, y_prev_lens
+ *   (N, Kp) int64; prev_is_prefix (N, Kp, Kp) bool bytes.
+ * Outputs, contiguous: y_next (S + 1, N, width) int64 (entries beyond y_next_lens
+ *   unspecified, as in the reference); y_next_last, y_next_lens, next_src (N, width) int64;
+ *   nb_next, b_next (N, width) float32; next_is_prefix (N, width, width) and next_is_nonext
+ *   (N, width) bool bytes.  Kp, width <= 32.
+ * ------------------------------------------------------------------------------------- */
+int pdt_ctc_prefix_search_advance(
+    const float *ext, int64_t ext_sn, int64_t ext_sk, int64_t ext_sv, const float *nonext,
+    int64_t ne_sn, int64_t ne_sv, const float *blank, int64_t bl_sn, int64_t N, int64_t Kp,
+    int64_t V, int64_t width, const float *nb_prev, int64_t nb_sn, int64_t nb_sk,
+    const float *b_prev, int64_t b_sn, int64_t b_sk, const int64_t *y_prev, int64_t S,
+    int64_t yp_ss, int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_last, int64_t la_sn,
+    int64_t la_sk, const int64_t *y_prev_lens, int64_t le_sn, int64_t le_sk,
+    const uint8_t *prev_is_prefix, int64_t ip_sn, int64_t ip_sa, int64_t ip_sb, int64_t *y_next,
+    int64_t *y_next_last, int64_t *y_next_lens, float *nb_next, float *b_next,
+    uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext, void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * beam_search_advance (reference _decoding.py:41-155): one beam-search step.
+ *   log_probs_t (N, Kp, V), log_probs_prev (N, Kp) float32; y_prev (S, N, Kp) int64;
+ *   y_prev_lens (N, Kp) int64 or NULL (all S).  S_out = rows of y_next: S + 1 when
+ *   y_prev_lens is NULL or some length equals S (the caller decides, :133-135), else S.
+ * Outputs, contiguous: y_next (S_out, N, width), y_next_lens / next_src (N, width) int64,
+ *   log_probs_next (N, width).  Slots beyond min(width, Kp * V) get -inf / length 0 / source 0.
+ *   Kp, width <= 64.
+ * ------------------------------------------------------------------------------------- */
+int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_sk, int64_t lt_sv,
+                            int64_t N, int64_t Kp, int64_t V, int64_t width,
+                            const float *log_probs_prev, int64_t lp_sn, int64_t lp_sk,
+                            const int64_t *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn,
+                            int64_t yp_sk, const int64_t *y_prev_lens, int64_t le_sn,
+                            int64_t le_sk, int64_t S_out, int64_t *y_next, int64_t *y_next_lens,
+                            float *log_probs_next, int64_t *next_src, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

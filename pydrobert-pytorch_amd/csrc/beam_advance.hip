@@ -1,0 +1,292 @@
+// Step functions of the two beam searches for gfx950, one wave per batch element:
+//   * pdt_ctc_prefix_search_advance -- ctc_prefix_search_advance (reference
+//     _decoding.py:636-934) with arbitrary per-prefix extension probabilities (language-model
+//     fusion) and dense (S, N, K') histories, as the reference's signature requires;
+//   * pdt_beam_search_advance       -- beam_search_advance (_decoding.py:41-155).
+// Both select the top-K of K'*V (+K') candidates WITHOUT materialising them: each old prefix
+// gets the sorted list of its best tokens (wave_top_sorted), then K rounds of a wave-wide
+// max-reduce over the list heads pick the winners in order.  Ties go to the lowest flat
+// candidate index (the reference's torch.topk leaves them unspecified).
+#include "ctc_frame.hpp"
+
+namespace pdt {
+
+struct CtcAdvArgs {
+  const float *ext;     int64_t ext_sn, ext_sk, ext_sv;   // (N, Kp, V)
+  const float *nonext;  int64_t ne_sn, ne_sv;             // (N, V)
+  const float *blank;   int64_t bl_sn;                    // (N,)
+  const float *nb_prev; const float *b_prev; int64_t pb_sn, pb_sk, pbb_sn, pbb_sk;  // (N, Kp)
+  const int64_t *y_prev; int64_t yp_ss, yp_sn, yp_sk;     // (S, N, Kp)
+  const int64_t *last;  int64_t la_sn, la_sk;             // (N, Kp)
+  const int64_t *lens;  int64_t le_sn, le_sk;             // (N, Kp)
+  const uint8_t *isp;   int64_t ip_sn, ip_sa, ip_sb;      // (N, Kp, Kp) bool
+  int N, Kp, V, W, S;
+  // outputs, contiguous
+  int64_t *y_next;      // (S + 1, N, W)
+  int64_t *y_next_last, *y_next_lens, *next_src;  // (N, W)
+  float *nb_next, *b_next;                        // (N, W)
+  uint8_t *next_isp;                              // (N, W, W)
+  uint8_t *next_nonext;                           // (N, W)
+  int lds_per_wave, waves_per_wg;
+};
+
+__global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int64_t n = (int64_t)blockIdx.x * a.waves_per_wg + wave;
+  if (n >= a.N) return;
+  const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
+  const int RS = W > Kp ? W : Kp;
+  unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
+  u64 *surv = reinterpret_cast<u64 *>(base);
+  float *p = reinterpret_cast<float *>(surv + PDT_SURV_CAP);
+  int *tl = reinterpret_cast<int *>(p + ((V + 1 + 3) & ~3));
+  int *rem = tl + Kp * PDT_WAVE;
+  int *srcs = rem + RS * RS;
+
+  for (int v = lane; v < V; v += PDT_WAVE) p[v] = a.nonext[n * a.ne_sn + v * a.ne_sv];
+  if (lane == 0) p[V] = a.blank[n * a.bl_sn];
+  Beam bm;
+  bm.nb = lane < Kp ? a.nb_prev[n * a.pb_sn + lane * a.pb_sk] : -PDT_INF;
+  bm.b = lane < Kp ? a.b_prev[n * a.pbb_sn + lane * a.pbb_sk] : -PDT_INF;
+  bm.last = lane < Kp ? (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)-1), (int64_t)V) : 0;
+  bm.len = lane < Kp ? (int)a.lens[n * a.le_sn + lane * a.le_sk] : 0;
+  bm.node = -1;
+  u64 m = 0ull;
+  if (lane < Kp)
+    for (int b = 0; b < Kp; ++b)
+      if (a.isp[n * a.ip_sn + lane * a.ip_sa + b * a.ip_sb]) m |= 1ull << b;
+  bm.isp = m;
+  wave_sync();
+
+  DenseCtx dc;
+  dc.ext = a.ext + n * a.ext_sn;
+  dc.ext_sk = a.ext_sk;
+  dc.ext_sv = a.ext_sv;
+  dc.y_prev = a.y_prev + n * a.yp_sn;
+  dc.yp_ss = a.yp_ss;
+  dc.yp_sk = a.yp_sk;
+  dc.S = S;
+  CtcArgs dummy{};
+  dummy.N = a.N;
+  int new_src, new_tok, new_kind;
+  const int old_len = bm.len;
+  (void)old_len;
+  ctc_frame<true>(bm, p, 1.0f, V, W, Kp, RS, 0, n, dummy, dc, surv, tl, rem, nullptr, nullptr,
+                  new_src, new_tok, new_kind);
+
+  // ---- outputs (:855-934) ----------------------------------------------------------------
+  if (lane < W) {
+    const bool valid = new_kind >= 0;
+    a.y_next_last[n * W + lane] = bm.last;
+    a.y_next_lens[n * W + lane] = bm.len;
+    a.nb_next[n * W + lane] = bm.nb;
+    a.b_next[n * W + lane] = bm.b;
+    a.next_src[n * W + lane] = valid ? new_src : 0;
+    a.next_nonext[n * W + lane] = (uint8_t)(new_kind == 2);
+    for (int b = 0; b < W; ++b) a.next_isp[(n * W + lane) * W + b] = (uint8_t)((bm.isp >> b) & 1ull);
+    srcs[lane] = valid ? new_src : -1;
+    // the new token sits right after the source prefix (:862-864)
+    if (valid && new_kind != 2) a.y_next[((int64_t)(bm.len - 1) * a.N + n) * W + lane] = new_tok;
+  }
+  wave_sync();
+  // history rows of the source prefix, below the position just written
+  for (int idx = lane; idx < (S + 1) * W; idx += PDT_WAVE) {
+    const int s = idx / W, i = idx - s * W;
+    const int src = srcs[i];
+    const int len_i = __shfl(bm.len, i);
+    const bool ext_i = __shfl(new_kind, i) == 0 || __shfl(new_kind, i) == 1;
+    const int plen = len_i - (ext_i ? 1 : 0);
+    if (src < 0)
+      a.y_next[((int64_t)s * a.N + n) * W + i] = 0;
+    else if (!(ext_i && s == plen))
+      a.y_next[((int64_t)s * a.N + n) * W + i] = s < S ? dc.y_prev[(int64_t)s * dc.yp_ss + src * dc.yp_sk] : 0;
+  }
+}
+
+int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
+  if (a.W < 1 || a.W > kMaxWidth || a.Kp < 1 || a.Kp > kMaxWidth) return PDT_E_TOO_LONG;
+  const int RS = a.W > a.Kp ? a.W : a.Kp;
+  size_t per_wave = (size_t)PDT_SURV_CAP * 8 + (size_t)((a.V + 1 + 3) & ~3) * 4 +
+                    (size_t)a.Kp * PDT_WAVE * 4 + (size_t)RS * RS * 4 + (size_t)a.W * 4;
+  per_wave = (per_wave + 15) & ~(size_t)15;
+  const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
+  if (per_wave > hard_cap) return PDT_E_TOO_LONG;
+  int wpw = (int)(soft_cap / per_wave);
+  wpw = wpw > 4 ? 4 : (wpw < 1 ? 1 : wpw);
+  a.waves_per_wg = wpw;
+  a.lds_per_wave = (int)per_wave;
+  const size_t smem = per_wave * wpw;
+  if (smem > soft_cap) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_advance_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(ctc_advance_kernel, dim3((a.N + wpw - 1) / wpw), dim3(64 * wpw), smem, stream, a);
+  return (int)hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------------------
+struct BeamAdvArgs {
+  const float *lpt;     int64_t lt_sn, lt_sk, lt_sv;   // log_probs_t (N, Kp, V)
+  const float *lpp;     int64_t lp_sn, lp_sk;          // log_probs_prev (N, Kp)
+  const int64_t *y_prev; int64_t yp_ss, yp_sn, yp_sk;  // (S, N, Kp)
+  const int64_t *lens;  int64_t le_sn, le_sk;          // (N, Kp) or null
+  int N, Kp, V, W, S, S_out;
+  int64_t *y_next;      // (S_out, N, W)
+  int64_t *y_next_lens, *next_src;  // (N, W)
+  float *lp_next;                   // (N, W)
+  int lds_per_wave, waves_per_wg;
+};
+
+__global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int64_t n = (int64_t)blockIdx.x * a.waves_per_wg + wave;
+  if (n >= a.N) return;
+  const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
+  const int K = min(W, (int)min((int64_t)Kp * V, (int64_t)PDT_WAVE));  // :121
+  const int M = min(V, K);
+  unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
+  u64 *surv = reinterpret_cast<u64 *>(base);
+  int *tl = reinterpret_cast<int *>(surv + PDT_SURV_CAP);
+  int *srcs = tl + Kp * PDT_WAVE;
+  int *toks = srcs + W;
+
+  // per-prefix sorted lists of the best tokens
+  for (int k = 0; k < Kp; ++k) {
+    const u64 tk = wave_top_sorted_strided(a.lpt + n * a.lt_sn + k * a.lt_sk, a.lt_sv, V, M, surv);
+    if (lane < M) tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
+    wave_sync();
+  }
+  const bool live = lane < Kp;
+  const float lp_prev = live ? a.lpp[n * a.lp_sn + lane * a.lp_sk] : 0.0f;
+  const float *myrow = a.lpt + n * a.lt_sn + (live ? lane : 0) * a.lt_sk;
+  const int *mytl = tl + (live ? lane : 0) * PDT_WAVE;
+  int ptr = 0;
+  int new_src = 0, new_tok = 0;
+  float new_lp = -PDT_INF;
+  bool valid = false;
+  for (int i = 0; i < K; ++i) {
+    const bool has = live && ptr < M;
+    const int tok = has ? mytl[ptr] : 0;
+    const float mass = has ? lp_prev + myrow[(int64_t)tok * a.lt_sv] : 0.0f;  // :122
+    const unsigned key = has ? fkey(mass) : 0u;
+    const unsigned mx = wave_max_u32(key);
+    if (mx == 0u) break;
+    const int win = (int)__builtin_ctzll(__ballot(key == mx));
+    const int wtok = __builtin_amdgcn_readlane(tok, win);
+    const float wmass = readlane_f(mass, win);
+    if (lane == i) {
+      new_src = win;
+      new_tok = wtok;
+      new_lp = wmass;
+      valid = true;
+    }
+    if (lane == win) ++ptr;
+  }
+  int plen = 0;
+  if (lane < W) {
+    plen = valid ? (a.lens ? (int)a.lens[n * a.le_sn + new_src * a.le_sk] : S) : -1;
+    a.lp_next[n * W + lane] = valid ? new_lp : -PDT_INF;            // :145-153 for the overflow
+    a.next_src[n * W + lane] = valid ? new_src : 0;
+    a.y_next_lens[n * W + lane] = valid ? plen + 1 : 0;
+    srcs[lane] = valid ? new_src : -1;
+    toks[lane] = new_tok;
+  }
+  wave_sync();
+  for (int idx = lane; idx < a.S_out * W; idx += PDT_WAVE) {
+    const int s = idx / W, i = idx - s * W;
+    const int src = srcs[i];
+    const int pl = __shfl(plen, i);
+    int64_t v;
+    if (src < 0)
+      v = 0;
+    else if (s == pl || s >= S)  // :130/:135 the appended token row, :137 the scatter
+      v = toks[i];
+    else
+      v = a.y_prev[(int64_t)s * a.yp_ss + n * a.yp_sn + src * a.yp_sk];
+    a.y_next[((int64_t)s * a.N + n) * W + i] = v;
+  }
+}
+
+int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
+  if (a.W < 1 || a.W > PDT_WAVE || a.Kp < 1 || a.Kp > PDT_WAVE) return PDT_E_TOO_LONG;
+  size_t per_wave = (size_t)PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 4 + (size_t)a.W * 8;
+  per_wave = (per_wave + 15) & ~(size_t)15;
+  int wpw = (int)((64 * 1024) / per_wave);
+  wpw = wpw > 4 ? 4 : (wpw < 1 ? 1 : wpw);
+  a.waves_per_wg = wpw;
+  a.lds_per_wave = (int)per_wave;
+  hipLaunchKernelGGL(beam_advance_kernel, dim3((a.N + wpw - 1) / wpw), dim3(64 * wpw),
+                     per_wave * wpw, stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pdt
+
+extern "C" {
+
+int pdt_ctc_prefix_search_advance(
+    const float *ext, int64_t ext_sn, int64_t ext_sk, int64_t ext_sv, const float *nonext,
+    int64_t ne_sn, int64_t ne_sv, const float *blank, int64_t bl_sn, int64_t N, int64_t Kp,
+    int64_t V, int64_t width, const float *nb_prev, int64_t nb_sn, int64_t nb_sk,
+    const float *b_prev, int64_t b_sn, int64_t b_sk, const int64_t *y_prev, int64_t S,
+    int64_t yp_ss, int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_last, int64_t la_sn,
+    int64_t la_sk, const int64_t *y_prev_lens, int64_t le_sn, int64_t le_sk,
+    const uint8_t *prev_is_prefix, int64_t ip_sn, int64_t ip_sa, int64_t ip_sb, int64_t *y_next,
+    int64_t *y_next_last, int64_t *y_next_lens, float *nb_next, float *b_next,
+    uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext, void *stream) {
+  using namespace pdt;
+  if (N < 0 || Kp < 1 || V < 1 || width < 1 || S < 0) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!ext || !nonext || !blank || !nb_prev || !b_prev || !y_prev_last || !y_prev_lens ||
+      !prev_is_prefix || (S > 0 && !y_prev) || !y_next || !y_next_last || !y_next_lens ||
+      !nb_next || !b_next || !next_is_prefix || !next_src || !next_is_nonext)
+    return PDT_E_ARG;
+  if (V >= (1 << 30) || S >= (1 << 26) || N >= (1ll << 31)) return PDT_E_TOO_LONG;
+  CtcAdvArgs a{};
+  a.ext = ext; a.ext_sn = ext_sn; a.ext_sk = ext_sk; a.ext_sv = ext_sv;
+  a.nonext = nonext; a.ne_sn = ne_sn; a.ne_sv = ne_sv;
+  a.blank = blank; a.bl_sn = bl_sn;
+  a.nb_prev = nb_prev; a.pb_sn = nb_sn; a.pb_sk = nb_sk;
+  a.b_prev = b_prev; a.pbb_sn = b_sn; a.pbb_sk = b_sk;
+  a.y_prev = y_prev; a.yp_ss = yp_ss; a.yp_sn = yp_sn; a.yp_sk = yp_sk;
+  a.last = y_prev_last; a.la_sn = la_sn; a.la_sk = la_sk;
+  a.lens = y_prev_lens; a.le_sn = le_sn; a.le_sk = le_sk;
+  a.isp = prev_is_prefix; a.ip_sn = ip_sn; a.ip_sa = ip_sa; a.ip_sb = ip_sb;
+  a.N = (int)N; a.Kp = (int)Kp; a.V = (int)V; a.W = (int)width; a.S = (int)S;
+  a.y_next = y_next; a.y_next_last = y_next_last; a.y_next_lens = y_next_lens;
+  a.next_src = next_src; a.nb_next = nb_next; a.b_next = b_next;
+  a.next_isp = next_is_prefix; a.next_nonext = next_is_nonext;
+  return launch_ctc_advance(a, (hipStream_t)stream);
+}
+
+int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_sk, int64_t lt_sv,
+                            int64_t N, int64_t Kp, int64_t V, int64_t width,
+                            const float *log_probs_prev, int64_t lp_sn, int64_t lp_sk,
+                            const int64_t *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn,
+                            int64_t yp_sk, const int64_t *y_prev_lens, int64_t le_sn,
+                            int64_t le_sk, int64_t S_out, int64_t *y_next, int64_t *y_next_lens,
+                            float *log_probs_next, int64_t *next_src, void *stream) {
+  using namespace pdt;
+  if (N < 0 || Kp < 1 || V < 1 || width < 1 || S < 0 || (S_out != S && S_out != S + 1))
+    return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!log_probs_t || !log_probs_prev || (S > 0 && !y_prev) || !y_next || !y_next_lens ||
+      !log_probs_next || !next_src)
+    return PDT_E_ARG;
+  if (V >= (1 << 30) || S >= (1 << 26) || N >= (1ll << 31)) return PDT_E_TOO_LONG;
+  BeamAdvArgs a{};
+  a.lpt = log_probs_t; a.lt_sn = lt_sn; a.lt_sk = lt_sk; a.lt_sv = lt_sv;
+  a.lpp = log_probs_prev; a.lp_sn = lp_sn; a.lp_sk = lp_sk;
+  a.y_prev = y_prev; a.yp_ss = yp_ss; a.yp_sn = yp_sn; a.yp_sk = yp_sk;
+  a.lens = y_prev_lens; a.le_sn = le_sn; a.le_sk = le_sk;
+  a.N = (int)N; a.Kp = (int)Kp; a.V = (int)V; a.W = (int)width; a.S = (int)S; a.S_out = (int)S_out;
+  a.y_next = y_next; a.y_next_lens = y_next_lens; a.lp_next = log_probs_next; a.next_src = next_src;
+  return launch_beam_advance(a, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -40,6 +40,17 @@ SIGNATURES = {
         + [_INT, _P, _P, _P, _P, _P],
     ),
     "pdt_oc_expand": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P]),
+    "pdt_ctc_prefix_search_advance": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64]
+        + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64]
+        + [_P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    ),
+    "pdt_beam_search_advance": (
+        _INT,
+        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
+        + [_P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    ),
     "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_ctc_prefix_search": (
         _INT,

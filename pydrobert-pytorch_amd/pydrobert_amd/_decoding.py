@@ -2,18 +2,200 @@
 
 Host-side mirror of the reference's ``_decoding.py`` for the operators on the hot path:
 ``CTCPrefixSearch`` / ``ctc_prefix_search_advance`` and ``BeamSearch`` /
-``beam_search_advance``.  The searches run in ``csrc/ctc_search.hip`` and
-``csrc/beam_advance.hip`` through the C ABI (``include/pdt_amd.h``).
+``beam_search_advance``.  The step functions and the fused CTC search run in
+``csrc/beam_advance.hip`` and ``csrc/ctc_search.hip`` through the C ABI
+(``include/pdt_amd.h``); the Modules keep the reference's control flow around a
+user-supplied language model.
 """
+import math
 from typing import Dict, Optional, Tuple
 
 import torch
 
-from . import _cabi, argcheck
+from . import _cabi, argcheck, config
+from ._lm import ExtractableSequentialLanguageModel, MixableSequentialLanguageModel
 
-__all__ = ["CTCPrefixSearch", "ctc_prefix_search"]
+__all__ = [
+    "BeamSearch",
+    "CTCPrefixSearch",
+    "beam_search_advance",
+    "ctc_prefix_search",
+    "ctc_prefix_search_advance",
+]
 
-MAX_WIDTH = 32
+MAX_CTC_WIDTH = 32
+MAX_BEAM_WIDTH = 64
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return t if t.dtype == torch.float else t.float()
+
+
+def _i64(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    return t if t.dtype == torch.long else t.long()
+
+
+def beam_search_advance(
+    log_probs_t: torch.Tensor,
+    width: int,
+    log_probs_prev: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_lens: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Beam search step function (reference _decoding.py:41-155).
+
+    Returns ``(y_next, y_next_lens, log_probs_next, next_src)``.
+    """
+    if log_probs_t.dim() != 3:
+        raise RuntimeError("log_probs_t must be 3 dimensional")
+    N, Kp, V = log_probs_t.shape
+    if width < 1:
+        raise RuntimeError("Expected width to be >= 1, got {}".format(width))
+    if log_probs_prev.shape != (N, Kp):
+        raise RuntimeError(
+            "Expected log_probs_prev to be of shape {}, got {}".format((N, Kp), tuple(log_probs_prev.shape))
+        )
+    if y_prev.dim() != 3:
+        raise RuntimeError("y_prev must be 3 dimensional")
+    if y_prev.shape[1:] != (N, Kp):
+        raise RuntimeError(
+            "Expected the last two dimensions of y_prev to be {}, got {}".format(
+                (N, Kp), tuple(y_prev.shape[1:])
+            )
+        )
+    S = y_prev.size(0)
+    if y_prev_lens is not None and y_prev_lens.shape != (N, Kp):
+        raise RuntimeError(
+            "Expected y_prev_lens to have shape {}, got {}".format((N, Kp), tuple(y_prev_lens.shape))
+        )
+    device = _cabi.require_hip(log_probs_t, log_probs_prev, y_prev, y_prev_lens)
+    if width > MAX_BEAM_WIDTH or Kp > MAX_BEAM_WIDTH:
+        raise RuntimeError("beam widths above {} are not supported".format(MAX_BEAM_WIDTH))
+    lpt, lpp, yp = _f32(log_probs_t), _f32(log_probs_prev), _i64(y_prev)
+    ypl = None if y_prev_lens is None else _i64(y_prev_lens)
+    grow = True
+    if ypl is not None and N * Kp:
+        if S:
+            grow = int(ypl.max().item()) >= S  # :133-135 don't make y bigger unless we have to
+        elif bool((ypl != 0).any()):
+            raise RuntimeError("Invalid lengths for t=0")  # :139-140
+    S_out = S + (1 if grow else 0)
+    with torch.cuda.device(device):
+        y_next = torch.empty((S_out, N, width), device=device, dtype=torch.long)
+        y_next_lens = torch.empty((N, width), device=device, dtype=torch.long)
+        next_src = torch.empty((N, width), device=device, dtype=torch.long)
+        lp_next = torch.empty((N, width), device=device, dtype=torch.float)
+        if N and V:
+            rc = _cabi.lib().pdt_beam_search_advance(
+                _cabi.ptr(lpt), lpt.stride(0), lpt.stride(1), lpt.stride(2), N, Kp, V, int(width),
+                _cabi.ptr(lpp), lpp.stride(0), lpp.stride(1),
+                _cabi.ptr(yp), S, yp.stride(0), yp.stride(1), yp.stride(2),
+                _cabi.ptr(ypl), 0 if ypl is None else ypl.stride(0), 0 if ypl is None else ypl.stride(1),
+                S_out, _cabi.ptr(y_next), _cabi.ptr(y_next_lens), _cabi.ptr(lp_next),
+                _cabi.ptr(next_src), _cabi.stream_ptr(device),
+            )  # fmt: skip
+            _cabi.check(rc, "pdt_beam_search_advance")
+    return y_next, y_next_lens, lp_next.to(log_probs_t.dtype), next_src
+
+
+def ctc_prefix_search_advance(
+    probs_t: Tuple[torch.Tensor, torch.Tensor, torch.Tensor],
+    width: int,
+    probs_prev: Tuple[torch.Tensor, torch.Tensor],
+    y_prev: torch.Tensor,
+    y_prev_last: torch.Tensor,
+    y_prev_lens: torch.Tensor,
+    prev_is_prefix: torch.Tensor,
+):
+    """CTC prefix search step function (reference _decoding.py:636-934).
+
+    Returns ``(y_next, y_next_last, y_next_lens, (nb_probs_next, b_probs_next),
+    next_is_prefix, next_src, next_is_nonext)``.
+    """
+    if width < 1:
+        raise RuntimeError("width must be positive")
+    ext, nonext, blank = probs_t
+    if ext.dim() != 3:
+        raise RuntimeError("ext_probs_t must be 3 dimensional")
+    N, Kp, V = ext.shape
+    if nonext.shape != (N, V):
+        raise RuntimeError(
+            "expected nonext_probs_t to have shape {}, got {}".format((N, V), tuple(nonext.shape))
+        )
+    if blank.shape != (N,):
+        raise RuntimeError(
+            "expected blank_probs_t to have shape {}, got {}".format((N,), tuple(blank.shape))
+        )
+    nb, b = probs_prev
+    if nb.shape != (N, Kp):
+        raise RuntimeError(
+            "expected nb_probs_prev to have shape {}, got {}".format((N, Kp), tuple(nb.shape))
+        )
+    if b.shape != (N, Kp):
+        raise RuntimeError(
+            "expected b_probs_prev to have shape {}, got {}".format((N, Kp), tuple(b.shape))
+        )
+    if y_prev.dim() != 3:
+        raise RuntimeError("y_prev must be 3 dimensional")
+    if y_prev.shape[1:] != (N, Kp):
+        raise RuntimeError(
+            "expected last two dimensions of y_prev to be {}, got {}".format(
+                (N, Kp), tuple(y_prev.shape[1:])
+            )
+        )
+    S = y_prev.size(0)
+    if y_prev_last.shape != (N, Kp):
+        raise RuntimeError(
+            "expected y_prev_last to have shape {}, got {}".format((N, Kp), tuple(y_prev_last.shape))
+        )
+    if y_prev_lens.shape != (N, Kp):
+        raise RuntimeError(
+            "expected y_prev_lens to have shape {}, got {}".format((N, Kp), tuple(y_prev_lens.shape))
+        )
+    if prev_is_prefix.shape != (N, Kp, Kp):
+        raise RuntimeError(
+            "expected prev_is_prefix to have shape {}, got {}".format(
+                (N, Kp, Kp), tuple(prev_is_prefix.shape)
+            )
+        )
+    device = _cabi.require_hip(ext, nonext, blank, nb, b, y_prev, y_prev_last, y_prev_lens,
+                               prev_is_prefix)  # fmt: skip
+    if width > MAX_CTC_WIDTH or Kp > MAX_CTC_WIDTH:
+        raise RuntimeError("CTC beam widths above {} are not supported".format(MAX_CTC_WIDTH))
+    dtype = ext.dtype
+    ext, nonext, blank, nb, b = (_f32(x) for x in (ext, nonext, blank, nb, b))
+    yp, last, lens = _i64(y_prev), _i64(y_prev_last), _i64(y_prev_lens)
+    isp = prev_is_prefix.detach()
+    if isp.dtype != torch.bool:
+        isp = isp.bool()
+    W = int(width)
+    with torch.cuda.device(device):
+        y_next = torch.empty((S + 1, N, W), device=device, dtype=torch.long)
+        o_last = torch.empty((N, W), device=device, dtype=torch.long)
+        o_lens = torch.empty((N, W), device=device, dtype=torch.long)
+        o_src = torch.empty((N, W), device=device, dtype=torch.long)
+        o_nb = torch.empty((N, W), device=device, dtype=torch.float)
+        o_b = torch.empty((N, W), device=device, dtype=torch.float)
+        o_isp = torch.empty((N, W, W), device=device, dtype=torch.bool)
+        o_non = torch.empty((N, W), device=device, dtype=torch.bool)
+        if N:
+            rc = _cabi.lib().pdt_ctc_prefix_search_advance(
+                _cabi.ptr(ext), ext.stride(0), ext.stride(1), ext.stride(2),
+                _cabi.ptr(nonext), nonext.stride(0), nonext.stride(1),
+                _cabi.ptr(blank), blank.stride(0), N, Kp, V, W,
+                _cabi.ptr(nb), nb.stride(0), nb.stride(1), _cabi.ptr(b), b.stride(0), b.stride(1),
+                _cabi.ptr(yp), S, yp.stride(0), yp.stride(1), yp.stride(2),
+                _cabi.ptr(last), last.stride(0), last.stride(1),
+                _cabi.ptr(lens), lens.stride(0), lens.stride(1),
+                _cabi.ptr(isp), isp.stride(0), isp.stride(1), isp.stride(2),
+                _cabi.ptr(y_next), _cabi.ptr(o_last), _cabi.ptr(o_lens), _cabi.ptr(o_nb),
+                _cabi.ptr(o_b), _cabi.ptr(o_isp), _cabi.ptr(o_src), _cabi.ptr(o_non),
+                _cabi.stream_ptr(device),
+            )  # fmt: skip
+            _cabi.check(rc, "pdt_ctc_prefix_search_advance")
+    return y_next, o_last, o_lens, (o_nb.to(dtype), o_b.to(dtype)), o_isp, o_src, o_non
 
 
 def ctc_prefix_search(
@@ -34,11 +216,10 @@ def ctc_prefix_search(
         raise RuntimeError("logits must have at least one non-blank class")
     if width < 1:
         raise RuntimeError("width must be positive")
-    if width > MAX_WIDTH:
-        raise RuntimeError("width {} exceeds the MI355X kernel's limit of {}".format(width, MAX_WIDTH))
-    logits = logits.detach()
-    if logits.dtype != torch.float:
-        logits = logits.float()
+    if width > MAX_CTC_WIDTH:
+        raise RuntimeError("CTC beam widths above {} are not supported".format(MAX_CTC_WIDTH))
+    dtype = logits.dtype
+    logits = _f32(logits)
     if lens is None:
         S = T
     elif lens.dim() != 1:
@@ -46,7 +227,7 @@ def ctc_prefix_search(
     elif lens.size(0) != N:
         raise RuntimeError("expected dim 0 of lens to be {}, got {}".format(N, lens.size(0)))
     else:
-        lens = lens.long().contiguous()
+        lens = _i64(lens).contiguous()
         S = int(lens.max().item()) if N else 0  # the reference's len_max host read (:1089)
         S = max(0, min(S, T))
     L = _cabi.lib()
@@ -64,18 +245,28 @@ def ctc_prefix_search(
             _cabi.ptr(ws), _cabi.stream_ptr(device),
         )  # fmt: skip
     _cabi.check(rc, "pdt_ctc_prefix_search")
-    return y, y_lens, y_probs
+    return y, y_lens, y_probs.to(dtype)
 
 
 class CTCPrefixSearch(torch.nn.Module):
-    """Beam search over CTC prefixes (reference _decoding.py:937-1204).
+    """Beam search over CTC prefixes, optionally with shallow fusion (reference
+    _decoding.py:937-1204).
 
-    ``lm=None`` (or ``beta == 0``) runs the fused MI355X kernel.
+    Without a language model (``lm=None`` or ``beta == 0``) the whole search is one fused
+    kernel.  With one, the reference's per-frame loop is kept -- the LM forward is the
+    user's PyTorch code -- and each frame's prefix bookkeeping is one kernel
+    (``ctc_prefix_search_advance``).
     """
 
     __constants__ = ["width", "beta", "valid_mixture"]
 
-    def __init__(self, width: int, beta: float = 0.2, lm=None, valid_mixture: bool = False):
+    def __init__(
+        self,
+        width: int,
+        beta: float = 0.2,
+        lm: Optional[MixableSequentialLanguageModel] = None,
+        valid_mixture: bool = False,
+    ):
         width = argcheck.is_posi(width, name="width")
         beta = argcheck.is_closed01(beta, name="beta")
         valid_mixture = argcheck.is_bool(valid_mixture, "valid_mixture")
@@ -99,6 +290,206 @@ class CTCPrefixSearch(torch.nn.Module):
         lens: Optional[torch.Tensor] = None,
         initial_state: Optional[Dict[str, torch.Tensor]] = None,
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        if logits.dim() != 3:
+            raise RuntimeError("logits must be 3 dimensional")
+        T, N, Vp1 = logits.shape
+        V = Vp1 - 1
+        if self.lm is not None and self.lm.vocab_size != V:
+            raise RuntimeError(
+                "Expected dim 2 of logits to be {}, got {}".format(self.lm.vocab_size + 1, Vp1)
+            )
         if self.lm is None or not self.beta:
             return ctc_prefix_search(logits, self.width, lens)
-        raise NotImplementedError("shallow fusion: use the step function")
+        return self._fused_with_lm(logits, lens, dict() if initial_state is None else initial_state)
+
+    def _fused_with_lm(self, logits, lens, prev):
+        # reference _decoding.py:1083-1202, frame loop around the user's language model
+        T, N, Vp1 = logits.shape
+        V, W = Vp1 - 1, self.width
+        device, dtype = logits.device, logits.dtype
+        if lens is None:
+            lens = torch.full((N,), T, device=device, dtype=torch.long)
+            len_min = len_max = T
+        elif lens.dim() != 1:
+            raise RuntimeError("lens must be 1 dimensional")
+        elif lens.size(0) != N:
+            raise RuntimeError("expected dim 0 of lens to be {}, got {}".format(N, lens.size(0)))
+        else:
+            len_min, len_max = int(lens.min().item()), int(lens.max().item())
+        probs = logits.softmax(2)
+        blank_probs, nonext_probs = probs[..., V], probs[..., :V]
+        nb = torch.zeros((N, 1), device=device, dtype=dtype)
+        b = torch.ones((N, 1), device=device, dtype=dtype)
+        y = torch.empty((0, N, 1), dtype=torch.long, device=device)
+        y_lens = y_last = torch.zeros((N, 1), dtype=torch.long, device=device)
+        is_prefix = torch.ones((N, 1, 1), device=device, dtype=torch.bool)
+        prev = self.lm.update_input(prev, y)
+        Kp = 1
+        pad_y = torch.zeros((1, N, W), device=device, dtype=torch.long)
+        for t in range(len_max):
+            valid = None if t < len_min else (t < lens).unsqueeze(1)
+            nonext_t, blank_t = nonext_probs[t], blank_probs[t]
+            lm_lp, in_next = self.lm.calc_idx_log_probs(y.flatten(1), prev, y_lens.flatten())
+            if self.valid_mixture:  # :1120-1128
+                lm_p = self.beta * lm_lp.softmax(-1).view(N, Kp, V) * (1 - blank_t.view(N, 1, 1))
+                ext_t = (1.0 - self.beta) * nonext_t.unsqueeze(1) + lm_p
+            else:  # :1130-1135
+                lm_p = (self.beta * lm_lp.log_softmax(-1)).exp().view(N, Kp, V)
+                ext_t = lm_p * nonext_t.unsqueeze(1)
+            (y_next, last_next, lens_next, (nb_next, b_next), isp_next, src, is_nonext) = \
+                ctc_prefix_search_advance(
+                    (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
+                )  # fmt: skip
+            flat = (torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1) + src).flatten()
+            prev = self.lm.extract_by_src(prev, flat)  # :1154-1163
+            in_next = self.lm.extract_by_src(in_next, flat)
+            prev = self.lm.mix_by_mask(prev, in_next, is_nonext.flatten())
+            if valid is None:
+                y_lens, nb, b = lens_next, nb_next, b_next
+            else:  # :1165-1181 freeze finished batch elements
+                y = torch.cat([y.expand(-1, -1, W), pad_y], 0)
+                y_next = torch.where(valid.unsqueeze(0), y_next, y)
+                y_lens = torch.where(valid, lens_next, y_lens)
+                if Kp < W:
+                    neg_inf = nb.new_full((N, W - Kp), -float("inf"))
+                    nb, b = torch.cat([nb, neg_inf], 1), torch.cat([b, neg_inf], 1)
+                nb = torch.where(valid, nb_next, nb)
+                b = torch.where(valid, b_next, b)
+            y, y_last, is_prefix, Kp = y_next, last_next, isp_next, W
+        probs_out = nb + b
+        if Kp == 1 != W:  # :1190-1200
+            y = y.repeat(1, 1, W)
+            y_lens = y_lens.repeat(1, W)
+            probs_out = torch.cat([probs_out, probs_out.new_full((N, W - 1), -float("inf"))], 1)
+        return y, y_lens, probs_out
+
+
+class BeamSearch(torch.nn.Module):
+    """Beam search driven by an :class:`ExtractableSequentialLanguageModel` (reference
+    _decoding.py:158-504).  Each iteration is the user's LM forward, a ``log_softmax``, the
+    overridable :meth:`update_log_probs_for_step` hook and ONE ``beam_search_advance`` kernel.
+    """
+
+    __constants__ = ["width", "eos", "finish_all_paths", "pad_value"]
+
+    def __init__(
+        self,
+        lm: ExtractableSequentialLanguageModel,
+        width: int,
+        eos: Optional[int] = None,
+        finish_all_paths: bool = False,
+        pad_value: int = config.INDEX_PAD_VALUE,
+    ):
+        width = argcheck.is_posi(width, "width")
+        eos = argcheck.is_int(eos, "eos", True)
+        finish_all_paths = argcheck.is_bool(finish_all_paths, "finish_all_paths")
+        pad_value = argcheck.is_int(pad_value, "pad_value")
+        super().__init__()
+        if eos is not None:
+            if eos < -lm.vocab_size or eos > lm.vocab_size - 1:
+                raise ValueError(
+                    "Expected eos to be in the range [{}, {}], got {}".format(
+                        -lm.vocab_size, lm.vocab_size - 1, eos
+                    )
+                )
+            eos = (eos + lm.vocab_size) % lm.vocab_size
+        self.lm, self.width, self.eos = lm, width, eos
+        self.finish_all_paths, self.pad_value = finish_all_paths, pad_value
+        try:
+            device = next(iter(lm.parameters())).device
+        except StopIteration:
+            device = torch.device("cpu")
+        self.register_buffer("device_buffer", torch.empty(0, device=device))
+
+    def reset_parameters(self) -> None:
+        if hasattr(self.lm, "reset_parameters"):
+            self.lm.reset_parameters()
+
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+    def update_log_probs_for_step(
+        self,
+        log_probs_prev: torch.Tensor,
+        log_probs_t: torch.Tensor,
+        y_prev: torch.Tensor,
+        y_prev_lens: torch.Tensor,
+        eos_mask: torch.Tensor,
+    ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Hook: subclasses may rescore paths ``(N, K)`` and extensions ``(N, K, V)`` at every
+        step (reference _decoding.py:306-350).  The default is the identity."""
+        return log_probs_prev, log_probs_t
+
+    def _to_width(self, y, log_probs, lens):
+        # reference _decoding.py:352-372
+        S, N, Kp = y.shape
+        if Kp < self.width:
+            rem = self.width - Kp
+            log_probs = torch.cat([log_probs, log_probs.new_full((N, rem), -float("inf"))], 1)
+            y = torch.cat([y, y.new_zeros(S, N, rem)], 2)
+            lens = torch.cat([lens, lens.new_zeros(N, rem)], 1)
+        elif Kp > self.width:
+            log_probs, src = log_probs.topk(self.width, 1)
+            y = y.gather(2, src.unsqueeze(0).expand(S, N, self.width))
+            lens = lens.gather(1, src)
+        return y, log_probs, lens
+
+    def forward(
+        self,
+        initial_state: Optional[Dict[str, torch.Tensor]] = None,
+        batch_size: Optional[int] = None,
+        max_iters: Optional[int] = None,
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        prev = dict() if initial_state is None else initial_state
+        device = self.device_buffer.device
+        N = 1 if batch_size is None else batch_size
+        V, W = self.lm.vocab_size, self.width
+        Kp = 1
+        y = torch.empty((0, N), dtype=torch.long, device=device)
+        prev = self.lm.update_input(prev, y)
+        y = y.unsqueeze(2)
+        log_probs = torch.full((N, Kp), -math.log(Kp), device=device)
+        lens = torch.zeros((N, Kp), dtype=torch.long, device=device)
+        if max_iters is None:
+            if self.eos is None:
+                raise RuntimeError("max_iters must be set when eos is unset")
+            max_iters = 1073741824
+        elif max_iters < 0:
+            raise RuntimeError("max_iters must be non-negative, got {}".format(max_iters))
+        pad_y = torch.full((1, N, W), self.pad_value, device=device, dtype=torch.long)
+        for t in range(max_iters):
+            t_ = torch.tensor(t, device=device)
+            if self.eos is not None and t:  # :413-427 which paths have ended; are we done?
+                last = y.permute(1, 2, 0).gather(2, (lens - 1).clamp(min=0).unsqueeze(2)).squeeze(2)
+                eos_mask = (last == self.eos) & (lens > 0)
+                done = eos_mask.all(1, keepdim=True) if self.finish_all_paths else eos_mask[..., :1]
+                if bool(done.all()):
+                    break
+            else:
+                eos_mask = torch.zeros((N, Kp), device=device, dtype=torch.bool)
+                done = eos_mask[..., :1]
+            y_ = y.clamp(0, V - 1)
+            lp_t, in_next = self.lm.calc_idx_log_probs(y_.flatten(1), prev, t_)
+            lp_t = lp_t.reshape(N, Kp, V).log_softmax(-1)
+            log_probs, lp_t = self.update_log_probs_for_step(log_probs, lp_t, y_, lens, eos_mask)
+            if self.eos is not None:  # :448-458 ended paths may only emit eos, for free
+                lp_t = lp_t.masked_fill(eos_mask.unsqueeze(2), -float("inf"))
+                lp_t[..., self.eos] = lp_t[..., self.eos].masked_fill(eos_mask, 0.0)
+            y_next, lens_next, lp_next, src = beam_search_advance(lp_t, W, log_probs, y_, lens)
+            if self.eos is not None:  # :465-468 ended sources do not grow
+                lens_next = lens_next - eos_mask.gather(1, src).to(lens_next)
+            flat = (torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1) + src).flatten()
+            prev = self.lm.extract_by_src(in_next, flat)
+            if self.eos is not None and bool(done.any()):  # :479-486 frozen batch elements
+                y, log_probs, lens = self._to_width(y, log_probs, lens)
+                y = torch.cat([y, pad_y], 0)
+                if y.size(0) < y_next.size(0):
+                    y = torch.cat([y, pad_y.expand(y_next.size(0) - y.size(0), -1, -1)], 0)
+                y_next = torch.where(done.unsqueeze(0), y[: y_next.size(0)], y_next)
+                lp_next = torch.where(done, log_probs, lp_next)
+                lens_next = torch.where(done, lens, lens_next)
+            y, lens, log_probs, Kp = y_next, lens_next, lp_next, W
+        y, log_probs, lens = self._to_width(y, log_probs, lens)
+        if batch_size is None:
+            y, lens, log_probs = y.squeeze(1), lens.squeeze(0), log_probs.squeeze(0)
+        return y, lens, log_probs

@@ -1,7 +1,11 @@
 """Functional namespace -- mirrors ``pydrobert.torch.functional`` (functional.py:17-95)
 for the operators on the MI355X hot path."""
 
-from ._decoding import ctc_prefix_search
+from ._decoding import (
+    beam_search_advance,
+    ctc_prefix_search,
+    ctc_prefix_search_advance,
+)
 from ._string import (
     edit_distance,
     error_rate,
@@ -12,7 +16,9 @@ from ._string import (
 )
 
 __all__ = [
+    "beam_search_advance",
     "ctc_prefix_search",
+    "ctc_prefix_search_advance",
     "edit_distance",
     "error_rate",
     "fill_after_eos",

@@ -1,7 +1,12 @@
 """Module namespace -- mirrors ``pydrobert.torch.modules`` (modules.py:28-124) for the
 operators on the MI355X hot path."""
 
-from ._decoding import CTCPrefixSearch
+from ._decoding import BeamSearch, CTCPrefixSearch
+from ._lm import (
+    ExtractableSequentialLanguageModel,
+    MixableSequentialLanguageModel,
+    SequentialLanguageModel,
+)
 from ._string import (
     EditDistance,
     ErrorRate,
@@ -12,7 +17,11 @@ from ._string import (
 )
 
 __all__ = [
+    "BeamSearch",
     "CTCPrefixSearch",
+    "ExtractableSequentialLanguageModel",
+    "MixableSequentialLanguageModel",
+    "SequentialLanguageModel",
     "EditDistance",
     "ErrorRate",
     "FillAfterEndOfSequence",

@@ -122,3 +122,107 @@ def test_ctc_strided_logits_and_errors(device):
         F.ctc_prefix_search(t, 3, torch.zeros((4, 1), dtype=torch.long, device=device))
     with pytest.raises(ValueError):
         M.CTCPrefixSearch(0)
+
+
+# ---------------------------------------------------------------------------------------
+# step functions
+# ---------------------------------------------------------------------------------------
+def _cmp_ctc_step(act, exp, what):
+    (y, last, lens, (nb, b), isp, src, non) = [
+        tuple(z.cpu().numpy() for z in x) if isinstance(x, tuple) else x.cpu().numpy() for x in act
+    ]
+    (ey, elast, elens, (enb, eb), eisp, esrc, enon) = exp
+    assert y.shape == ey.shape, what
+    assert np.array_equal(lens, elens), (what, lens, elens)
+    assert np.array_equal(src, esrc), (what, src, esrc)
+    assert np.array_equal(non, enon), what
+    assert np.array_equal(last, elast), what
+    assert np.array_equal(isp, eisp), (what, np.argwhere(isp != eisp)[:5])
+    valid = np.isfinite(enb)
+    assert np.array_equal(np.isfinite(nb), valid), what
+    assert np.allclose(nb[valid], enb[valid], rtol=RTOL, atol=0), what
+    assert np.allclose(b[valid], eb[valid], rtol=RTOL, atol=0), what
+    S1, N, W = ey.shape
+    for n in range(N):
+        for k in range(W):
+            assert np.array_equal(y[: elens[n, k], n, k], ey[: elens[n, k], n, k]), (what, n, k)
+
+
+@pytest.mark.parametrize("V,W", [(3, 2), (4, 5), (9, 4), (30, 8), (100, 16), (300, 32)])
+def test_ctc_prefix_search_advance_teacher_forced(device, V, W):
+    """Run the oracle's search with per-prefix (LM-like) extension probabilities and, at every
+    frame, feed the oracle's state to the kernel and compare all seven outputs."""
+    rng = np.random.default_rng(V * 100 + W)
+    N, T = 3, 12
+    nb, b = np.zeros((N, 1), np.float32), np.ones((N, 1), np.float32)
+    y = np.zeros((0, N, 1), np.int64)
+    last = lens = np.zeros((N, 1), np.int64)
+    isp = np.ones((N, 1, 1), bool)
+    for t in range(T):
+        Kp = nb.shape[1]
+        p = np.exp(rng.normal(size=(N, V + 1)) * 1.5).astype(np.float32)
+        p /= p.sum(1, keepdims=True)
+        nonext, blank = np.ascontiguousarray(p[:, :V]), np.ascontiguousarray(p[:, V])
+        lm = np.exp(rng.normal(size=(N, Kp, V)) * 0.7).astype(np.float32)
+        lm /= lm.sum(2, keepdims=True)
+        ext = (lm ** 0.5 * nonext[:, None]).astype(np.float32)
+        exp = oracle.ctc_prefix_search_advance((ext, nonext, blank), W, (nb, b), y, last, lens, isp)
+        tt = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)  # noqa: E731
+        act = F.ctc_prefix_search_advance(
+            (tt(ext), tt(nonext), tt(blank)), W, (tt(nb), tt(b)), tt(y), tt(last), tt(lens), tt(isp)
+        )
+        _cmp_ctc_step(act, exp, (V, W, t))
+        y, last, lens, (nb, b), isp = exp[0], exp[1], exp[2], exp[3], exp[4]
+
+
+def test_ctc_prefix_search_advance_broadcast_ext(device):
+    """No-LM form: ext_probs_t is an expand()ed view of nonext_probs_t (stride 0)."""
+    rng = np.random.default_rng(77)
+    N, V, W = 4, 6, 4
+    p = rng.dirichlet(np.ones(V + 1), N).astype(np.float32)
+    nonext, blank = torch.from_numpy(p[:, :V].copy()).to(device), torch.from_numpy(p[:, V].copy()).to(device)
+    z = lambda *s: torch.zeros(s, dtype=torch.long, device=device)  # noqa: E731
+    act = F.ctc_prefix_search_advance(
+        (nonext.unsqueeze(1).expand(N, 1, V), nonext, blank), W,
+        (torch.zeros(N, 1, device=device), torch.ones(N, 1, device=device)),
+        z(0, N, 1), z(N, 1), z(N, 1), torch.ones(N, 1, 1, dtype=torch.bool, device=device),
+    )  # fmt: skip
+    exp = oracle.ctc_prefix_search_advance(
+        (p[:, None, :V].copy(), p[:, :V].copy(), p[:, V].copy()), W,
+        (np.zeros((N, 1), np.float32), np.ones((N, 1), np.float32)),
+        np.zeros((0, N, 1), np.int64), np.zeros((N, 1), np.int64), np.zeros((N, 1), np.int64),
+        np.ones((N, 1, 1), bool),
+    )  # fmt: skip
+    _cmp_ctc_step(act, exp, "broadcast")
+
+
+@pytest.mark.parametrize("with_lens", [False, True])
+def test_beam_search_advance_random(device, with_lens):
+    rng = np.random.default_rng(31 + with_lens)
+    for it in range(40):
+        N, Kp, V = int(rng.integers(1, 5)), int(rng.integers(1, 9)), int(rng.integers(2, 90))
+        W, S = int(rng.integers(1, 20)), int(rng.integers(0, 6))
+        lpt = np.log(rng.dirichlet(np.ones(V), (N, Kp))).astype(np.float32)
+        lpp = rng.normal(size=(N, Kp)).astype(np.float32)
+        yp = rng.integers(0, V, (S, N, Kp))
+        ypl = rng.integers(0, S + 1, (N, Kp)) if with_lens else None
+        exp = oracle.beam_search_advance(lpt, W, lpp, yp, ypl)
+        tt = lambda a: None if a is None else torch.from_numpy(a).to(device)  # noqa: E731
+        act = [x.cpu().numpy() for x in F.beam_search_advance(tt(lpt), W, tt(lpp), tt(yp), tt(ypl))]
+        K = min(W, Kp * V)
+        assert act[0].shape == exp[0].shape, (it, act[0].shape, exp[0].shape)
+        assert np.array_equal(act[1], exp[1]) and np.array_equal(act[3], exp[3]), it
+        assert np.array_equal(act[2], exp[2]), it  # float adds are the same single operation
+        assert np.array_equal(act[0][..., :K], exp[0][..., :K]), it
+
+
+def test_beam_search_advance_errors(device):
+    lpt = torch.zeros(2, 3, 4, device=device)
+    with pytest.raises(RuntimeError, match="3 dimensional"):
+        F.beam_search_advance(lpt[0], 2, torch.zeros(2, 3, device=device), torch.zeros(0, 2, 3, dtype=torch.long, device=device))
+    with pytest.raises(RuntimeError, match="width"):
+        F.beam_search_advance(lpt, 0, torch.zeros(2, 3, device=device), torch.zeros(0, 2, 3, dtype=torch.long, device=device))
+    with pytest.raises(RuntimeError, match="Invalid lengths"):
+        F.beam_search_advance(lpt, 2, torch.zeros(2, 3, device=device),
+                              torch.zeros(0, 2, 3, dtype=torch.long, device=device),
+                              torch.ones(2, 3, dtype=torch.long, device=device))  # fmt: skip
