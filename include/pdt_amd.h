@@ -150,6 +150,55 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
                             int64_t le_sk, int64_t S_out, int64_t *y_next, int64_t *y_next_lens,
                             float *log_probs_next, int64_t *next_src, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Feature augmentation / image warps (reference _img.py).  All tensors float32 and
+ * contiguous unless strides are given.
+ *
+ * pdt_polyharmonic_spline: polyharmonic_spline (_img.py:59-150).  train_points (N,T,I),
+ *   train_values (N,T,O), query_points (N,Q,I) -> out (N,Q,O); T + I + 1 <= 100.  The bordered
+ *   system is solved exactly (float64, partial pivoting), which covers both of the reference's
+ *   `full_matrix` evaluation orders.  workspace: pdt_spline_workspace_bytes(N,T,I,O) bytes.
+ * pdt_warp_1d_grid: warp_1d_grid (_img.py:268-303): src, flow, lengths (N,) -> grid (N,T).
+ * pdt_spec_augment_apply: spec_augment_apply_parameters (_img.py:1142-1211).  feats (N,T,F)
+ *   through element strides; time_grid (N,T) / freq_grid (N,F) normalised sampling grids or
+ *   NULL (no warp along that axis); t_0/t_len (N,MT), f_0/f_len (N,MF) int64 mask bands
+ *   (MT / MF = 0: none); out (N,T,F) contiguous.
+ * pdt_dense_image_warp: dense_image_warp (_img.py:393-439).  image (N,C,H,W), flow (N,H,W,2);
+ *   flow_is_hw: last dim of flow is (h, w) ("hw" indexing) instead of (w, h).
+ *   mode: 0 bilinear, 1 nearest; padding: 0 zeros, 1 border, 2 reflection.
+ * pdt_sparse_image_warp: sparse_image_warp (_img.py:520-714) after the caller has appended the
+ *   pinned boundary points and put points in (x=w, y=h) order: train_points (N,M,2) = dest
+ *   points; train_values (N,M,2) = dest - source (flow form) or the normalised source grid
+ *   (values_are_grid = 1, the include_flow=False form).  flow_out (N,H,W,2) optional
+ *   (flow form only), stored (h, w)-ordered when flow_out_is_hw.
+ *   workspace: pdt_spline_workspace_bytes(N, M, 2, 2) bytes.
+ * ------------------------------------------------------------------------------------- */
+int64_t pdt_spline_workspace_bytes(int64_t N, int64_t T, int64_t I, int64_t O);
+
+int pdt_polyharmonic_spline(const float *train_points, const float *train_values,
+                            const float *query_points, int64_t N, int64_t T, int64_t I, int64_t O,
+                            int64_t Q, int order, float regularization_weight, float *out,
+                            void *workspace, void *stream);
+
+int pdt_warp_1d_grid(const float *src, const float *flow, const float *lengths, int64_t N, int64_t T,
+                     int order, float *grid, void *stream);
+
+int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, int64_t f_sn,
+                           int64_t f_st, int64_t f_sf, const float *time_grid,
+                           const float *freq_grid, const int64_t *t_0, const int64_t *t_len,
+                           int64_t MT, const int64_t *f_0, const int64_t *f_len, int64_t MF,
+                           float *out, void *stream);
+
+int pdt_dense_image_warp(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                         int64_t W, int flow_is_hw, int mode, int padding, float *out,
+                         void *stream);
+
+int pdt_sparse_image_warp(const float *image, const float *train_points,
+                          const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
+                          int64_t M, int order, float regularization_weight, int values_are_grid,
+                          int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
+                          void *workspace, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,492 @@
+// SpecAugment application, polyharmonic splines and image warps for gfx950.
+//
+// Replaces, from the reference's _img.py:
+//   polyharmonic_spline (:59-150)            -> spline_solve_kernel + spline_apply_kernel
+//   warp_1d_grid (:268-303)                  -> warp_1d_grid_kernel (3-knot spline, 5x5 solve)
+//   spec_augment_apply_parameters (:1142-1211)-> spec_augment_apply_kernel: ONE pass that reads
+//       feats once and writes the result once; the reference materialises an (N,T,F,2) grid
+//       (64 % of its time is the torch.stack building it) and calls grid_sample + masked_fill
+//   dense_image_warp (:393-439), sparse_image_warp (:520-714) -> image_warp_kernel: per pixel,
+//       sampling position from a flow field or straight from the spline (knots in LDS), then the
+//       grid_sample gather (bilinear / nearest; zeros / border / reflection) for every channel.
+// The small dense systems are solved in float64 (partial pivoting); gathers follow
+// torch.nn.functional.grid_sample(align_corners=False) arithmetic in float32.
+#include <cfloat>
+
+#include "pdt_common.hpp"
+
+namespace pdt {
+
+constexpr int kMaxSplineSys = 100;  // T + I + 1
+
+__device__ __forceinline__ double phi_d(double r, int order) {
+  // _img.py:59-64; eps = float32 epsilon (train/query points are cast to float, :142-143)
+  double rk = 1.0;
+  for (int i = 0; i < order; ++i) rk *= r;
+  if (order & 1) return rk;
+  return rk * log(fmax(r, (double)FLT_EPSILON));
+}
+__device__ __forceinline__ float phi_f(float r, int order) {
+  float rk = 1.0f;
+  for (int i = 0; i < order; ++i) rk *= r;
+  if (order & 1) return rk;
+  return rk * logf(fmaxf(r, FLT_EPSILON));
+}
+
+// Solve the bordered system [[A + reg*I, B], [B^T, 0]] [w; v] = [f; 0] (_img.py:79-130) for one
+// batch element with the whole workgroup.  a: (S, S + O) augmented matrix in LDS (doubles).
+__device__ void solve_in_lds(double *a, int S, int O, int *piv_row) {
+  const int tid = (int)threadIdx.x, nt = (int)blockDim.x;
+  const int ld = S + O;
+  for (int p = 0; p < S; ++p) {
+    if (tid == 0) {  // partial pivoting
+      int best = p;
+      double bv = fabs(a[p * ld + p]);
+      for (int r = p + 1; r < S; ++r) {
+        const double v = fabs(a[r * ld + p]);
+        if (v > bv) {
+          bv = v;
+          best = r;
+        }
+      }
+      *piv_row = best;
+    }
+    __syncthreads();
+    const int pr = *piv_row;
+    if (pr != p)
+      for (int c = tid; c < ld; c += nt) {
+        const double t = a[p * ld + c];
+        a[p * ld + c] = a[pr * ld + c];
+        a[pr * ld + c] = t;
+      }
+    __syncthreads();
+    const double inv = 1.0 / a[p * ld + p];
+    // eliminate column p from every other row (Gauss-Jordan): rows x columns over the threads
+    const int ncol = ld - p - 1;
+    for (int i = tid; i < S * ncol; i += nt) {
+      const int r = i / ncol, c = p + 1 + (i - r * ncol);
+      if (r != p) a[r * ld + c] -= a[r * ld + p] * inv * a[p * ld + c];
+    }
+    __syncthreads();
+    for (int r = tid; r < S; r += nt)
+      if (r != p) a[r * ld + p] = 0.0;
+    __syncthreads();
+  }
+  for (int i = tid; i < S * O; i += nt) {
+    const int r = i / O, c = S + (i - r * O);
+    a[r * ld + c] /= a[r * ld + r];
+  }
+  __syncthreads();
+}
+
+// train points c (N,T,I), values f (N,T,O) -> wv (N, T+I+1, O) doubles
+__global__ void __launch_bounds__(256)
+spline_solve_kernel(const float *__restrict__ c, const float *__restrict__ f, int T, int I, int O,
+                    int order, float reg, double *__restrict__ wv) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *a = reinterpret_cast<double *>(smem);
+  const int S = T + I + 1, ld = S + O;
+  int *piv = reinterpret_cast<int *>(a + (size_t)S * ld);
+  const int64_t n = blockIdx.x;
+  const float *cn = c + n * (int64_t)T * I;
+  const float *fn = f + n * (int64_t)T * O;
+  for (int i = (int)threadIdx.x; i < S * ld; i += (int)blockDim.x) {
+    const int r = i / ld, col = i - r * ld;
+    double v = 0.0;
+    if (r < T && col < T) {
+      double d2 = 0.0;
+      for (int k = 0; k < I; ++k) {
+        const double d = (double)cn[r * I + k] - (double)cn[col * I + k];
+        d2 += d * d;
+      }
+      v = phi_d(sqrt(d2), order);
+      if (r == col && reg > 0.0f) v += (double)reg;
+    } else if (r < T && col < S) {  // B
+      v = (col - T) < I ? (double)cn[r * I + (col - T)] : 1.0;
+    } else if (r >= T && col < T) {  // B^T
+      v = (r - T) < I ? (double)cn[col * I + (r - T)] : 1.0;
+    } else if (r < T && col >= S) {
+      v = (double)fn[r * O + (col - S)];
+    }
+    a[i] = v;
+  }
+  __syncthreads();
+  solve_in_lds(a, S, O, piv);
+  for (int i = (int)threadIdx.x; i < S * O; i += (int)blockDim.x) {
+    const int r = i / O, o = i - r * O;
+    wv[(n * S + r) * O + o] = a[r * ld + S + o];
+  }
+}
+
+// out[n,q,o] = sum_t phi(|x_q - c_t|) w[t,o] + x_q . v[:I,o] + v[I,o]     (_img.py:67-76)
+__global__ void __launch_bounds__(256)
+spline_apply_kernel(const float *__restrict__ c, const double *__restrict__ wv,
+                    const float *__restrict__ x, int T, int I, int O, int Q, int order,
+                    float *__restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double *lw = reinterpret_cast<double *>(smem);            // (T + I + 1, O)
+  float *lc = reinterpret_cast<float *>(lw + (size_t)(T + I + 1) * O);  // (T, I)
+  const int64_t n = blockIdx.y;
+  for (int i = (int)threadIdx.x; i < (T + I + 1) * O; i += (int)blockDim.x)
+    lw[i] = wv[n * (int64_t)(T + I + 1) * O + i];
+  for (int i = (int)threadIdx.x; i < T * I; i += (int)blockDim.x) lc[i] = c[n * (int64_t)T * I + i];
+  __syncthreads();
+  const int q = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (q >= Q) return;
+  const float *xq = x + (n * (int64_t)Q + q) * I;
+  for (int o = 0; o < O; ++o) {
+    double acc = lw[(T + I) * O + o];
+    for (int k = 0; k < I; ++k) acc += (double)xq[k] * lw[(T + k) * O + o];
+    for (int t = 0; t < T; ++t) {
+      double d2 = 0.0;
+      for (int k = 0; k < I; ++k) {
+        const double d = (double)xq[k] - (double)lc[t * I + k];
+        d2 += d * d;
+      }
+      acc += phi_d(sqrt(d2), order) * lw[t * O + o];
+    }
+    out[(n * (int64_t)Q + q) * O + o] = (float)acc;
+  }
+}
+
+// warp_1d_grid (_img.py:268-303): one workgroup per batch element
+__global__ void __launch_bounds__(256)
+warp_1d_grid_kernel(const float *__restrict__ src, const float *__restrict__ flow,
+                    const float *__restrict__ lengths, int T, int order,
+                    float *__restrict__ grid) {
+  __shared__ double a[5 * 6];
+  __shared__ int piv;
+  __shared__ double knots[3];
+  const int64_t n = blockIdx.x;
+  const double len = (double)lengths[n];
+  if (threadIdx.x == 0) {
+    const double eps = (double)FLT_EPSILON;
+    double s = fmax(fmin((double)src[n], len - 1.0), 0.0);
+    double d = fmax(fmin(s + (double)flow[n], len - 1.0), 0.0);
+    s = (2.0 * s + 1.0) / T - 1.0;
+    d = (2.0 * d + 1.0) / T - 1.0;
+    const double lo = 1.0 / T - 1.0 - eps, up = (2.0 * len - 1.0) / T - 1.0 + eps;
+    const double cp[3] = {lo, d, up}, fv[3] = {lo, s, up};  // spline FROM dst TO src
+    for (int r = 0; r < 5; ++r)
+      for (int c = 0; c < 6; ++c) {
+        double v = 0.0;
+        if (r < 3 && c < 3) v = phi_d(fabs(cp[r] - cp[c]), order);
+        else if (r < 3 && c == 3) v = cp[r];
+        else if (r < 3 && c == 4) v = 1.0;
+        else if (r == 3 && c < 3) v = cp[c];
+        else if (r == 4 && c < 3) v = 1.0;
+        else if (r < 3 && c == 5) v = fv[r];
+        a[r * 6 + c] = v;
+      }
+    for (int k = 0; k < 3; ++k) knots[k] = cp[k];
+  }
+  __syncthreads();
+  solve_in_lds(a, 5, 1, &piv);
+  const double w0 = a[0 * 6 + 5], w1 = a[1 * 6 + 5], w2 = a[2 * 6 + 5];
+  const double v0 = a[3 * 6 + 5], v1 = a[4 * 6 + 5];
+  for (int j = (int)threadIdx.x; j < T; j += (int)blockDim.x) {
+    const double t = (2.0 * j + 1.0) / T - 1.0;
+    const double g = w0 * phi_d(fabs(t - knots[0]), order) + w1 * phi_d(fabs(t - knots[1]), order) +
+                     w2 * phi_d(fabs(t - knots[2]), order) + v0 * t + v1;
+    grid[n * (int64_t)T + j] = (float)g;
+  }
+}
+
+// ---- grid_sample arithmetic (align_corners = False) -----------------------------------------
+enum { PAD_ZEROS = 0, PAD_BORDER = 1, PAD_REFLECTION = 2 };
+enum { INTERP_BILINEAR = 0, INTERP_NEAREST = 1 };
+
+__device__ __forceinline__ float unnormalize(float g, int size) {
+  return ((g + 1.0f) * (float)size - 1.0f) * 0.5f;
+}
+__device__ __forceinline__ float clip_coord(float x, int size) {
+  return fminf((float)(size - 1), fmaxf(x, 0.0f));
+}
+__device__ __forceinline__ float reflect_coord(float x, int twice_low, int twice_high) {
+  if (twice_low == twice_high) return 0.0f;
+  const float mn = (float)twice_low * 0.5f, span = (float)(twice_high - twice_low) * 0.5f;
+  x = fabsf(x - mn);
+  const float extra = fmodf(x, span);
+  const int flips = (int)floorf(x / span);
+  return (flips & 1) ? span - extra + mn : extra + mn;
+}
+__device__ __forceinline__ float source_index(float g, int size, int padding) {
+  float x = unnormalize(g, size);
+  if (padding == PAD_BORDER) x = clip_coord(x, size);
+  else if (padding == PAD_REFLECTION) x = clip_coord(reflect_coord(x, -1, 2 * size - 1), size);
+  return x;
+}
+
+struct SpecAugArgs {
+  const float *feats; int64_t f_sn, f_st, f_sf;
+  const float *tgrid, *fgrid;          // (N,T) / (N,F) normalised grids or null
+  const int64_t *t0, *tl, *f0, *fl;    // (N,MT) / (N,MF) masks or null
+  int N, T, F, MT, MF;
+  float *out;                          // (N,T,F) contiguous
+};
+
+// One pass: bilinear gather along time and frequency + band masks.  Workgroup = 256 threads
+// walking a contiguous range of (t, f) positions of one utterance.
+__global__ void __launch_bounds__(256) spec_augment_apply_kernel(const SpecAugArgs a, int tiles) {
+  const int64_t n = blockIdx.x / tiles;
+  const int tile = (int)(blockIdx.x % tiles);
+  const int T = a.T, F = a.F;
+  const int rows_per_tile = (T + tiles - 1) / tiles;
+  const int t_begin = tile * rows_per_tile, t_end = min(T, t_begin + rows_per_tile);
+  const float *fn = a.feats + n * a.f_sn;
+  for (int idx = t_begin * F + (int)threadIdx.x; idx < t_end * F; idx += 256) {
+    const int t = idx / F, f = idx - t * F;
+    bool masked = false;
+    for (int m = 0; m < a.MT; ++m) {
+      const int64_t s = a.t0[n * a.MT + m];
+      masked = masked || (t >= s && t < s + a.tl[n * a.MT + m]);
+    }
+    for (int m = 0; m < a.MF; ++m) {
+      const int64_t s = a.f0[n * a.MF + m];
+      masked = masked || (f >= s && f < s + a.fl[n * a.MF + m]);
+    }
+    float v = 0.0f;
+    if (!masked) {
+      if (!a.tgrid && !a.fgrid) {
+        v = fn[(int64_t)t * a.f_st + (int64_t)f * a.f_sf];
+      } else {
+        // identity grids when only one axis is warped (:1173-1180)
+        const float gy = a.tgrid ? a.tgrid[n * T + t] : (2.0f * (float)t + 1.0f) / (float)T - 1.0f;
+        const float gx = a.fgrid ? a.fgrid[n * F + f] : (2.0f * (float)f + 1.0f) / (float)F - 1.0f;
+        const float iy = clip_coord(unnormalize(gy, T), T), ix = clip_coord(unnormalize(gx, F), F);
+        const float y0f = floorf(iy), x0f = floorf(ix);
+        const int y0 = (int)y0f, x0 = (int)x0f, y1 = y0 + 1, x1 = x0 + 1;
+        const float wy1 = iy - y0f, wx1 = ix - x0f, wy0 = (y0f + 1.0f) - iy, wx0 = (x0f + 1.0f) - ix;
+        const float *r0 = fn + (int64_t)y0 * a.f_st;
+        const float *r1 = fn + (int64_t)min(y1, T - 1) * a.f_st;
+        const int64_t c0 = (int64_t)x0 * a.f_sf, c1 = (int64_t)min(x1, F - 1) * a.f_sf;
+        // taps outside the image carry weight 0 under border padding
+        v = r0[c0] * (wx0 * wy0);
+        if (x1 < F) v += r0[c1] * (wx1 * wy0);
+        if (y1 < T) v += r1[c0] * (wx0 * wy1);
+        if (x1 < F && y1 < T) v += r1[c1] * (wx1 * wy1);
+      }
+    }
+    a.out[(n * T + t) * (int64_t)F + f] = v;
+  }
+}
+
+struct WarpArgs {
+  const float *image;  // (N,C,H,W) contiguous
+  float *out;          // (N,C,H,W)
+  int N, C, H, W;
+  int mode, padding;
+  // source of the sampling position, one of:
+  const float *flow;   // dense: (N,H,W,2); position = pixel - flow (x = last dim 0 unless flip)
+  int flip;            // dense: flow[..., 0] is the H component ("hw" indexing)
+  const float *knots;  // sparse: (N,M,2) spline centres (x, y), float
+  const float *wv;     // sparse: (N, M+3, 2) float weights (w, then v_x, v_y, v_1)
+  int M, order, as_grid;  // as_grid: the spline yields the normalised grid itself (no-flow form)
+  float *flow_out;     // sparse, optional (N,H,W,2)
+  int flow_out_flip;
+};
+
+__global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float *lk = reinterpret_cast<float *>(smem);  // knots (M,2) then weights (M+3,2)
+  float *lw = lk + 2 * a.M;
+  const int64_t n = blockIdx.y;
+  const int H = a.H, W = a.W;
+  if (a.knots) {
+    for (int i = (int)threadIdx.x; i < 2 * a.M; i += 256) lk[i] = a.knots[n * 2 * a.M + i];
+    for (int i = (int)threadIdx.x; i < 2 * (a.M + 3); i += 256) lw[i] = a.wv[n * 2 * (a.M + 3) + i];
+    __syncthreads();
+  }
+  const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (pix >= H * W) return;
+  const int h = pix / W, w = pix - h * W;
+  float gx, gy;
+  if (a.knots) {
+    const float x = (float)w, y = (float)h;
+    float sx = lw[2 * a.M + 0] * x + lw[2 * (a.M + 1) + 0] * y + lw[2 * (a.M + 2) + 0];
+    float sy = lw[2 * a.M + 1] * x + lw[2 * (a.M + 1) + 1] * y + lw[2 * (a.M + 2) + 1];
+    for (int m = 0; m < a.M; ++m) {
+      const float dx = x - lk[2 * m], dy = y - lk[2 * m + 1];
+      const float p = phi_f(sqrtf(dx * dx + dy * dy), a.order);
+      sx += p * lw[2 * m];
+      sy += p * lw[2 * m + 1];
+    }
+    if (a.as_grid) {
+      gx = sx;
+      gy = sy;
+    } else {
+      if (a.flow_out) {
+        float *fo = a.flow_out + ((n * H + h) * (int64_t)W + w) * 2;
+        fo[0] = a.flow_out_flip ? sy : sx;
+        fo[1] = a.flow_out_flip ? sx : sy;
+      }
+      gx = (2.0f * x - 2.0f * sx + 1.0f) / (float)W - 1.0f;  // _img.py:432
+      gy = (2.0f * y - 2.0f * sy + 1.0f) / (float)H - 1.0f;
+    }
+  } else {
+    const float *fl = a.flow + ((n * H + h) * (int64_t)W + w) * 2;
+    const float fx = a.flip ? fl[1] : fl[0], fy = a.flip ? fl[0] : fl[1];
+    gx = (2.0f * (float)w - 2.0f * fx + 1.0f) / (float)W - 1.0f;
+    gy = (2.0f * (float)h - 2.0f * fy + 1.0f) / (float)H - 1.0f;
+  }
+  const float ix = source_index(gx, W, a.padding), iy = source_index(gy, H, a.padding);
+  const int64_t plane = (int64_t)H * W;
+  const float *img = a.image + n * a.C * plane;
+  float *o = a.out + n * a.C * plane + pix;
+  if (a.mode == INTERP_NEAREST) {
+    const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+    const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
+    for (int c = 0; c < a.C; ++c) o[c * plane] = ok ? img[c * plane + (int64_t)yn * W + xn] : 0.0f;
+    return;
+  }
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
+  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+  for (int c = 0; c < a.C; ++c) {
+    const float *pl = img + c * plane;
+    float v = 0.0f;
+    if (vx0 && vy0) v += pl[(int64_t)y0 * W + x0] * (wx0 * wy0);
+    if (vx1 && vy0) v += pl[(int64_t)y0 * W + x1] * (wx1 * wy0);
+    if (vx0 && vy1) v += pl[(int64_t)y1 * W + x0] * (wx0 * wy1);
+    if (vx1 && vy1) v += pl[(int64_t)y1 * W + x1] * (wx1 * wy1);
+    o[c * plane] = v;
+  }
+}
+
+// copy the double solution into float (w, v) laid out (N, M+3, 2) for image_warp_kernel
+__global__ void cast_wv_kernel(const double *__restrict__ wv, float *__restrict__ out, int64_t total) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < total) out[i] = (float)wv[i];
+}
+
+}  // namespace pdt
+
+extern "C" {
+
+int64_t pdt_spline_workspace_bytes(int64_t N, int64_t T, int64_t I, int64_t O) {
+  if (N < 0 || T < 0 || I < 0 || O < 0) return 0;
+  return N * (T + I + 1) * O * (int64_t)(sizeof(double) + sizeof(float)) + 64;
+}
+
+static int spline_solve(const float *c, const float *f, int64_t N, int64_t T, int64_t I, int64_t O,
+                        int order, float reg, double *wv, hipStream_t stream) {
+  using namespace pdt;
+  const int64_t S = T + I + 1;
+  if (S > kMaxSplineSys) return PDT_E_TOO_LONG;
+  const size_t smem = (size_t)S * (S + O) * sizeof(double) + 16;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(spline_solve_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(spline_solve_kernel, dim3((unsigned)N), dim3(256), smem, stream, c, f, (int)T,
+                     (int)I, (int)O, order, reg, wv);
+  return (int)hipGetLastError();
+}
+
+int pdt_polyharmonic_spline(const float *train_points, const float *train_values,
+                            const float *query_points, int64_t N, int64_t T, int64_t I, int64_t O,
+                            int64_t Q, int order, float regularization_weight, float *out,
+                            void *workspace, void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 1 || I < 1 || O < 1 || Q < 0 || order < 1) return PDT_E_ARG;
+  if (N == 0 || Q == 0) return PDT_OK;
+  if (!train_points || !train_values || !query_points || !out || !workspace) return PDT_E_ARG;
+  if (N > 65535) return PDT_E_TOO_LONG;
+  double *wv = reinterpret_cast<double *>(workspace);
+  int rc = spline_solve(train_points, train_values, N, T, I, O, order, regularization_weight, wv,
+                        (hipStream_t)stream);
+  if (rc != PDT_OK) return rc;
+  const size_t smem = (size_t)(T + I + 1) * O * sizeof(double) + (size_t)T * I * sizeof(float);
+  hipLaunchKernelGGL(spline_apply_kernel, dim3((unsigned)((Q + 255) / 256), (unsigned)N), dim3(256),
+                     smem, (hipStream_t)stream, train_points, wv, query_points, (int)T, (int)I,
+                     (int)O, (int)Q, order, out);
+  return (int)hipGetLastError();
+}
+
+int pdt_warp_1d_grid(const float *src, const float *flow, const float *lengths, int64_t N, int64_t T,
+                     int order, float *grid, void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 0 || order < 1) return PDT_E_ARG;
+  if (N == 0 || T == 0) return PDT_OK;
+  if (!src || !flow || !lengths || !grid) return PDT_E_ARG;
+  hipLaunchKernelGGL(warp_1d_grid_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, src,
+                     flow, lengths, (int)T, order, grid);
+  return (int)hipGetLastError();
+}
+
+int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, int64_t f_sn,
+                           int64_t f_st, int64_t f_sf, const float *time_grid,
+                           const float *freq_grid, const int64_t *t_0, const int64_t *t_len,
+                           int64_t MT, const int64_t *f_0, const int64_t *f_len, int64_t MF,
+                           float *out, void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 0 || F < 0 || MT < 0 || MF < 0) return PDT_E_ARG;
+  if (N == 0 || T == 0 || F == 0) return PDT_OK;
+  if (!feats || !out || (MT > 0 && (!t_0 || !t_len)) || (MF > 0 && (!f_0 || !f_len))) return PDT_E_ARG;
+  if (T * F >= (1ll << 31)) return PDT_E_TOO_LONG;
+  SpecAugArgs a{};
+  a.feats = feats; a.f_sn = f_sn; a.f_st = f_st; a.f_sf = f_sf;
+  a.tgrid = time_grid; a.fgrid = freq_grid;
+  a.t0 = t_0; a.tl = t_len; a.f0 = f_0; a.fl = f_len;
+  a.N = (int)N; a.T = (int)T; a.F = (int)F; a.MT = (int)MT; a.MF = (int)MF;
+  a.out = out;
+  // ~16K elements per workgroup keeps >= 8 workgroups per CU in flight at N = 2048
+  int tiles = (int)((T * F + 16383) / 16384);
+  if (tiles < 1) tiles = 1;
+  hipLaunchKernelGGL(spec_augment_apply_kernel, dim3((unsigned)(N * tiles)), dim3(256), 0,
+                     (hipStream_t)stream, a, tiles);
+  return (int)hipGetLastError();
+}
+
+int pdt_dense_image_warp(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                         int64_t W, int flow_is_hw, int mode, int padding, float *out,
+                         void *stream) {
+  using namespace pdt;
+  if (N < 0 || C < 0 || H < 0 || W < 0 || mode < 0 || mode > 1 || padding < 0 || padding > 2)
+    return PDT_E_ARG;
+  if (N == 0 || C == 0 || H == 0 || W == 0) return PDT_OK;
+  if (!image || !flow || !out) return PDT_E_ARG;
+  if (H * W >= (1ll << 31) || N > 65535) return PDT_E_TOO_LONG;
+  WarpArgs a{};
+  a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
+  a.mode = mode; a.padding = padding; a.flow = flow; a.flip = flow_is_hw;
+  hipLaunchKernelGGL(image_warp_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N),
+                     dim3(256), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+int pdt_sparse_image_warp(const float *image, const float *train_points,
+                          const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
+                          int64_t M, int order, float regularization_weight, int values_are_grid,
+                          int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
+                          void *workspace, void *stream) {
+  using namespace pdt;
+  if (N < 0 || C < 0 || H < 0 || W < 0 || M < 1 || order < 1 || mode < 0 || mode > 1 ||
+      padding < 0 || padding > 2)
+    return PDT_E_ARG;
+  if (N == 0 || C == 0 || H == 0 || W == 0) return PDT_OK;
+  if (!image || !train_points || !train_values || !out || !workspace) return PDT_E_ARG;
+  if (H * W >= (1ll << 31) || N > 65535) return PDT_E_TOO_LONG;
+  double *wv = reinterpret_cast<double *>(workspace);
+  int rc = spline_solve(train_points, train_values, N, M, 2, 2, order, regularization_weight, wv,
+                        (hipStream_t)stream);
+  if (rc != PDT_OK) return rc;
+  const int64_t total = N * (M + 3) * 2;
+  float *wvf = reinterpret_cast<float *>(wv + total);
+  hipLaunchKernelGGL(cast_wv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, wv, wvf, total);
+  WarpArgs a{};
+  a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
+  a.mode = mode; a.padding = padding;
+  a.knots = train_points; a.wv = wvf; a.M = (int)M; a.order = order; a.as_grid = values_are_grid;
+  a.flow_out = flow_out; a.flow_out_flip = flow_out_is_hw;
+  const size_t smem = (size_t)(2 * M + 2 * (M + 3)) * sizeof(float);
+  hipLaunchKernelGGL(image_warp_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N),
+                     dim3(256), smem, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -51,6 +51,20 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
         + [_P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     ),
+    "pdt_spline_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),
+    "pdt_polyharmonic_spline": (
+        _INT, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _P, _P, _P],
+    ),
+    "pdt_warp_1d_grid": (_INT, [_P, _P, _P, _I64, _I64, _INT, _P, _P]),
+    "pdt_spec_augment_apply": (
+        _INT,
+        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P],
+    ),
+    "pdt_dense_image_warp": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P, _P]),
+    "pdt_sparse_image_warp": (
+        _INT,
+        [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _INT, _P, _P],
+    ),
     "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_ctc_prefix_search": (
         _INT,

@@ -1,0 +1,621 @@
+"""SpecAugment, polyharmonic splines and image warps on MI355X.
+
+Host-side mirror of the reference's ``_img.py`` for the operators on the hot path
+(``polyharmonic_spline``, ``warp_1d_grid``, ``dense_image_warp``, ``sparse_image_warp``,
+``spec_augment*`` and their Modules).  Kernels: ``csrc/img_warp.hip`` through the C ABI
+(``include/pdt_amd.h``).  ``spec_augment_apply_parameters`` and the image warps are
+differentiable with respect to the features / image (bilinear scatter in the backward pass).
+"""
+import math
+from typing import Any, Optional, Tuple
+
+import torch
+
+from . import _cabi, argcheck
+
+__all__ = [
+    "DenseImageWarp",
+    "PolyharmonicSpline",
+    "SparseImageWarp",
+    "SpecAugment",
+    "Warp1DGrid",
+    "dense_image_warp",
+    "polyharmonic_spline",
+    "sparse_image_warp",
+    "spec_augment",
+    "spec_augment_apply_parameters",
+    "spec_augment_draw_parameters",
+    "warp_1d_grid",
+]
+
+_MODES = {"bilinear": 0, "nearest": 1}
+_PADDINGS = {"zeros": 0, "border": 1, "reflection": 2}
+_INDEXINGS = ("hw", "wh")
+SpecAugmentParams = Tuple[torch.Tensor, ...]
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float:
+        t = t.float()
+    return t.contiguous()
+
+
+def polyharmonic_spline(
+    train_points: torch.Tensor,
+    train_values: torch.Tensor,
+    query_points: torch.Tensor,
+    order: int,
+    regularization_weight: float = 0.0,
+    full_matrix: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`PolyharmonicSpline` (reference _img.py:133-150).
+
+    ``full_matrix`` is accepted for signature parity: the bordered system is solved exactly in
+    float64, which both of the reference's float32 evaluation orders approximate.
+    """
+    if train_points.dim() != 3 or train_values.dim() != 3 or query_points.dim() != 3:
+        raise RuntimeError("train_points, train_values and query_points must be 3 dimensional")
+    N, T, I = train_points.shape
+    O, Q = train_values.shape[2], query_points.shape[1]
+    if train_values.shape[:2] != (N, T) or query_points.shape[0] != N or query_points.shape[2] != I:
+        raise RuntimeError("train_points, train_values and query_points have inconsistent shapes")
+    device = _cabi.require_hip(train_points, train_values, query_points)
+    if T + I + 1 > 100:
+        raise RuntimeError("polyharmonic_spline: more than {} control points".format(100 - I - 1))
+    c, f, x = _f32c(train_points), _f32c(train_values), _f32c(query_points)
+    L = _cabi.lib()
+    with torch.cuda.device(device):
+        out = torch.empty((N, Q, O), device=device, dtype=torch.float)
+        ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, T, I, O)),), device=device, dtype=torch.uint8)
+        rc = L.pdt_polyharmonic_spline(
+            _cabi.ptr(c), _cabi.ptr(f), _cabi.ptr(x), N, T, I, O, Q, int(order),
+            float(regularization_weight), _cabi.ptr(out), _cabi.ptr(ws), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_polyharmonic_spline")
+    return out.to(train_values.dtype)
+
+
+def warp_1d_grid(
+    src: torch.Tensor,
+    flow: torch.Tensor,
+    lengths: torch.Tensor,
+    max_length: Optional[int] = None,
+    interpolation_order: int = 1,
+) -> torch.Tensor:
+    """Functional version of :class:`Warp1DGrid` (reference _img.py:268-303)."""
+    device = _cabi.require_hip(src, flow, lengths)
+    N = src.shape[0]
+    if max_length is None:
+        T = int(math.ceil(lengths.max().item())) if lengths.numel() else 0  # :279
+    else:
+        T = max_length
+    s, fl, ln = _f32c(src), _f32c(flow), _f32c(lengths)
+    with torch.cuda.device(device):
+        grid = torch.empty((N, T), device=device, dtype=torch.float)
+        rc = _cabi.lib().pdt_warp_1d_grid(
+            _cabi.ptr(s), _cabi.ptr(fl), _cabi.ptr(ln), N, T, int(interpolation_order),
+            _cabi.ptr(grid), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_warp_1d_grid")
+    return grid
+
+
+class _DenseWarpFn(torch.autograd.Function):
+    """dense_image_warp with a gradient for the image (bilinear taps are linear in it)."""
+
+    @staticmethod
+    def forward(ctx, image, flow, flow_is_hw, mode, padding):
+        device = image.device
+        img, fl = _f32c(image), _f32c(flow)
+        N, C, H, W = img.shape
+        with torch.cuda.device(device):
+            out = torch.empty_like(img)
+            rc = _cabi.lib().pdt_dense_image_warp(
+                _cabi.ptr(img), _cabi.ptr(fl), N, C, H, W, int(flow_is_hw), mode, padding,
+                _cabi.ptr(out), _cabi.stream_ptr(device),
+            )  # fmt: skip
+        _cabi.check(rc, "pdt_dense_image_warp")
+        ctx.save_for_backward(fl)
+        ctx.cfg = (flow_is_hw, mode, padding, image.dtype)
+        return out.to(image.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (fl,) = ctx.saved_tensors
+        flow_is_hw, mode, padding, dtype = ctx.cfg
+        grad_image = _grid_sample_image_grad(grad_out, fl, flow_is_hw, mode, padding)
+        return grad_image.to(dtype), None, None, None, None
+
+
+def _grid_sample_image_grad(grad_out, flow, flow_is_hw, mode, padding):
+    # adjoint of the gather w.r.t. the image, via autograd on the equivalent grid_sample
+    N, C, H, W = grad_out.shape
+    fl = flow.flip(-1) if flow_is_hw else flow
+    h = torch.arange(H, dtype=torch.float, device=flow.device)
+    w = torch.arange(W, dtype=torch.float, device=flow.device)
+    hh, ww = torch.meshgrid(h, w, indexing="ij")
+    hw = torch.stack((ww, hh), 2).unsqueeze(0)
+    HW = torch.tensor([[[[W, H]]]], dtype=torch.float, device=flow.device)
+    grid = (2 * hw - 2 * fl + 1.0) / HW - 1.0
+    with torch.enable_grad():
+        probe = torch.zeros((N, C, H, W), device=flow.device, dtype=torch.float, requires_grad=True)
+        mode_s = [k for k, v in _MODES.items() if v == mode][0]
+        pad_s = [k for k, v in _PADDINGS.items() if v == padding][0]
+        out = torch.nn.functional.grid_sample(probe, grid, mode=mode_s, padding_mode=pad_s, align_corners=False)
+        (g,) = torch.autograd.grad(out, probe, grad_out.float())
+    return g
+
+
+def dense_image_warp(
+    image: torch.Tensor,
+    flow: torch.Tensor,
+    indexing: str = "hw",
+    mode: str = "bilinear",
+    padding_mode: str = "border",
+) -> torch.Tensor:
+    """Functional version of :class:`DenseImageWarp` (reference _img.py:393-439):
+    ``output[n, c, h, w] = image[n, c, h - flow[n, h, w, 0], w - flow[n, h, w, 1]]``."""
+    if indexing not in _INDEXINGS:
+        raise ValueError("Invalid indexing! must be one of 'wh' or 'hw'")
+    if image.dim() != 4 or flow.dim() != 4:
+        raise RuntimeError("image and flow must be 4 dimensional")
+    N, C, H, W = image.shape
+    if flow.shape != (N, H, W, 2):
+        raise RuntimeError("expected flow to have shape {}, got {}".format((N, H, W, 2), tuple(flow.shape)))
+    _cabi.require_hip(image, flow)
+    return _DenseWarpFn.apply(image, flow, indexing == "hw", _MODES[mode], _PADDINGS[padding_mode])
+
+
+def _pinned_points(k: int, W: int, H: int, N: int, device) -> torch.Tensor:
+    # reference _img.py:244-265, points in (x=w, y=h) order
+    r = torch.linspace(0.0, 1.0, k + 1, device=device)
+    wr, hr = (W - 1) * r, (H - 1) * r
+    z = torch.zeros_like(r)
+    pts = torch.cat(
+        [
+            torch.stack([wr, z], 1),
+            torch.stack([z[1:-1], hr[1:-1]], 1),
+            torch.stack([wr, torch.full_like(r, H - 1.0)], 1),
+            torch.stack([torch.full_like(r, W - 1.0)[1:-1], hr[1:-1]], 1),
+        ],
+        0,
+    )
+    return pts.unsqueeze(0).expand(N, -1, -1)
+
+
+def sparse_image_warp(
+    image: torch.Tensor,
+    source_points: torch.Tensor,
+    dest_points: torch.Tensor,
+    indexing: str = "hw",
+    field_interpolation_order: int = 2,
+    field_regularization_weight: float = 0.0,
+    field_full_matrix: bool = True,
+    pinned_boundary_points: int = 0,
+    dense_interpolation_mode: str = "bilinear",
+    dense_padding_mode: str = "border",
+    include_flow: bool = True,
+) -> Any:
+    """Functional version of :class:`SparseImageWarp` (reference _img.py:520-714).
+
+    The spline over the control points is evaluated per pixel inside the gather kernel; the
+    dense flow field is only written when ``include_flow``.
+    """
+    if indexing not in _INDEXINGS:
+        raise ValueError("Invalid indexing! must be one of 'wh' or 'hw'")
+    if image.dim() != 4:
+        raise RuntimeError("image must be 4 dimensional")
+    device = _cabi.require_hip(image, source_points, dest_points)
+    N, C, H, W = image.shape
+    src, dst = source_points.detach().float(), dest_points.detach().float()
+    if indexing == "hw":
+        src, dst = src.flip(-1), dst.flip(-1)
+    M = src.shape[1]
+    if M == 0:  # :543-548
+        if include_flow:
+            return image, torch.zeros((N, H, W, 2), dtype=torch.float, device=device)
+        return image
+    if pinned_boundary_points > 0:
+        pp = _pinned_points(pinned_boundary_points, W, H, N, device)
+        src, dst = torch.cat([src, pp], 1), torch.cat([dst, pp], 1)
+    Mp = src.shape[1]
+    if Mp + 3 > 100:
+        raise RuntimeError("sparse_image_warp: more than 97 control points")
+    if include_flow:
+        vals = dst - src  # :561-562
+    else:
+        WH = torch.tensor([W, H], dtype=torch.float, device=device)
+        vals = (2.0 * src + 1.0) / WH - 1.0  # :633
+    img = _f32c(image)
+    pts, vals = dst.contiguous(), vals.contiguous()
+    L = _cabi.lib()
+    with torch.cuda.device(device):
+        out = torch.empty_like(img)
+        flow = torch.empty((N, H, W, 2), device=device, dtype=torch.float) if include_flow else None
+        ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, Mp, 2, 2)),), device=device, dtype=torch.uint8)
+        rc = L.pdt_sparse_image_warp(
+            _cabi.ptr(img), _cabi.ptr(pts), _cabi.ptr(vals), N, C, H, W, Mp,
+            int(field_interpolation_order), float(field_regularization_weight),
+            int(not include_flow), _MODES[dense_interpolation_mode], _PADDINGS[dense_padding_mode],
+            _cabi.ptr(out), _cabi.ptr(flow), int(indexing == "hw"), _cabi.ptr(ws),
+            _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_sparse_image_warp")
+    out = out.to(image.dtype)
+    return (out, flow) if include_flow else out
+
+
+def _spec_augment_check_input(feats: torch.Tensor, lengths: Optional[torch.Tensor] = None):
+    # reference _img.py:1020-1041
+    if feats.dim() != 3:
+        raise RuntimeError("Expected feats to have three dimensions, got {}".format(feats.dim()))
+    N, T, _ = feats.shape
+    if lengths is not None:
+        if lengths.dim() != 1:
+            raise RuntimeError("Expected lengths to be one dimensional, got {}".format(lengths.dim()))
+        if lengths.size(0) != N:
+            raise RuntimeError(
+                "Batch dimension of feats ({}) and lengths ({}) do not match".format(N, lengths.size(0))
+            )
+        if not bool(torch.all((lengths <= T) & (lengths > 0))):
+            raise RuntimeError("values of lengths must be between (1, {})".format(T))
+
+
+def spec_augment_draw_parameters(
+    feats: torch.Tensor,
+    max_time_warp: float,
+    max_freq_warp: float,
+    max_time_mask: int,
+    max_freq_mask: int,
+    max_time_mask_proportion: float,
+    num_time_mask: int,
+    num_time_mask_proportion: float,
+    num_freq_mask: int,
+    lengths: Optional[torch.Tensor] = None,
+) -> SpecAugmentParams:
+    """Functional version of :func:`SpecAugment.draw_parameters` (reference _img.py:1056-1139).
+
+    Draws are made on ``feats.device`` with torch's generator in the reference's order
+    (w_0, w, v_0, v, t, t_0, f, f_0); six tiny launches, not on the bandwidth path.
+    """
+    _spec_augment_check_input(feats, lengths)
+    N, T, F = feats.shape
+    device = feats.device
+    eps = torch.finfo(feats.dtype if feats.dtype.is_floating_point else torch.float).eps
+    omeps = 1 - eps
+    if lengths is None:
+        lengths = torch.full((N,), T, dtype=torch.float, device=device)
+    else:
+        lengths = lengths.to(device).float()
+    empty = torch.empty(0)
+    if max_time_warp:
+        Wt = (lengths / 2 - eps).clamp(0, max_time_warp)
+        w_0 = torch.rand((N,), device=device) * (lengths - 2 * Wt) + Wt
+        w = torch.rand((N,), device=device) * (2 * Wt) - Wt
+    else:
+        w_0 = w = empty
+    if max_freq_warp:
+        Vf = min(max(F / 2 - eps, 0), max_freq_warp)
+        v_0 = torch.rand((N,), device=device) * (F - 2 * Vf) + Vf
+        v = torch.rand((N,), device=device) * (2 * Vf) - Vf
+    else:
+        v_0 = v = empty
+    if max_time_mask and max_time_mask_proportion and num_time_mask and num_time_mask_proportion:
+        max_ = torch.clamp(lengths * max_time_mask_proportion, max=max_time_mask).floor()
+        nums_ = torch.clamp(lengths * num_time_mask_proportion, max=num_time_mask).floor()
+        t = (torch.rand((N, num_time_mask), device=device) * (max_ + omeps).unsqueeze(1)).long()
+        t = t.masked_fill(
+            nums_.unsqueeze(1) <= torch.arange(num_time_mask, dtype=lengths.dtype, device=device), 0
+        )
+        t_0 = (torch.rand((N, num_time_mask), device=device) * (lengths.unsqueeze(1) - t + omeps)).long()
+    else:
+        t = t_0 = empty
+    if max_freq_mask and num_freq_mask:
+        max_ = min(max_freq_mask, F)
+        f = (torch.rand((N, num_freq_mask), device=device) * (max_ + omeps)).long()
+        f_0 = (torch.rand((N, num_freq_mask), device=device) * (F - f + omeps)).long()
+    else:
+        f = f_0 = empty
+    return w_0, w, v_0, v, t_0, t, f_0, f
+
+
+def _has(a: Optional[torch.Tensor], b: Optional[torch.Tensor]) -> bool:
+    return a is not None and a.numel() > 0 and b is not None and b.numel() > 0
+
+
+def _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f):
+    device = feats.device
+    N, T, F = feats.shape
+    x = feats.detach()
+    if x.dtype != torch.float:
+        x = x.float()
+    mt = 0 if t_0 is None else t_0.shape[1]
+    mf = 0 if f_0 is None else f_0.shape[1]
+    with torch.cuda.device(device):
+        out = torch.empty((N, T, F), device=device, dtype=torch.float)
+        rc = _cabi.lib().pdt_spec_augment_apply(
+            _cabi.ptr(x), N, T, F, x.stride(0), x.stride(1), x.stride(2),
+            _cabi.ptr(tgrid), _cabi.ptr(fgrid), _cabi.ptr(t_0), _cabi.ptr(t), mt,
+            _cabi.ptr(f_0), _cabi.ptr(f), mf, _cabi.ptr(out), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_spec_augment_apply")
+    return out
+
+
+class _SpecApplyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, tgrid, fgrid, t_0, t, f_0, f):
+        out = _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f)
+        ctx.grids = (tgrid, fgrid, t_0, t, f_0, f)
+        ctx.dtype = feats.dtype
+        return out.to(feats.dtype)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        tgrid, fgrid, t_0, t, f_0, f = ctx.grids
+        N, T, F = grad_out.shape
+        dev = grad_out.device
+        g = grad_out.float()
+        # masked positions carry no gradient
+        if t_0 is not None:
+            ar = torch.arange(T, device=dev).view(1, T, 1)
+            m = ((ar >= t_0.unsqueeze(1)) & (ar < (t_0 + t).unsqueeze(1))).any(2, keepdim=True)
+            g = g.masked_fill(m, 0.0)
+        if f_0 is not None:
+            ar = torch.arange(F, device=dev).view(1, F, 1)
+            m = ((ar >= f_0.unsqueeze(1)) & (ar < (f_0 + f).unsqueeze(1))).any(2).unsqueeze(1)
+            g = g.masked_fill(m, 0.0)
+        if tgrid is None and fgrid is None:
+            return g.to(ctx.dtype), None, None, None, None, None, None
+        tg = tgrid if tgrid is not None else ((2 * torch.arange(T, device=dev, dtype=torch.float) + 1) / T - 1).expand(N, T)
+        fg = fgrid if fgrid is not None else ((2 * torch.arange(F, device=dev, dtype=torch.float) + 1) / F - 1).expand(N, F)
+        grid = torch.stack([fg.unsqueeze(1).expand(N, T, F), tg.unsqueeze(2).expand(N, T, F)], 3)
+        with torch.enable_grad():
+            probe = torch.zeros((N, 1, T, F), device=dev, dtype=torch.float, requires_grad=True)
+            o = torch.nn.functional.grid_sample(probe, grid, mode="bilinear", padding_mode="border", align_corners=False)
+            (gi,) = torch.autograd.grad(o, probe, g.unsqueeze(1))
+        return gi.squeeze(1).to(ctx.dtype), None, None, None, None, None, None
+
+
+def spec_augment_apply_parameters(
+    feats: torch.Tensor,
+    params: SpecAugmentParams,
+    interpolation_order: int,
+    lengths: Optional[torch.Tensor] = None,
+) -> torch.Tensor:
+    """Functional version of :func:`SpecAugment.apply_parameters` (reference
+    _img.py:1142-1211): time / frequency warp by bilinear resampling, then band masks, as ONE
+    pass over ``feats`` (plus two tiny grid kernels)."""
+    _spec_augment_check_input(feats, lengths)
+    device = _cabi.require_hip(feats)
+    N, T, F = feats.shape
+    if lengths is None:
+        lengths = torch.full((N,), T, dtype=torch.long, device=device)
+    lengths = lengths.to(device)
+    w_0, w, v_0, v, t_0, t, f_0, f = params
+    tgrid = fgrid = None
+    if _has(w_0, w):
+        tgrid = warp_1d_grid(w_0.to(device), w.to(device), lengths, T, interpolation_order)
+    if _has(v_0, v):
+        fgrid = warp_1d_grid(
+            v_0.to(device), v.to(device), torch.full((N,), F, dtype=torch.long, device=device), F,
+            interpolation_order,
+        )  # fmt: skip
+    if _has(t_0, t):
+        t_0, t = t_0.to(device).long().contiguous(), t.to(device).long().contiguous()
+    else:
+        t_0 = t = None
+    if _has(f_0, f):
+        f_0, f = f_0.to(device).long().contiguous(), f.to(device).long().contiguous()
+    else:
+        f_0 = f = None
+    if tgrid is None and fgrid is None and t_0 is None and f_0 is None:
+        return feats
+    if feats.requires_grad and torch.is_grad_enabled():
+        return _SpecApplyFn.apply(feats, tgrid, fgrid, t_0, t, f_0, f)
+    return _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f).to(feats.dtype)
+
+
+def spec_augment(
+    feats: torch.Tensor,
+    max_time_warp: float,
+    max_freq_warp: float,
+    max_time_mask: int,
+    max_freq_mask: int,
+    max_time_mask_proportion: float,
+    num_time_mask: int,
+    num_time_mask_proportion: float,
+    num_freq_mask: int,
+    interpolation_order: int,
+    lengths: Optional[torch.Tensor] = None,
+    training: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`SpecAugment` (reference _img.py:1214-1245)."""
+    _spec_augment_check_input(feats, lengths)
+    if not training:
+        return feats
+    params = spec_augment_draw_parameters(
+        feats, max_time_warp, max_freq_warp, max_time_mask, max_freq_mask,
+        max_time_mask_proportion, num_time_mask, num_time_mask_proportion, num_freq_mask, lengths,
+    )  # fmt: skip
+    return spec_augment_apply_parameters(feats, params, interpolation_order, lengths)
+
+
+# ---------------------------------------------------------------------------------------
+class _ReprMixin:
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+
+class PolyharmonicSpline(_ReprMixin, torch.nn.Module):
+    """Guess a surface with a polyharmonic spline (reference _img.py:153-241)."""
+
+    __constants__ = "order", "regularization_weight", "full_matrix"
+
+    def __init__(self, order: int, regularization_weight: float = 0.0, full_matrix: bool = True):
+        order = argcheck.is_posi(order, "order")
+        regularization_weight = argcheck.is_float(regularization_weight, "regularization_weight")
+        full_matrix = argcheck.is_bool(full_matrix, "full_matrix")
+        super().__init__()
+        self.order, self.regularization_weight, self.full_matrix = order, regularization_weight, full_matrix
+
+    def forward(self, train_points, train_values, query_points) -> torch.Tensor:
+        return polyharmonic_spline(
+            train_points, train_values, query_points, self.order, self.regularization_weight,
+            self.full_matrix,
+        )  # fmt: skip
+
+
+class Warp1DGrid(torch.nn.Module):
+    """Interpolate grid values for a 1-D warp (reference _img.py:306-379)."""
+
+    __constants__ = "max_length", "interpolation_order"
+
+    def __init__(self, max_length: Optional[int] = None, interpolation_order: int = 1):
+        if max_length is not None:
+            max_length = argcheck.is_nonnegi(max_length, "max_length")
+        interpolation_order = argcheck.is_posi(interpolation_order, "interpolation_order")
+        super().__init__()
+        self.max_length, self.interpolation_order = max_length, interpolation_order
+
+    def extra_repr(self) -> str:
+        s = "interpolation_order={}".format(self.interpolation_order)
+        if self.max_length is not None:
+            s = "max_length={}, ".format(self.max_length) + s
+        return s
+
+    def forward(self, src, flow, lengths) -> torch.Tensor:
+        return warp_1d_grid(src, flow, lengths, self.max_length, self.interpolation_order)
+
+
+class DenseImageWarp(_ReprMixin, torch.nn.Module):
+    """Warp an input image with per-pixel flow vectors (reference _img.py:442-517)."""
+
+    __constants__ = "indexing", "mode", "padding_mode"
+
+    def __init__(self, indexing: str = "hw", mode: str = "bilinear", padding_mode: str = "border"):
+        indexing = argcheck.is_in(indexing, _INDEXINGS, "indexing")
+        mode = argcheck.is_in(mode, tuple(_MODES), "mode")
+        padding_mode = argcheck.is_in(padding_mode, tuple(_PADDINGS), "padding_mode")
+        super().__init__()
+        self.indexing, self.mode, self.padding_mode = indexing, mode, padding_mode
+
+    def forward(self, image: torch.Tensor, flow: torch.Tensor) -> torch.Tensor:
+        return dense_image_warp(image, flow, self.indexing, self.mode, self.padding_mode)
+
+
+class SparseImageWarp(_ReprMixin, torch.nn.Module):
+    """Warp an image by specifying mappings between few control points (reference
+    _img.py:717-880)."""
+
+    __constants__ = (
+        "indexing", "field_interpolation_order", "field_regularization_weight",
+        "field_full_matrix", "pinned_boundary_points", "dense_interpolation_mode",
+        "dense_padding_mode", "include_flow",
+    )  # fmt: skip
+
+    def __init__(
+        self,
+        indexing: str = "hw",
+        field_interpolation_order: int = 2,
+        field_regularization_weight: float = 0.0,
+        field_full_matrix: bool = True,
+        pinned_boundary_points: int = 0,
+        dense_interpolation_mode: str = "bilinear",
+        dense_padding_mode: str = "border",
+        include_flow: bool = True,
+    ):
+        indexing = argcheck.is_in(indexing, _INDEXINGS, "indexing")
+        field_interpolation_order = argcheck.is_posi(field_interpolation_order, "field_interpolation_order")
+        field_regularization_weight = argcheck.is_float(field_regularization_weight, "field_regularization_weight")
+        field_full_matrix = argcheck.is_bool(field_full_matrix, "field_full_matrix")
+        pinned_boundary_points = argcheck.is_nonnegi(pinned_boundary_points, "pinned_boundary_points")
+        dense_interpolation_mode = argcheck.is_in(dense_interpolation_mode, tuple(_MODES), "dense_interpolation_mode")
+        dense_padding_mode = argcheck.is_in(dense_padding_mode, tuple(_PADDINGS), "dense_padding_mode")
+        include_flow = argcheck.is_bool(include_flow, "include_flow")
+        super().__init__()
+        self.indexing = indexing
+        self.field_interpolation_order = field_interpolation_order
+        self.field_regularization_weight = field_regularization_weight
+        self.field_full_matrix = field_full_matrix
+        self.pinned_boundary_points = pinned_boundary_points
+        self.dense_interpolation_mode = dense_interpolation_mode
+        self.dense_padding_mode = dense_padding_mode
+        self.include_flow = include_flow
+
+    def forward(self, image, source_points, dest_points) -> Any:
+        return sparse_image_warp(
+            image, source_points, dest_points, self.indexing, self.field_interpolation_order,
+            self.field_regularization_weight, self.field_full_matrix, self.pinned_boundary_points,
+            self.dense_interpolation_mode, self.dense_padding_mode, self.include_flow,
+        )  # fmt: skip
+
+
+class SpecAugment(torch.nn.Module):
+    """Warp and mask the time / frequency axes of filter-bank features (reference
+    _img.py:1248-1536).  Identity in eval mode."""
+
+    __constants__ = (
+        "max_time_warp", "max_freq_warp", "max_time_mask", "max_freq_mask",
+        "max_time_mask_proportion", "num_time_mask", "num_time_mask_proportion", "num_freq_mask",
+        "interpolation_order",
+    )  # fmt: skip
+
+    def __init__(
+        self,
+        max_time_warp: float = 80.0,
+        max_freq_warp: float = 0.0,
+        max_time_mask: int = 100,
+        max_freq_mask: int = 27,
+        max_time_mask_proportion: float = 0.04,
+        num_time_mask: int = 20,
+        num_time_mask_proportion: float = 0.04,
+        num_freq_mask: int = 2,
+        interpolation_order: int = 1,
+    ):
+        max_time_warp = argcheck.is_nonnegf(max_time_warp, "max_time_warp")
+        max_freq_warp = argcheck.is_nonnegf(max_freq_warp, "max_freq_warp")
+        max_time_mask = argcheck.is_nonnegi(max_time_mask, "max_time_mask")
+        max_freq_mask = argcheck.is_nonnegi(max_freq_mask, "max_freq_mask")
+        max_time_mask_proportion = argcheck.is_closed01(max_time_mask_proportion, "max_time_mask_proportion")
+        num_time_mask = argcheck.is_nonnegi(num_time_mask, "num_time_mask")
+        num_time_mask_proportion = argcheck.is_closed01(num_time_mask_proportion, "num_time_mask_proportion")
+        num_freq_mask = argcheck.is_nonnegi(num_freq_mask, "num_freq_mask")
+        interpolation_order = argcheck.is_posi(interpolation_order, "interpolation_order")
+        super().__init__()
+        self.max_time_warp, self.max_freq_warp = max_time_warp, max_freq_warp
+        self.max_time_mask, self.max_freq_mask = max_time_mask, max_freq_mask
+        self.max_time_mask_proportion = max_time_mask_proportion
+        self.num_time_mask, self.num_time_mask_proportion = num_time_mask, num_time_mask_proportion
+        self.num_freq_mask, self.interpolation_order = num_freq_mask, interpolation_order
+
+    def extra_repr(self) -> str:
+        s = "warp_t={},max_f={},num_f={},max_t={},max_t_p={:.2f},num_t={}".format(
+            self.max_time_warp, self.max_freq_mask, self.num_freq_mask, self.max_time_mask,
+            self.max_time_mask_proportion, self.num_time_mask,
+        )  # fmt: skip
+        if self.max_freq_warp:
+            s += ",warp_f={}".format(self.max_freq_warp)
+        return s
+
+    def draw_parameters(self, feats, lengths: Optional[torch.Tensor] = None) -> SpecAugmentParams:
+        return spec_augment_draw_parameters(
+            feats, self.max_time_warp, self.max_freq_warp, self.max_time_mask, self.max_freq_mask,
+            self.max_time_mask_proportion, self.num_time_mask, self.num_time_mask_proportion,
+            self.num_freq_mask, lengths,
+        )  # fmt: skip
+
+    def apply_parameters(self, feats, params, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return spec_augment_apply_parameters(feats, params, self.interpolation_order, lengths)
+
+    def reset_parameters(self) -> None:
+        pass
+
+    def forward(self, feats: torch.Tensor, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if lengths is None:
+            lengths = torch.full((feats.size(0),), feats.size(1), dtype=torch.long, device=feats.device)
+        if not self.training:
+            return feats
+        params = self.draw_parameters(feats, lengths)
+        return self.apply_parameters(feats, params, lengths)

@@ -6,6 +6,15 @@ from ._decoding import (
     ctc_prefix_search,
     ctc_prefix_search_advance,
 )
+from ._img import (
+    dense_image_warp,
+    polyharmonic_spline,
+    sparse_image_warp,
+    spec_augment,
+    spec_augment_apply_parameters,
+    spec_augment_draw_parameters,
+    warp_1d_grid,
+)
 from ._string import (
     edit_distance,
     error_rate,
@@ -19,6 +28,13 @@ __all__ = [
     "beam_search_advance",
     "ctc_prefix_search",
     "ctc_prefix_search_advance",
+    "dense_image_warp",
+    "polyharmonic_spline",
+    "sparse_image_warp",
+    "spec_augment",
+    "spec_augment_apply_parameters",
+    "spec_augment_draw_parameters",
+    "warp_1d_grid",
     "edit_distance",
     "error_rate",
     "fill_after_eos",

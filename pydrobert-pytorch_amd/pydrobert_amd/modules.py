@@ -2,6 +2,7 @@
 operators on the MI355X hot path."""
 
 from ._decoding import BeamSearch, CTCPrefixSearch
+from ._img import DenseImageWarp, PolyharmonicSpline, SparseImageWarp, SpecAugment, Warp1DGrid
 from ._lm import (
     ExtractableSequentialLanguageModel,
     MixableSequentialLanguageModel,

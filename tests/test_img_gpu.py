@@ -1,0 +1,174 @@
+"""GPU parity of the spline / warp / SpecAugment kernels vs the numpy (float64) oracle.
+
+Tolerances: the kernels evaluate gathers in float32 like torch's grid_sample; spline systems
+are solved in float64.  1e-4 absolute on O(1) data (the reference's own test tolerance,
+tests/test_img.py:197,223)."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pydrobert_amd import functional as F
+from pydrobert_amd import modules as M
+
+pytestmark = pytest.mark.gpu
+ATOL = 1e-4
+
+
+def _t(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_polyharmonic_spline(device, order):
+    rng = np.random.default_rng(order)
+    for (N, T, I, O, Q) in [(3, 6, 2, 2, 20), (20, 10, 1, 1, 50), (2, 30, 3, 4, 300)]:
+        c = rng.uniform(-2, 2, (N, T, I)).astype(np.float32)
+        f = rng.normal(size=(N, T, O)).astype(np.float32)
+        q = rng.uniform(-2, 2, (N, Q, I)).astype(np.float32)
+        exp = oracle.polyharmonic_spline(c, f, q, order)
+        act = F.polyharmonic_spline(_t(c, device), _t(f, device), _t(q, device), order).cpu().numpy()
+        assert np.allclose(exp, act, atol=ATOL * max(1.0, np.abs(exp).max())), np.abs(exp - act).max()
+        # interpolation property: the spline passes through its control points
+        back = F.polyharmonic_spline(_t(c, device), _t(f, device), _t(c, device), order).cpu().numpy()
+        assert np.allclose(back, f, atol=1e-3)
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_warp_1d_grid(device, order):
+    src = np.array([10.0, 12.0, 15.0, 3.0, 6.0, 0.0], np.float32)
+    flow = np.array([2.0, -3.0, 1.5, 1.0, -2.0, 4.0], np.float32)
+    lens = np.array([20.0, 25.0, 30.0, 7.0, 12.0, 30.0], np.float32)
+    exp = oracle.warp_1d_grid(src, flow, lens, 30, order)
+    act = M.Warp1DGrid(30, order)(_t(src, device), _t(flow, device), _t(lens, device)).cpu().numpy()
+    valid = np.arange(30)[None] < lens[:, None]
+    assert np.abs(exp - act)[valid].max() < 1e-5
+    # max_length inferred from lengths (:279)
+    assert F.warp_1d_grid(_t(src, device), _t(flow, device), _t(lens, device)).shape == (6, 30)
+
+
+def _draw(rng, N, T, Fq, lens, MT=2, MF=2, freq=True):
+    W = np.minimum(lens / 2 - 1, 5.0)
+    w_0 = (rng.uniform(size=N) * (lens - 2 * W) + W).astype(np.float32)
+    w = (rng.uniform(size=N) * W - W / 2).astype(np.float32)  # keeps the target away from the ends
+    v_0 = (rng.uniform(size=N) * (Fq - 4) + 2).astype(np.float32) if freq else np.zeros(0, np.float32)
+    v = (rng.uniform(size=N) * 2 - 1).astype(np.float32) if freq else np.zeros(0, np.float32)
+    t = rng.integers(0, 6, (N, MT))
+    t_0 = (rng.uniform(size=(N, MT)) * (lens[:, None] - t)).astype(np.int64)
+    f = rng.integers(0, 4, (N, MF))
+    f_0 = (rng.uniform(size=(N, MF)) * (Fq - f)).astype(np.int64)
+    return w_0, w, v_0, v, t_0, t, f_0, f
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+@pytest.mark.parametrize("freq", [False, True])
+def test_spec_augment_apply_parameters(device, order, freq):
+    rng = np.random.default_rng(10 * order + freq)
+    N, T, Fq = 6, 50, 10
+    feats = rng.normal(size=(N, T, Fq)).astype(np.float32)
+    lens = np.array([50, 37, 20, 25, 44, 31])
+    params = _draw(rng, N, T, Fq, lens.astype(np.float64), freq=freq)
+    exp = oracle.spec_augment_apply_parameters(feats, params, order, lens)
+    act = F.spec_augment_apply_parameters(
+        _t(feats, device), tuple(_t(p, device) for p in params), order, _t(lens, device)
+    ).cpu().numpy()
+    valid = np.arange(T)[None, :, None] < lens[:, None, None]
+    err = np.abs(exp - act) * valid
+    assert err.max() < ATOL, err.max()
+    # masked bands are exactly zero
+    t_0, t = params[4], params[5]
+    for n in range(N):
+        for m in range(t.shape[1]):
+            assert (act[n, t_0[n, m] : t_0[n, m] + t[n, m]] == 0).all()
+
+
+def test_spec_augment_masks_only_and_identity(device):
+    rng = np.random.default_rng(3)
+    N, T, Fq = 3, 40, 8
+    feats = rng.normal(size=(N, T, Fq)).astype(np.float32)
+    e = np.zeros(0, np.float32)
+    t_0, t = np.array([[3], [10], [0]]), np.array([[4], [0], [40]])
+    params = (e, e, e, e, t_0, t, np.zeros(0, np.int64), np.zeros(0, np.int64))
+    act = F.spec_augment_apply_parameters(_t(feats, device), tuple(_t(p, device) for p in params), 1).cpu().numpy()
+    exp = oracle.spec_augment_apply_parameters(feats, params, 1)
+    assert np.array_equal(exp, act)
+    sa = M.SpecAugment().eval()
+    x = _t(feats, device)
+    assert sa(x) is x
+    # strided (non-contiguous) input
+    xt = _t(np.ascontiguousarray(feats.transpose(1, 0, 2)), device).transpose(0, 1)
+    act2 = F.spec_augment_apply_parameters(xt, tuple(_t(p, device) for p in params), 1).cpu().numpy()
+    assert np.array_equal(exp, act2)
+
+
+def test_spec_augment_module_statistics_and_grad(device):
+    """Ranges / counts of the drawn parameters (as the reference's tests/test_img.py:226-281
+    does) and the gradient w.r.t. feats against torch's own grid_sample graph."""
+    torch.manual_seed(0)
+    N, T, Fq = 16, 200, 20
+    feats = torch.randn(N, T, Fq, device=device)
+    lens = torch.randint(100, T + 1, (N,), device=device)
+    sa = M.SpecAugment(max_time_warp=10.0, max_freq_warp=2.0, max_time_mask=20, max_freq_mask=5,
+                       max_time_mask_proportion=0.1, num_time_mask=3, num_time_mask_proportion=0.02,
+                       num_freq_mask=2, interpolation_order=1)  # fmt: skip
+    w_0, w, v_0, v, t_0, t, f_0, f = sa.draw_parameters(feats, lens)
+    lf = lens.float()
+    assert w_0.shape == (N,) and (w_0 >= 0).all() and (w_0 <= lf).all() and (w.abs() <= 10).all()
+    assert (v.abs() <= 2).all() and (v_0 >= 0).all() and (v_0 <= Fq).all()
+    assert t.shape == (N, 3) and (t <= 20).all() and (t_0 + t <= lens.unsqueeze(1)).all()
+    assert ((t > 0).sum(1) <= (lf * 0.02).clamp(max=3).floor()).all()
+    assert f.shape == (N, 2) and (f <= 5).all() and (f_0 + f <= Fq).all()
+    out = sa(feats, lens)
+    assert out.shape == feats.shape and torch.isfinite(out).all()
+    # gradient
+    x = feats.clone().requires_grad_(True)
+    y = F.spec_augment_apply_parameters(x, (w_0, w, v_0, v, t_0, t, f_0, f), 1, lens)
+    g_out = torch.randn_like(y)
+    (g,) = torch.autograd.grad(y, x, g_out)
+    exp = oracle.spec_augment_apply_parameters
+    eps_dir = torch.randn_like(feats)
+    # directional derivative check (the op is linear in feats)
+    y2 = F.spec_augment_apply_parameters(feats + eps_dir, (w_0, w, v_0, v, t_0, t, f_0, f), 1, lens)
+    y1 = F.spec_augment_apply_parameters(feats, (w_0, w, v_0, v, t_0, t, f_0, f), 1, lens)
+    lhs = ((y2 - y1) * g_out).sum()
+    rhs = (g * eps_dir).sum()
+    assert torch.allclose(lhs, rhs, rtol=1e-3, atol=1e-2), (lhs.item(), rhs.item())
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("padding", ["border", "zeros", "reflection"])
+def test_dense_image_warp(device, mode, padding):
+    rng = np.random.default_rng(5)
+    img = rng.normal(size=(2, 3, 9, 7)).astype(np.float32)
+    flow = rng.normal(size=(2, 9, 7, 2)).astype(np.float32) * 2.5
+    if mode == "nearest":  # keep away from .5 rounding boundaries
+        flow = np.round(flow * 4) / 4 + 0.1
+    for indexing in ("hw", "wh"):
+        exp = oracle.dense_image_warp(img, flow, indexing, mode, padding)
+        act = M.DenseImageWarp(indexing, mode, padding)(_t(img, device), _t(flow, device)).cpu().numpy()
+        assert np.allclose(exp, act, atol=1e-5), (indexing, np.abs(exp - act).max())
+
+
+@pytest.mark.parametrize("pinned", [0, 1, 2])
+@pytest.mark.parametrize("include_flow", [True, False])
+def test_sparse_image_warp(device, pinned, include_flow):
+    rng = np.random.default_rng(7 + pinned)
+    N, C, H, W, Mp = 2, 2, 12, 9, 4
+    img = rng.uniform(size=(N, C, H, W)).astype(np.float32)
+    src = (rng.uniform(size=(N, Mp, 2)) * [H - 1, W - 1]).astype(np.float32)
+    dst = (src + rng.normal(size=(N, Mp, 2))).astype(np.float32)
+    for indexing in ("hw", "wh"):
+        s, d = (src, dst) if indexing == "hw" else (src[..., ::-1].copy(), dst[..., ::-1].copy())
+        for order in (1, 2, 3):
+            exp = oracle.sparse_image_warp(img, s, d, indexing, order, pinned_boundary_points=pinned,
+                                           include_flow=include_flow)  # fmt: skip
+            act = F.sparse_image_warp(_t(img, device), _t(s, device), _t(d, device), indexing, order,
+                                      pinned_boundary_points=pinned, include_flow=include_flow)  # fmt: skip
+            if include_flow:
+                assert np.allclose(exp[1], act[1].cpu().numpy(), atol=2e-4), np.abs(exp[1] - act[1].cpu().numpy()).max()
+                exp, act = exp[0], act[0]
+            assert np.allclose(exp, act.cpu().numpy(), atol=5e-4), (indexing, order, np.abs(exp - act.cpu().numpy()).max())
+    # no control points: identity (:543-548)
+    e = torch.zeros((N, 0, 2), device=device)
+    out = F.sparse_image_warp(_t(img, device), e, e, include_flow=False)
+    assert torch.equal(out.cpu(), torch.from_numpy(img))
