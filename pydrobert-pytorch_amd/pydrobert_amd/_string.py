@@ -55,6 +55,13 @@ def _seq_strides(t: torch.Tensor, batch_first: bool):
 def _prep(ref: torch.Tensor, hyp: torch.Tensor, batch_first: bool):
     if ref.dim() != 2 or hyp.dim() != 2:
         raise RuntimeError("ref and hyp must be 2 dimensional")  # _string.py:166-167
+    if (ref.shape[0] if batch_first else ref.shape[1]) != (hyp.shape[0] if batch_first else hyp.shape[1]):
+        raise RuntimeError(
+            "ref has batch size {}, but hyp has {}".format(
+                ref.shape[0] if batch_first else ref.shape[1],
+                hyp.shape[0] if batch_first else hyp.shape[1],
+            )
+        )  # _string.py:191-194
     device = _cabi.require_hip(ref, hyp)
     ref, hyp = ref.detach(), hyp.detach()  # _string.py:186-187
     if ref.dtype != torch.long:
@@ -62,9 +69,7 @@ def _prep(ref: torch.Tensor, hyp: torch.Tensor, batch_first: bool):
     if hyp.dtype != torch.long:
         hyp = hyp.long()
     R, N, rst, rsn = _seq_strides(ref, batch_first)
-    H, N2, hst, hsn = _seq_strides(hyp, batch_first)
-    if N != N2:
-        raise RuntimeError("ref has batch size {}, but hyp has {}".format(N, N2))  # :191-194
+    H, _, hst, hsn = _seq_strides(hyp, batch_first)
     return device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N
 
 

@@ -1,0 +1,28 @@
+"""A stateless bigram-table language model under this package's LM interface (the same model
+tests/golden/make_golden.py defines under the reference's interface)."""
+import torch
+
+from pydrobert_amd.modules import MixableSequentialLanguageModel
+
+
+class BigramLM(MixableSequentialLanguageModel):
+    def __init__(self, table):
+        super().__init__(table.shape[1])
+        self.register_buffer("table", table)
+
+    def calc_idx_log_probs(self, hist, prev, idx):
+        V = self.vocab_size
+        N = hist.shape[1]
+        if idx.dim() == 0:
+            idx = idx.expand(N)
+        prev_tok = torch.full((N,), V, dtype=torch.long, device=hist.device)
+        if hist.shape[0]:
+            last = hist.gather(0, (idx - 1).clamp(min=0).unsqueeze(0)).squeeze(0).clamp(0, V - 1)
+            prev_tok = torch.where(idx > 0, last, prev_tok)
+        return self.table[prev_tok], prev
+
+    def extract_by_src(self, prev, src):
+        return prev
+
+    def mix_by_mask(self, prev_true, prev_false, mask):
+        return prev_true

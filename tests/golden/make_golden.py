@@ -1,0 +1,286 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures under tests/golden/ from the LIVE reference.
+
+Run in the build container only (the reference never travels to the GPU box):
+
+    PYTHONPATH=/root/reference/src python tests/golden/make_golden.py
+
+Every fixture is DATA: the inputs fed to the reference and the outputs it returned, stored
+as .npz.  The tfa_*.npy files next to this script are the TensorFlow-addons arrays the
+reference's own tests ship (tests/polyharmonic_spline, tests/dense_image_warp,
+tests/sparse_image_warp), copied verbatim.  sclite.npz is the NIST sclite known answer of
+tests/sclite (50 utterances, costs 3/3/4) turned into token-id arrays with the reference's
+own .trn reader.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+REF = os.environ.get("PDT_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(REF, "src"))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+import pydrobert.torch.functional as F  # noqa: E402
+from pydrobert.torch import modules as M  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+
+def save(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items()})
+
+
+def string_goldens():
+    rng = np.random.default_rng(0x5EED0001)
+    # G-S1: config-1 shape, several cost triples
+    ref = rng.integers(0, 32, (128, 64))
+    hyp = rng.integers(0, 32, (128, 64))
+    costs = [(1, 1, 1), (2, 2, 2), (3, 3, 4), (2, 0.5, 1), (0.1, 0.7, 1.3)]
+    d = dict(ref=ref, hyp=hyp, costs=np.array(costs, np.float64))
+    tr, th = torch.from_numpy(ref), torch.from_numpy(hyp)
+    for i, c in enumerate(costs):
+        for norm in (False, True):
+            kw = dict(norm=norm, ins_cost=c[0], del_cost=c[1], sub_cost=c[2], warn=False)
+            d["er_c{}_n{}".format(i, int(norm))] = F.error_rate(tr, th, **kw)
+            d["ed_c{}_n{}".format(i, int(norm))] = F.edit_distance(tr, th, **kw)
+    save("string_s1", **d)
+    # G-S2/S3/S4: ragged, tie-rich, with empty ref / hyp rows
+    N, R, H, V = 48, 40, 37, 6
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    rl = rng.integers(0, R + 1, N)
+    hl = rng.integers(0, H + 1, N)
+    rl[:3], hl[:3] = [0, 5, 0], [4, 0, 0]
+    for n in range(N):
+        if rl[n] < R:
+            ref[rl[n], n] = V
+        if hl[n] < H:
+            hyp[hl[n], n] = V
+    d = dict(ref=ref, hyp=hyp, eos=np.array(V))
+    tr, th = torch.from_numpy(ref), torch.from_numpy(hyp)
+    for inc in (False, True):
+        for bf in (False, True):
+            a, b = (tr.t().contiguous(), th.t().contiguous()) if bf else (tr, th)
+            tag = "i{}_b{}".format(int(inc), int(bf))
+            kw = dict(eos=V, include_eos=inc, batch_first=bf, warn=False)
+            d["er_" + tag] = F.error_rate(a, b, ins_cost=3.0, del_cost=3.0, sub_cost=4.0, **kw)
+            d["ed_" + tag] = F.edit_distance(a, b, ins_cost=2.0, del_cost=0.5, sub_cost=1.0, **kw)
+            for ex in (False, True):
+                for norm in (False, True):
+                    t2 = tag + "_x{}_n{}".format(int(ex), int(norm))
+                    d["per_" + t2] = F.prefix_error_rates(
+                        a, b, norm=norm, exclude_last=ex, padding=-100, ins_cost=1.0, del_cost=2.0,
+                        sub_cost=3.0, **kw)  # fmt: skip
+                    d["ped_" + t2] = F.prefix_edit_distances(
+                        a, b, norm=norm, exclude_last=ex, padding=-7, **kw)  # fmt: skip
+                d["oc_" + tag + "_x{}".format(int(ex))] = F.optimal_completion(
+                    a, b, exclude_last=ex, padding=-100, **kw)  # fmt: skip
+    save("string_s2", **d)
+
+
+def sclite_golden():
+    from pydrobert.torch._parsing import read_trn
+
+    d = os.path.join(REF, "tests", "sclite")
+    tok2id = {}
+    with open(os.path.join(d, "token2id.txt")) as f:
+        for line in f:
+            t, i = line.split()
+            tok2id[t] = int(i)
+    refs = dict(read_trn(os.path.join(d, "ref.trn")))
+    hyps = dict(read_trn(os.path.join(d, "hyp.trn")))
+    utts = sorted(refs)
+    per_utt = {}
+    with open(os.path.join(d, "per_utt.txt")) as f:
+        for line in f:
+            u, v = line.split()
+            per_utt[u] = float(v)
+    with open(os.path.join(d, "total.txt")) as f:
+        total = float(f.read().strip())
+
+    def to_ids(seq):
+        return [tok2id[t] for t in seq]
+
+    R = max(len(refs[u]) for u in utts)
+    H = max(len(hyps[u]) for u in utts)
+    ref = np.full((R + 1, len(utts)), -1, np.int64)
+    hyp = np.full((H + 1, len(utts)), -1, np.int64)
+    for n, u in enumerate(utts):
+        r, h = to_ids(refs[u]), to_ids(hyps[u])
+        ref[: len(r), n] = r
+        hyp[: len(h), n] = h
+    errs = F.error_rate(torch.from_numpy(ref), torch.from_numpy(hyp), eos=-1, norm=False,
+                        ins_cost=3.0, del_cost=3.0, sub_cost=4.0, warn=False)  # fmt: skip
+    save("sclite", ref=ref, hyp=hyp, per_utt=np.array([per_utt[u] for u in utts]),
+         total=np.array(total), ref_errs=errs)  # fmt: skip
+
+
+class BigramLM(M.MixableSequentialLanguageModel):
+    """Stateless bigram table LM used for the search fixtures (table rows: previous token,
+    last row = start of sequence)."""
+
+    def __init__(self, table):
+        super().__init__(table.shape[1])
+        self.register_buffer("table", table)
+
+    def calc_idx_log_probs(self, hist, prev, idx):
+        V = self.vocab_size
+        N = hist.shape[1]
+        if idx.dim() == 0:
+            idx = idx.expand(N)
+        prev_tok = torch.full((N,), V, dtype=torch.long, device=hist.device)
+        if hist.shape[0]:
+            last = hist.gather(0, (idx - 1).clamp(min=0).unsqueeze(0)).squeeze(0).clamp(0, V - 1)
+            prev_tok = torch.where(idx > 0, last, prev_tok)
+        return self.table[prev_tok], prev
+
+    def extract_by_src(self, prev, src):
+        return prev
+
+    def mix_by_mask(self, prev_true, prev_false, mask):
+        return prev_true
+
+
+def decoding_goldens():
+    rng = np.random.default_rng(0x5EED0003)
+    torch.manual_seed(3)
+    # G-D2: CTC prefix search, peaky logits, ragged lens
+    T, N, V, K = 30, 8, 12, 4
+    lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+    peak = rng.integers(0, V + 1, (T, N))
+    np.put_along_axis(lg, peak[..., None], np.take_along_axis(lg, peak[..., None], 2) + 6.0, 2)
+    lens = rng.integers(10, T + 1, N)
+    y, yl, yp = M.CTCPrefixSearch(K)(torch.from_numpy(lg), torch.from_numpy(lens))
+    mask = torch.arange(y.shape[0]).view(-1, 1, 1) < yl.unsqueeze(0)
+    d = dict(logits=lg, lens=lens, width=np.array(K), y=torch.where(mask, y, torch.zeros_like(y)),
+             y_lens=yl, y_probs=yp)  # fmt: skip
+    # with shallow fusion / valid mixture
+    table = torch.from_numpy(rng.normal(size=(V + 1, V)).astype(np.float32)).log_softmax(-1)
+    lm = BigramLM(table)
+    d["lm_table"] = table
+    for name, vm in (("fusion", False), ("valid", True)):
+        y, yl, yp = M.CTCPrefixSearch(K, 0.3, lm, valid_mixture=vm)(torch.from_numpy(lg), torch.from_numpy(lens))
+        mask = torch.arange(y.shape[0]).view(-1, 1, 1) < yl.unsqueeze(0)
+        d["y_" + name] = torch.where(mask, y, torch.zeros_like(y))
+        d["y_lens_" + name] = yl
+        d["y_probs_" + name] = yp
+    save("ctc_search", **d)
+
+    # G-D1: one ctc_prefix_search_advance call from a state reached by the reference itself
+    N, V, W = 8, 10, 6
+    nb, b = torch.zeros(N, 1), torch.ones(N, 1)
+    yprev = torch.empty((0, N, 1), dtype=torch.long)
+    last = lens_ = torch.zeros((N, 1), dtype=torch.long)
+    isp = torch.ones((N, 1, 1), dtype=torch.bool)
+    state = None
+    for t in range(6):
+        p = torch.from_numpy(rng.dirichlet(np.ones(V + 1) * 0.5, N).astype(np.float32))
+        Kp = nb.shape[1]
+        lmp = torch.from_numpy(rng.dirichlet(np.ones(V), (N, Kp)).astype(np.float32))
+        ext = lmp.sqrt() * p[:, None, :V]
+        inp = ((ext, p[:, :V].contiguous(), p[:, V].contiguous()), W, (nb, b), yprev, last, lens_, isp)
+        out = F.ctc_prefix_search_advance(*inp)
+        state = (inp, out)
+        yprev, last, lens_, (nb, b), isp = out[0], out[1], out[2], out[3], out[4]
+    (probs_t, W_, probs_prev, yprev_, last_, lens__, isp_), out = state
+    ynext = out[0]
+    mask = torch.arange(ynext.shape[0]).view(-1, 1, 1) < out[2].unsqueeze(0)
+    save("ctc_advance", ext=probs_t[0], nonext=probs_t[1], blank=probs_t[2], width=np.array(W_),
+         nb_prev=probs_prev[0], b_prev=probs_prev[1], y_prev=yprev_, y_prev_last=last_,
+         y_prev_lens=lens__, prev_is_prefix=isp_,
+         y_next=torch.where(mask, ynext, torch.zeros_like(ynext)), y_next_last=out[1],
+         y_next_lens=out[2], nb_next=out[3][0], b_next=out[3][1], next_is_prefix=out[4],
+         next_src=out[5], next_is_nonext=out[6])  # fmt: skip
+
+    # G-D3: beam_search_advance with / without lens, and width > K' * V
+    d = {}
+    for tag, (N, Kp, V, W, S, with_lens) in {
+        "a": (4, 3, 7, 5, 4, False), "b": (4, 3, 7, 5, 4, True), "c": (3, 2, 3, 9, 0, False),
+    }.items():  # fmt: skip
+        lpt = torch.from_numpy(rng.normal(size=(N, Kp, V)).astype(np.float32)).log_softmax(-1)
+        lpp = torch.from_numpy(rng.normal(size=(N, Kp)).astype(np.float32))
+        yp_ = torch.from_numpy(rng.integers(0, V, (S, N, Kp)))
+        ypl = torch.from_numpy(rng.integers(1, S + 1, (N, Kp))) if with_lens else None
+        if ypl is not None:
+            ypl[0, 0] = S
+        out = F.beam_search_advance(lpt, W, lpp, yp_, ypl)
+        K = min(W, Kp * V)
+        d.update({tag + "_lpt": lpt, tag + "_lpp": lpp, tag + "_yprev": yp_, tag + "_width": np.array(W),
+                  tag + "_ynext": out[0][..., :K], tag + "_lens": out[1], tag + "_lp": out[2], tag + "_src": out[3]})
+        if ypl is not None:
+            d[tag + "_yprevlens"] = ypl
+    save("beam_advance", **d)
+
+    # BeamSearch module with the bigram LM
+    V = 9
+    table = torch.from_numpy((rng.normal(size=(V + 1, V)) * 2).astype(np.float32)).log_softmax(-1)
+    lm = BigramLM(table)
+    d = dict(lm_table=table)
+    for tag, (kw, call) in {
+        "eos": (dict(width=4, eos=0), dict(batch_size=5, max_iters=12)),
+        "all": (dict(width=3, eos=2, finish_all_paths=True), dict(batch_size=2, max_iters=10)),
+        "noeos": (dict(width=5), dict(batch_size=3, max_iters=6)),
+    }.items():
+        y, yl, lp = M.BeamSearch(lm, **kw)(dict(), **call)
+        d["y_" + tag], d["lens_" + tag], d["lp_" + tag] = y, yl, lp
+    save("beam_search", **d)
+
+
+def image_goldens():
+    rng = np.random.default_rng(0x5EED0004)
+    torch.manual_seed(4)
+    d = {}
+    c = torch.from_numpy(rng.uniform(-2, 2, (3, 6, 2)).astype(np.float32))
+    f = torch.from_numpy(rng.normal(size=(3, 6, 2)).astype(np.float32))
+    q = torch.from_numpy(rng.uniform(-2, 2, (3, 20, 2)).astype(np.float32))
+    d.update(sp_c=c, sp_f=f, sp_q=q)
+    for o in (1, 2, 3):
+        d["sp_o{}".format(o)] = F.polyharmonic_spline(c, f, q, o)
+    src = torch.tensor([3.0, 2.5, 1.0, 4.0, 2.0])
+    flow = torch.tensor([1.0, -1.0, 2.0, -2.5, 0.5])
+    lens = torch.tensor([7.0, 6.0, 5.0, 7.0, 4.0])
+    d.update(w1_src=src, w1_flow=flow, w1_lens=lens)
+    for o in (1, 2, 3):
+        d["w1_o{}".format(o)] = F.warp_1d_grid(src, flow, lens, 7, o)
+    # SpecAugment apply with fixed (non-degenerate) parameters
+    N, T, Fq = 4, 50, 10
+    feats = torch.from_numpy(rng.normal(size=(N, T, Fq)).astype(np.float32))
+    lens = torch.tensor([50, 37, 20, 44])
+    params = (
+        torch.tensor([20.0, 15.0, 9.0, 30.0]), torch.tensor([3.0, -2.0, 1.5, -4.0]),
+        torch.tensor([4.0, 5.0, 3.0, 6.0]), torch.tensor([1.0, -1.0, 0.5, -0.5]),
+        torch.tensor([[5, 30], [0, 20], [3, 10], [40, 1]]), torch.tensor([[3, 2], [4, 0], [1, 5], [2, 2]]),
+        torch.tensor([[1, 7], [0, 4], [2, 2], [8, 5]]), torch.tensor([[2, 1], [1, 0], [3, 1], [1, 2]]),
+    )  # fmt: skip
+    d.update(sa_feats=feats, sa_lens=lens)
+    for i, p in enumerate(params):
+        d["sa_p{}".format(i)] = p
+    for o in (1, 2, 3):
+        d["sa_o{}".format(o)] = F.spec_augment_apply_parameters(feats, params, o, lens)
+    # sparse image warp
+    N, C, H, W, Mp = 2, 1, 12, 9, 4
+    img = torch.from_numpy(rng.uniform(size=(N, C, H, W)).astype(np.float32))
+    sp = torch.from_numpy((rng.uniform(size=(N, Mp, 2)) * [H - 1, W - 1]).astype(np.float32))
+    dp = sp + torch.from_numpy(rng.normal(size=(N, Mp, 2)).astype(np.float32))
+    d.update(siw_img=img, siw_src=sp, siw_dst=dp)
+    for pinned in (0, 1, 2):
+        w, fl = F.sparse_image_warp(img, sp, dp, pinned_boundary_points=pinned, include_flow=True)
+        d["siw_w{}".format(pinned)], d["siw_f{}".format(pinned)] = w, fl
+        d["siw_n{}".format(pinned)] = F.sparse_image_warp(img, sp, dp, pinned_boundary_points=pinned, include_flow=False)
+    save("image", **d)
+
+
+if __name__ == "__main__":
+    string_goldens()
+    sclite_golden()
+    decoding_goldens()
+    image_goldens()

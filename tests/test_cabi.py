@@ -1,0 +1,87 @@
+"""CPU: the C-ABI library loads and exports exactly what include/pdt_amd.h declares; the
+ctypes table mirrors the header; argument validation happens before anything touches a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "pdt_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+
+    from pydrobert_amd import _cabi
+
+    if not os.path.exists(_cabi.LIB_PATH):
+        g.build()
+    return _cabi.lib()
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pdt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libpdt_amd.so does not export " + n
+
+
+def test_ctypes_table_matches_header():
+    from pydrobert_amd import _cabi
+
+    assert sorted(_cabi.SIGNATURES) == _declared()
+    src = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    for name, (_, args) in _cabi.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\((.*?)\)\s*;", src, flags=re.S)
+        params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
+        assert len(params) == len(args), (name, len(params), len(args))
+        for p, a in zip(params, args):
+            if "*" in p:
+                assert a is ctypes.c_void_p, (name, p)
+            elif "float" in p:
+                assert a is ctypes.c_float, (name, p)
+            elif "int64_t" in p:
+                assert a is ctypes.c_int64, (name, p)
+            else:
+                assert a is ctypes.c_int, (name, p)
+
+
+def test_abi_version_and_arg_validation_without_gpu(lib):
+    """Entry points validate arguments and return early for empty batches before any launch,
+    so these calls are safe on a machine without a GPU."""
+    from pydrobert_amd import _cabi
+
+    assert lib.pdt_amd_abi_version() >= 1
+    assert lib.pdt_oc_mask_words(512) == 16 and lib.pdt_oc_mask_words(513) == 17
+    assert lib.pdt_ctc_prefix_search_workspace_bytes(10, 4, 16) >= 10 * 4 * 16 * 8
+    assert lib.pdt_spline_workspace_bytes(2, 3, 1, 1) > 0
+    z = [0] * 32
+    # N == 0: OK, nothing to do
+    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_OK
+    # bad mode / negative sizes
+    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 7, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_E_ARG
+    assert lib.pdt_lev(0, -1, 1, 1, 0, 5, 1, 1, 4, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_E_ARG
+    # null pointers with a non-empty batch
+    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 4, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_E_ARG
+    assert lib.pdt_ctc_prefix_search(0, 5, 2, 3, 1, 1, 1, 0, 64, 5, 0, 0, 0, 0, 0) != _cabi.PDT_OK
+    assert lib.pdt_ctc_prefix_search(0, 5, 0, 3, 1, 1, 1, 0, 4, 5, 0, 0, 0, 0, 0) == _cabi.PDT_OK
+    assert lib.pdt_spec_augment_apply(0, 0, 5, 5, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == _cabi.PDT_OK
+    assert lib.pdt_dense_image_warp(0, 0, 1, 1, 4, 4, 0, 5, 0, 0, 0) == _cabi.PDT_E_ARG
+    del z
+
+
+def test_check_maps_status_to_runtime_error():
+    from pydrobert_amd import _cabi
+
+    _cabi.check(0, "x")
+    for rc in (_cabi.PDT_E_ARG, _cabi.PDT_E_TOO_LONG, 700):
+        with pytest.raises(RuntimeError):
+            _cabi.check(rc, "x")

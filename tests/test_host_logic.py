@@ -1,0 +1,162 @@
+"""CPU: host-side behaviour of the drop-in boundary -- constructor validation, shape errors,
+the LM interface, and the absence of any CPU compute path."""
+import pytest
+import torch
+
+from pydrobert_amd import argcheck, config
+from pydrobert_amd import functional as F
+from pydrobert_amd import modules as M
+
+from _toy_lm import BigramLM
+
+
+def test_public_surface_matches_reference_names():
+    # reference functional.py:24-58 / modules.py:72-124, restricted to the hot path
+    for name in ("error_rate", "edit_distance", "prefix_error_rates", "prefix_edit_distances",
+                 "optimal_completion", "fill_after_eos", "beam_search_advance",
+                 "ctc_prefix_search_advance", "polyharmonic_spline", "warp_1d_grid",
+                 "dense_image_warp", "sparse_image_warp", "spec_augment",
+                 "spec_augment_draw_parameters", "spec_augment_apply_parameters"):  # fmt: skip
+        assert callable(getattr(F, name)), name
+    for name in ("ErrorRate", "EditDistance", "PrefixErrorRates", "PrefixEditDistances",
+                 "OptimalCompletion", "FillAfterEndOfSequence", "BeamSearch", "CTCPrefixSearch",
+                 "PolyharmonicSpline", "Warp1DGrid", "DenseImageWarp", "SparseImageWarp",
+                 "SpecAugment", "SequentialLanguageModel", "ExtractableSequentialLanguageModel",
+                 "MixableSequentialLanguageModel"):  # fmt: skip
+        assert isinstance(getattr(M, name), type), name
+    assert config.INDEX_PAD_VALUE == -100 and config.DEFT_INS_COST == 1.0
+
+
+def test_defaults_match_reference_signatures():
+    import inspect
+
+    def defaults(f):
+        return {k: v.default for k, v in inspect.signature(f).parameters.items() if v.default is not inspect._empty}
+
+    assert defaults(F.error_rate) == dict(eos=None, include_eos=False, norm=True, batch_first=False,
+                                          ins_cost=1.0, del_cost=1.0, sub_cost=1.0, warn=True)  # fmt: skip
+    assert defaults(F.edit_distance)["norm"] is False
+    d = defaults(F.prefix_error_rates)
+    assert d["include_eos"] is True and d["norm"] is True and d["padding"] == -100 and d["exclude_last"] is False
+    assert defaults(F.prefix_edit_distances)["norm"] is False
+    assert defaults(F.optimal_completion)["include_eos"] is True
+    d = defaults(F.sparse_image_warp)
+    assert d["indexing"] == "hw" and d["field_interpolation_order"] == 2 and d["include_flow"] is True
+    assert list(inspect.signature(F.ctc_prefix_search_advance).parameters) == [
+        "probs_t", "width", "probs_prev", "y_prev", "y_prev_last", "y_prev_lens", "prev_is_prefix"]  # fmt: skip
+    assert list(inspect.signature(F.beam_search_advance).parameters) == [
+        "log_probs_t", "width", "log_probs_prev", "y_prev", "y_prev_lens"]  # fmt: skip
+
+
+def test_argcheck_contract():
+    assert argcheck.is_int(3, "x") == 3 and argcheck.is_float(2, "x") == 2.0
+    assert argcheck.is_int(None, "x", True) is None
+    for fn, bad in ((argcheck.is_int, 1.5), (argcheck.is_bool, 1), (argcheck.is_float, "a"),
+                    (argcheck.is_posi, 0), (argcheck.is_nonnegi, -1), (argcheck.is_closed01, 1.5),
+                    (argcheck.is_nonnegf, -0.1)):  # fmt: skip
+        with pytest.raises(ValueError):
+            fn(bad, "x")
+    with pytest.raises(ValueError, match="is not one of"):
+        argcheck.is_in("q", ("a", "b"), "x")
+
+
+def test_module_constructors_validate():
+    M.ErrorRate(eos=3, norm=False)
+    with pytest.raises(ValueError):
+        M.ErrorRate(eos="a")
+    with pytest.raises(ValueError):
+        M.PrefixErrorRates(padding=1.5)
+    with pytest.raises(ValueError):
+        M.CTCPrefixSearch(4, beta=2.0)
+    with pytest.raises(ValueError):
+        M.SpecAugment(max_time_warp=-1)
+    with pytest.raises(ValueError):
+        M.DenseImageWarp(mode="cubic")
+    with pytest.raises(ValueError):
+        M.SparseImageWarp(indexing="xy")
+    lm = BigramLM(torch.zeros(5, 4))
+    with pytest.raises(ValueError):
+        M.BeamSearch(lm, 0)
+    with pytest.raises(ValueError):
+        M.BeamSearch(lm, 2, eos=7)
+    assert M.BeamSearch(lm, 2, eos=-1).eos == 3
+    r = repr(M.OptimalCompletion(eos=1, padding=-3))
+    assert "eos=1" in r and "padding=-3" in r
+    assert "warp_t=80.0" in repr(M.SpecAugment())
+
+
+def test_no_cpu_compute_path():
+    """CPU tensors are refused: the package has no fallback implementation."""
+    ref = torch.zeros((3, 2), dtype=torch.long)
+    for fn in (F.error_rate, F.edit_distance, F.prefix_error_rates, F.optimal_completion):
+        with pytest.raises(RuntimeError, match="ROCm"):
+            fn(ref, ref)
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.ctc_prefix_search(torch.zeros(2, 1, 3), 2)
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.spec_augment_apply_parameters(torch.zeros(1, 4, 3), (torch.ones(1), torch.ones(1)) + (torch.empty(0),) * 6, 1)
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.polyharmonic_spline(torch.zeros(1, 3, 1), torch.zeros(1, 3, 1), torch.zeros(1, 2, 1), 1)
+
+
+def test_shape_errors_precede_device_checks():
+    with pytest.raises(RuntimeError, match="2 dimensional"):
+        F.error_rate(torch.zeros(3, dtype=torch.long), torch.zeros((3, 1), dtype=torch.long))
+    with pytest.raises(RuntimeError, match="batch size"):
+        F.error_rate(torch.zeros((3, 2), dtype=torch.long), torch.zeros((3, 1), dtype=torch.long))
+    with pytest.raises(RuntimeError, match="3 dimensional"):
+        F.beam_search_advance(torch.zeros(2, 3), 1, torch.zeros(2, 3), torch.zeros(0, 2, 3))
+    with pytest.raises(RuntimeError, match="width must be positive"):
+        F.ctc_prefix_search_advance((torch.zeros(1, 1, 2), torch.zeros(1, 2), torch.zeros(1)), 0,
+                                    (torch.zeros(1, 1),) * 2, torch.zeros(0, 1, 1), torch.zeros(1, 1),
+                                    torch.zeros(1, 1), torch.ones(1, 1, 1, dtype=torch.bool))  # fmt: skip
+    with pytest.raises(RuntimeError, match="three dimensions"):
+        F.spec_augment(torch.zeros(4, 3), 1.0, 0.0, 1, 1, 0.1, 1, 0.1, 1, 1)
+    with pytest.raises(RuntimeError, match="values of lengths"):
+        F.spec_augment(torch.zeros(2, 4, 3), 1.0, 0.0, 1, 1, 0.1, 1, 0.1, 1, 1, torch.tensor([0, 4]))
+
+
+def test_fill_after_eos_semantics():
+    tok = torch.tensor([[1, 2], [0, 3], [4, 0], [0, 5]])
+    out = F.fill_after_eos(tok, 0, 0, -1)
+    assert out.t().tolist() == [[1, 0, -1, -1], [2, 3, 0, -1]]
+    assert M.FillAfterEndOfSequence(0)(tok).t().tolist() == [[1, 0, 0, 0], [2, 3, 0, 0]]
+    val = torch.arange(8.0).view(4, 2)
+    assert F.fill_after_eos(tok, 0, 0, 9.0, val)[:, 0].tolist() == [0.0, 2.0, 9.0, 9.0]
+
+
+def test_lm_interface_forward_idx_normalisation():
+    table = torch.randn(5, 4).log_softmax(-1)
+    lm = BigramLM(table)
+    hist = torch.tensor([[0, 1], [2, 3], [1, 1]])
+    full = lm(hist)
+    assert full.shape == (4, 2, 4)
+    assert torch.equal(full[0], table[4].expand(2, 4))
+    lp, _ = lm(hist, idx=-1)
+    assert torch.equal(lp, full[3])
+    lp, _ = lm(hist, idx=torch.tensor([1, 3]))
+    assert torch.equal(lp[0], full[1, 0]) and torch.equal(lp[1], full[3, 1])
+    with pytest.raises(RuntimeError, match="2 dimensional"):
+        lm(hist[0])
+    with pytest.raises(RuntimeError, match="between"):
+        lm(hist, idx=9)
+    with pytest.raises(TypeError):
+        M.SequentialLanguageModel(3)  # abstract
+
+
+def test_spec_augment_draw_parameters_on_cpu_ranges():
+    """Parameter draws are plain torch ops and run anywhere (reference tests/test_img.py:226-281)."""
+    torch.manual_seed(0)
+    N, T, Fq = 50, 120, 16
+    feats = torch.zeros(N, T, Fq)
+    lens = torch.randint(40, T + 1, (N,))
+    w_0, w, v_0, v, t_0, t, f_0, f = F.spec_augment_draw_parameters(feats, 8.0, 2.0, 12, 4, 0.1, 3, 0.03, 2, lens)
+    lf = lens.float()
+    Wm = (lf / 2).clamp(max=8.0)
+    assert ((w_0 >= Wm - 1e-4) & (w_0 <= lf - Wm + 1e-4)).all() and (w.abs() <= Wm + 1e-4).all()
+    assert ((v_0 >= 2 - 1e-4) & (v_0 <= Fq - 2 + 1e-4)).all() and (v.abs() <= 2 + 1e-4).all()
+    assert (t <= (lf * 0.1).clamp(max=12).floor().unsqueeze(1)).all() and (t_0 + t <= lens.unsqueeze(1)).all()
+    assert ((t > 0).sum(1) <= (lf * 0.03).clamp(max=3).floor()).all()
+    assert (f <= 4).all() and (f_0 >= 0).all() and (f_0 + f <= Fq).all()
+    out = F.spec_augment_draw_parameters(feats, 0.0, 0.0, 0, 0, 0.1, 3, 0.03, 0)
+    assert all(p.numel() == 0 for p in out)
