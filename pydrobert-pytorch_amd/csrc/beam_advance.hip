@@ -37,13 +37,11 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   const int64_t n = (int64_t)blockIdx.x * a.waves_per_wg + wave;
   if (n >= a.N) return;
   const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
-  const int RS = W > Kp ? W : Kp;
   unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
-  u64 *surv = reinterpret_cast<u64 *>(base);
-  float *p = reinterpret_cast<float *>(surv + PDT_SURV_CAP);
-  int *tl = reinterpret_cast<int *>(p + ((V + 1 + 3) & ~3));
-  int *rem = tl + Kp * PDT_WAVE;
-  int *srcs = rem + RS * RS;
+  float *p = reinterpret_cast<float *>(base);
+  FrameLds L;
+  L.carve(base + (size_t)((V + 1 + 3) & ~3) * 4, V, W, Kp, true);
+  int *srcs = reinterpret_cast<int *>(L.surv);  // reused after the frame
 
   for (int v = lane; v < V; v += PDT_WAVE) p[v] = a.nonext[n * a.ne_sn + v * a.ne_sv];
   if (lane == 0) p[V] = a.blank[n * a.bl_sn];
@@ -73,8 +71,7 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   int new_src, new_tok, new_kind;
   const int old_len = bm.len;
   (void)old_len;
-  ctc_frame<true>(bm, p, 1.0f, V, W, Kp, RS, 0, n, dummy, dc, surv, tl, rem, nullptr, nullptr,
-                  new_src, new_tok, new_kind);
+  ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind);
 
   // ---- outputs (:855-934) ----------------------------------------------------------------
   if (lane < W) {
@@ -107,9 +104,7 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
 
 int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.W > kMaxWidth || a.Kp < 1 || a.Kp > kMaxWidth) return PDT_E_TOO_LONG;
-  const int RS = a.W > a.Kp ? a.W : a.Kp;
-  size_t per_wave = (size_t)PDT_SURV_CAP * 8 + (size_t)((a.V + 1 + 3) & ~3) * 4 +
-                    (size_t)a.Kp * PDT_WAVE * 4 + (size_t)RS * RS * 4 + (size_t)a.W * 4;
+  size_t per_wave = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
   per_wave = (per_wave + 15) & ~(size_t)15;
   const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
   if (per_wave > hard_cap) return PDT_E_TOO_LONG;

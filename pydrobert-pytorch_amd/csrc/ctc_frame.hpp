@@ -46,109 +46,162 @@ struct DenseCtx {
   int S;
 };
 
+// Per-wave LDS scratch of one frame.
+struct FrameLds {
+  u64 *surv;           // [PDT_SURV_CAP] survivors of the top-M selection
+  int *tl_tok;         // [L * 64] sorted token list(s): L = 1 (shared) or Kp (DENSE)
+  float *tl_p;         // [L * 64] extension probability of each list entry
+  unsigned char *pos;  // [V] list index of a token or 0xFF (shared list only)
+  unsigned *chm;       // [max(W, Kp)] new beam entries that descend from old entry j
+  int *info;           // [2 * W] packed description of every new beam entry
+  int *nxt_old, *nxt_new;  // [W * W] token of prefix b right after prefix a (trie form only)
+  static __host__ __device__ size_t bytes(int V, int W, int Kp, bool dense) {
+    const int RS = W > Kp ? W : Kp;
+    size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)(dense ? Kp : 1) * PDT_WAVE * 8;
+    b += dense ? 0 : (size_t)((V + 15) & ~15);
+    b += (size_t)RS * 4 + (size_t)2 * W * 4 + (dense ? 0 : (size_t)2 * W * W * 4);
+    return (b + 15) & ~(size_t)15;
+  }
+  __device__ void carve(unsigned char *base, int V, int W, int Kp, bool dense) {
+    const int RS = W > Kp ? W : Kp, L = dense ? Kp : 1;
+    surv = reinterpret_cast<u64 *>(base);
+    tl_tok = reinterpret_cast<int *>(surv + PDT_SURV_CAP);
+    tl_p = reinterpret_cast<float *>(tl_tok + L * PDT_WAVE);
+    chm = reinterpret_cast<unsigned *>(tl_p + L * PDT_WAVE);
+    info = reinterpret_cast<int *>(chm + RS);
+    nxt_old = info + 2 * W;
+    nxt_new = nxt_old + (dense ? 0 : W * W);
+    pos = reinterpret_cast<unsigned char *>(nxt_new + (dense ? 0 : W * W));
+  }
+};
+
 // One frame of the search.  `p` holds the (unnormalised) non-extension probabilities of
 // v in [0, V] (index V = blank) and `sum` their normaliser (1 when already normalised).
-// Kp = number of live lanes (1 at t = 0, then W).  Per-wave LDS scratch:
-//   tl: sorted token list(s) -- one shared list of 64, or Kp lists when DENSE;
-//   rem[RS*RS] removed tokens per parent (RS = max(W, Kp)), nxt_old/nxt_new[W*W] (trie form).
-// On return new_src / new_tok / new_kind describe where lane i's new prefix came from.
+// Kp = number of live lanes (1 at t = 0, then W).
+// On return new_src / new_tok / new_kind describe where lane i's new prefix came from
+// (kind: 0/1 extension, 2 non-extension, -1 invalid).
 template <bool DENSE>
 __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float sum, const int V,
-                                          const int W, const int Kp, const int RS, const int t,
+                                          const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
-                                          u64 *surv, int *tl, int *rem, int *nxt_old,
-                                          int *nxt_new, int &new_src, int &new_tok,
+                                          const FrameLds &L, int &new_src, int &new_tok,
                                           int &new_kind) {
   const int lane = lane_id();
   const bool live = lane < Kp;
   const int K = min(W, Kp * (V + 1));  // _decoding.py:775
   const int M = min(V, K + Kp);
+  const int me = live ? lane : 0;
 
   // ---- sorted token list(s): tokens by descending extension probability ----------------
   if (!DENSE) {
-    const u64 tk = wave_top_sorted(p, V, M, surv);
-    if (lane < M) tl[lane] = (int)idx_of(tk);
+    const u64 tk = wave_top_sorted(p, V, M, L.surv);
+    if (lane < M) {
+      const int tok = (int)idx_of(tk);
+      L.tl_tok[lane] = tok;
+      L.tl_p[lane] = __fdiv_rn(p[tok], sum);
+      L.pos[tok] = (unsigned char)lane;
+    }
   } else {
     for (int k = 0; k < Kp; ++k) {
-      const u64 tk = wave_top_sorted_strided(dc.ext + k * dc.ext_sk, dc.ext_sv, V, M, surv);
-      if (lane < M) tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
+      const u64 tk = wave_top_sorted_strided(dc.ext + k * dc.ext_sk, dc.ext_sv, V, M, L.surv);
+      if (lane < M) {
+        L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
+        L.tl_p[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));
+      }
       wave_sync();
     }
   }
-  const int *mytl = DENSE ? tl + (lane < Kp ? lane : 0) * PDT_WAVE : tl;
-  // extension probability of (this lane's prefix, token v)
-  auto ext_prob = [&](int v) -> float {
-    if (DENSE) return dc.ext[(lane < Kp ? lane : 0) * dc.ext_sk + v * dc.ext_sv];
-    return __fdiv_rn(p[v], sum);
-  };
-  const float p_blank = __fdiv_rn(p[V], sum);
+  const int *mt = L.tl_tok + (DENSE ? me : 0) * PDT_WAVE;
+  const float *mp = L.tl_p + (DENSE ? me : 0) * PDT_WAVE;
 
   // ---- candidate masses that do not depend on the token (:777-794) ----------------------
+  const float p_blank = __fdiv_rn(p[V], sum);
   const int lastc = min(max(bm.last, 0), V - 1);
+  const float pl = __fdiv_rn(p[lastc], sum);  // non-extension probability of my last token
+  const float e_last = DENSE ? dc.ext[me * dc.ext_sk + lastc * dc.ext_sv] : pl;
   const float tot = bm.nb + bm.b;
   const float B = tot * p_blank;
-  float NB = bm.nb * __fdiv_rn(p[lastc], sum);
+  float NB = bm.nb * pl;
+  const bool valid_beam = live && tot > -PDT_INF;
   wave_sync();
 
-  // ---- merge: an extension of k that equals an existing prefix k' feeds k' (:804-837) ---
+  // index of my last token in my list (-1: not among the top M)
+  int jl = -1;
+  if (!DENSE) {
+    const int q = L.pos[lastc];
+    jl = q == 0xFF ? -1 : q;
+  } else {
+    for (int j = 0; j < M; ++j) jl = mt[j] == lastc ? j : jl;
+  }
+  // stream 0: list entries still available to this prefix (my own last token goes to stream 1)
+  u64 avail = M >= 64 ? ~0ull : ((1ull << M) - 1ull);
+  if (jl >= 0) avail &= ~(1ull << jl);
+  bool s1_open = valid_beam, s2_open = valid_beam;
+
+  // ---- merge: an extension of kk that equals an existing prefix feeds that prefix --------
+  // (:804-837); only prefixes that have descendants in the beam are visited
   float add = 0.0f;
-  int nrem = 0;  // number of removed tokens of THIS lane's prefix
-  for (int kk = 0; kk < Kp; ++kk) {
+  u64 par = __ballot(live && (bm.isp & ~(1ull << lane)) != 0ull);
+  while (par) {
+    const int kk = (int)__builtin_ctzll(par);
+    par &= par - 1ull;
     const u64 isp_kk = readlane_u64(bm.isp, kk);
-    if ((isp_kk & ~(1ull << kk)) == 0ull) continue;
     const int len_kk = __builtin_amdgcn_readlane(bm.len, kk);
     const bool child = live && ((isp_kk >> lane) & 1ull) && (len_kk + 1 == bm.len);
-    const u64 cm = __ballot(child);
+    u64 cm = __ballot(child);
     if (cm == 0ull) continue;
     const float nb_kk = readlane_f(bm.nb, kk), b_kk = readlane_f(bm.b, kk);
     const int last_kk = min(max(__builtin_amdgcn_readlane(bm.last, kk), 0), V - 1);
-    if (child) {
-      // to_match = the last token of the child (its length is len_kk + 1)
-      const float w = (lastc == last_kk ? 0.0f : nb_kk) + b_kk;
-      const float e = DENSE ? dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv] : __fdiv_rn(p[lastc], sum);
-      add += w * e;
-      const int pos = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(cm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)cm, 0u));
-      rem[kk * RS + pos] = lastc;
+    int jc = jl;  // index of my last token in kk's list
+    if (DENSE) {
+      jc = -1;
+      for (int j = 0; j < M; ++j) jc = L.tl_tok[kk * PDT_WAVE + j] == lastc ? j : jc;
     }
-    if (lane == kk) nrem = __popcll(cm);
+    if (child) {
+      // to_match = the last token of the child (whose length is len_kk + 1)
+      const float w = (lastc == last_kk ? 0.0f : nb_kk) + b_kk;
+      const float e = DENSE ? dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv] : pl;
+      add += w * e;
+    }
+    u64 rm = 0ull;
+    bool close1 = false;
+    while (cm) {
+      const int c = (int)__builtin_ctzll(cm);
+      cm &= cm - 1ull;
+      const int jcc = __builtin_amdgcn_readlane(jc, c);
+      if (jcc >= 0) rm |= 1ull << jcc;
+      close1 = close1 || (__builtin_amdgcn_readlane(lastc, c) == last_kk);
+    }
+    if (lane == kk) {
+      avail &= ~rm;
+      if (close1) s1_open = false;
+    }
   }
   NB = NB + add;
-  wave_sync();
 
   // ---- K-way merge of the per-prefix candidate streams ----------------------------------
-  // stream 0: tokens tl[ptr..] except `lastc` and removed ones, mass (nb + b) * p[v]
-  // stream 1: the token `lastc`, mass b * p[lastc]            (:784-789)
-  // stream 2: not extending, mass NB + B                       (:842-845)
-  auto removed = [&](int v) {
-    for (int i = 0; i < nrem; ++i)
-      if (rem[lane * RS + i] == v) return true;
-    return false;
-  };
-  const bool valid_beam = live && tot > -PDT_INF;
-  int ptr = 0;
-  auto skip = [&]() {
-    while (ptr < M) {
-      const int v = mytl[ptr];
-      if (v != lastc && !removed(v)) break;
-      ++ptr;
-    }
-  };
-  skip();
-  bool s1_open = valid_beam && !removed(lastc);
-  bool s2_open = valid_beam;
-  const float m1 = bm.b * ext_prob(lastc);
+  // stream 0: available list entries in order, mass (nb + b) * ext[v]
+  // stream 1: my last token, mass b * ext[last]                (:784-789)
+  // stream 2: not extending, mass NB + B                        (:842-845)
+  const float m1 = bm.b * e_last;
   const float m2 = NB + B;
-
-  new_src = 0, new_tok = 0, new_kind = -1;  // kind: 0/1 extension, 2 non-extension, -1 invalid
-  float new_mass = -PDT_INF;
-  for (int i = 0; i < K; ++i) {
-    float best = 0.0f;
-    int kind = -1;
-    if (valid_beam && ptr < M) {
-      best = tot * ext_prob(mytl[ptr]);
+  float m0 = 0.0f, best = 0.0f;
+  int t0 = 0, kind = -1;
+  unsigned key = 0u;
+  auto refresh = [&]() {
+    const bool has0 = valid_beam && avail != 0ull;
+    if (has0) {
+      const int j = (int)__builtin_ctzll(avail);
+      t0 = mt[j];
+      m0 = tot * mp[j];
+    }
+    kind = -1;
+    best = 0.0f;
+    if (has0) {
+      best = m0;
       kind = 0;
     }
-    if (s1_open && (kind < 0 || m1 > best || (m1 == best && lastc < mytl[ptr]))) {
+    if (s1_open && (kind < 0 || m1 > best || (m1 == best && lastc < t0))) {
       best = m1;
       kind = 1;
     }
@@ -156,12 +209,18 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       best = m2;
       kind = 2;
     }
-    const unsigned key = kind >= 0 ? fkey(best) : 0u;
+    key = kind >= 0 ? fkey(best) : 0u;
+  };
+  refresh();
+
+  new_src = 0, new_tok = 0, new_kind = -1;
+  float new_mass = -PDT_INF;
+  for (int i = 0; i < K; ++i) {
     const unsigned mx = wave_max_u32(key);
     if (mx == 0u) break;  // fewer valid candidates than K: the rest stay invalid (:902-924)
     const int win = (int)__builtin_ctzll(__ballot(key == mx));
     const int wkind = __builtin_amdgcn_readlane(kind, win);
-    const int wtok = __builtin_amdgcn_readlane(kind == 0 ? mytl[ptr < M ? ptr : 0] : lastc, win);
+    const int wtok = __builtin_amdgcn_readlane(kind == 0 ? t0 : lastc, win);
     const float wmass = readlane_f(best, win);
     if (lane == i) {
       new_src = win;
@@ -170,15 +229,15 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       new_mass = wmass;
     }
     if (lane == win) {
-      if (kind == 0) {
-        ++ptr;
-        skip();
-      } else if (kind == 1) {
-        s1_open = false;
-      } else {
-        s2_open = false;
-      }
+      if (kind == 0) avail &= avail - 1ull;
+      else if (kind == 1) s1_open = false;
+      else s2_open = false;
+      refresh();
     }
+  }
+  if (!DENSE) {
+    wave_sync();
+    if (lane < M) L.pos[L.tl_tok[lane]] = 0xFF;  // leave the inverse index clean
   }
 
   // ---- new beam state of lane i (:868-880) ---------------------------------------------
@@ -198,30 +257,40 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     a.trie[((int64_t)t * a.N + n) * W + lane] = make_int2(node_s, new_tok);
 
   // ---- is-prefix relation and next-token table of the new beam (:883-898) ---------------
-  // nxt[a * W + b] = token of prefix b at position len(a), defined when a is a strict prefix
+  // Only pairs (a, b) whose sources were related need work: chm[j] = new entries descending
+  // from old entry j, so lane a visits  U_{j in isp(src_a)} chm[j]  (usually 1-3 entries).
+  // nxt[a * W + b] = token of prefix b at position len(a), defined when a is a strict prefix.
+  const int RS = W > Kp ? W : Kp;
+  if (lane < RS) L.chm[lane] = 0u;
+  wave_sync();
+  if (is_valid) {
+    atomicOr(&L.chm[new_src], 1u << lane);
+    L.info[2 * lane] = new_tok;
+    L.info[2 * lane + 1] = len_s | (new_src << 20) | ((is_ext ? 1 : 0) << 28);
+  }
+  wave_sync();
   u64 isp_new = 0ull;
   bool need_walk = false;
-  for (int b = 0; b < K; ++b) {
-    const int kind_b = __builtin_amdgcn_readlane(new_kind, b);
-    if (kind_b < 0) continue;
-    const int src_b = __builtin_amdgcn_readlane(new_src, b);
-    const int tok_b = __builtin_amdgcn_readlane(new_tok, b);
-    const int lenB = __builtin_amdgcn_readlane(len_s, b);  // length of b's source prefix
-    const bool ext_b = kind_b != 2;
-    const int len_b = lenB + (ext_b ? 1 : 0);
-    bool ok = is_valid && ((isp_s >> src_b) & 1ull) && nw.len <= len_b;
-    int tok_at = -1;  // token of new prefix b at position len_s (= len of my source prefix)
-    if (ok) {
+  if (is_valid) {
+    unsigned cand = 0u;
+    for (u64 m = isp_s; m; m &= m - 1ull) cand |= L.chm[__builtin_ctzll(m)];
+    while (cand) {
+      const int b = __builtin_ctz(cand);
+      cand &= cand - 1u;
+      const int tok_b = L.info[2 * b], w1 = L.info[2 * b + 1];
+      const int lenB = w1 & 0xFFFFF, src_b = (w1 >> 20) & 0xFF;
+      const bool ext_b = (w1 >> 28) & 1;
+      const int len_b = lenB + (ext_b ? 1 : 0);
+      if (nw.len > len_b) continue;
+      int tok_at;  // token of new prefix b at position len_s (the length of my source prefix)
       if (lenB > len_s)
         tok_at = DENSE ? (int)dc.y_prev[(int64_t)len_s * dc.yp_ss + src_b * dc.yp_sk]
-                       : nxt_old[new_src * W + src_b];
+                       : L.nxt_old[new_src * W + src_b];
       else
         tok_at = ext_b ? tok_b : -1;  // lenB == len_s
-      if (is_ext) ok = tok_at == new_tok;
-    }
-    if (ok) {
+      if (is_ext && tok_at != new_tok) continue;
       isp_new |= 1ull << b;
-      if (!DENSE && nw.len < len_b) {  // strict prefix: record the token that follows me inside b
+      if (!DENSE && nw.len < len_b) {  // strict prefix: the token that follows me inside b
         int nx;
         if (!is_ext) {
           nx = tok_at;
@@ -231,7 +300,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
           nx = -(2 + b);  // deeper than the table reaches: resolved below by a trie walk
           need_walk = true;
         }
-        nxt_new[lane * W + b] = nx;
+        L.nxt_new[lane * W + b] = nx;
       }
     }
   }
@@ -242,18 +311,18 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     for (int b = 0; b < K; ++b) {
       const int node_b = __builtin_amdgcn_readlane(node_s, b);
       const int lenB = __builtin_amdgcn_readlane(len_s, b);
-      if (need_walk && ((isp_new >> b) & 1ull) && nxt_new[lane * W + b] == -(2 + b)) {
+      if (need_walk && ((isp_new >> b) & 1ull) && L.nxt_new[lane * W + b] == -(2 + b)) {
         int node = node_b, depth = lenB, tok = -1;
         while (node >= 0) {
           const int tt = node / W, ii = node - tt * W;
           const int2 *rec = a.trie + (((int64_t)tt * a.N + n) * W + ii);
-          const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int par_ = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (depth == nw.len + 1) break;
-          node = par;
+          node = par_;
           --depth;
         }
-        nxt_new[lane * W + b] = tok;
+        L.nxt_new[lane * W + b] = tok;
       }
     }
   }

@@ -31,12 +31,10 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
   if (n >= a.N) return;
   const int V = a.V, W = a.W;
   unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
-  u64 *surv = reinterpret_cast<u64 *>(base);
-  float *p = reinterpret_cast<float *>(surv + PDT_SURV_CAP);
-  int *tl = reinterpret_cast<int *>(p + ((V + 1 + 3) & ~3));
-  int *rem = tl + PDT_WAVE;
-  int *nxt0 = rem + W * W;
-  int *nxt1 = nxt0 + W * W;
+  float *p = reinterpret_cast<float *>(base);
+  FrameLds L;
+  L.carve(base + (size_t)((V + 1 + 3) & ~3) * 4, V, W, W, false);
+  for (int v = lane; v < V; v += PDT_WAVE) L.pos[v] = 0xFF;
 
   const int Tn = a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T;
   Beam bm;  // :1097-1105: one empty prefix with all the mass on "ends in blank"
@@ -65,10 +63,11 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
     }
     s = wave_sum_f(s);
     wave_sync();
-    int *nxt_old = (t & 1) ? nxt1 : nxt0, *nxt_new = (t & 1) ? nxt0 : nxt1;
     int ns, nt, nk;
-    ctc_frame<false>(bm, p, s, V, W, Kp, W, t, n, a, DenseCtx{}, surv, tl, rem, nxt_old, nxt_new, ns,
-                     nt, nk);
+    ctc_frame<false>(bm, p, s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk);
+    int *tmp = L.nxt_old;
+    L.nxt_old = L.nxt_new;
+    L.nxt_new = tmp;
     Kp = W;
   }
 
@@ -93,9 +92,7 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
 }
 
 size_t ctc_lds_per_wave(int V, int W) {
-  size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)((V + 1 + 3) & ~3) * 4 + PDT_WAVE * 4 +
-             (size_t)3 * W * W * 4;
-  return (b + 15) & ~(size_t)15;
+  return (size_t)((V + 1 + 3) & ~3) * 4 + FrameLds::bytes(V, W, W, false);
 }
 
 int launch_ctc_search(CtcArgs a, hipStream_t stream) {
