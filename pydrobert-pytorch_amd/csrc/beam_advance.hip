@@ -71,7 +71,10 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   int new_src, new_tok, new_kind;
   const int old_len = bm.len;
   (void)old_len;
-  ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind);
+  #ifdef PDT_STAMPS
+  unsigned long long pdt_stamp_acc[8] = {0};
+#endif
+  ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
 
   // ---- outputs (:855-934) ----------------------------------------------------------------
   if (lane < W) {

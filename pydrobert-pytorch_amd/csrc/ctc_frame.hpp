@@ -6,6 +6,22 @@
 
 namespace pdt {
 
+// Diagnostic build only (-DPDT_STAMPS): per-phase cycle totals of lane 0 of every wave.
+#ifdef PDT_STAMPS
+__device__ unsigned long long g_stamps[16];
+__device__ unsigned long long *g_stamp_lds_dummy;
+#define PDT_STAMP(ph)                                                        \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_readcyclecounter();           \
+    if (lane_id() == 0) pdt_stamp_acc[ph] += now_ - stamp_last_;             \
+    stamp_last_ = __builtin_readcyclecounter();                              \
+  } while (0)
+#define PDT_STAMP_BEGIN unsigned long long stamp_last_ = __builtin_readcyclecounter()
+#else
+#define PDT_STAMP(ph) do {} while (0)
+#define PDT_STAMP_BEGIN do {} while (0)
+#endif
+
 constexpr int kMaxWidth = 32;  // K + K' <= 64 tokens fit one per lane
 
 struct CtcArgs {
@@ -80,26 +96,38 @@ struct FrameLds {
 // Kp = number of live lanes (1 at t = 0, then W).
 // On return new_src / new_tok / new_kind describe where lane i's new prefix came from
 // (kind: 0/1 extension, 2 non-extension, -1 invalid).
+#ifdef PDT_STAMPS
+#define PDT_STAMP_PARAM , unsigned long long *pdt_stamp_acc
+#define PDT_STAMP_ARG , pdt_stamp_acc
+#else
+#define PDT_STAMP_PARAM
+#define PDT_STAMP_ARG
+#endif
+
 template <bool DENSE>
 __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float sum, const int V,
                                           const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
                                           const FrameLds &L, int &new_src, int &new_tok,
-                                          int &new_kind) {
+                                          int &new_kind PDT_STAMP_PARAM) {
   const int lane = lane_id();
   const bool live = lane < Kp;
   const int K = min(W, Kp * (V + 1));  // _decoding.py:775
   const int M = min(V, K + Kp);
   const int me = live ? lane : 0;
+  PDT_STAMP_BEGIN;
 
   // ---- sorted token list(s): tokens by descending extension probability ----------------
+  int list_tok = 0;      // shared list, entry `lane` (registers; also mirrored in LDS)
+  float list_p = 0.0f;
   if (!DENSE) {
     const u64 tk = wave_top_sorted(p, V, M, L.surv);
     if (lane < M) {
-      const int tok = (int)idx_of(tk);
-      L.tl_tok[lane] = tok;
-      L.tl_p[lane] = __fdiv_rn(p[tok], sum);
-      L.pos[tok] = (unsigned char)lane;
+      list_tok = (int)idx_of(tk);
+      list_p = __fdiv_rn(p[list_tok], sum);
+      L.tl_tok[lane] = list_tok;
+      L.tl_p[lane] = list_p;
+      L.pos[list_tok] = (unsigned char)lane;
     }
   } else {
     for (int k = 0; k < Kp; ++k) {
@@ -111,6 +139,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       wave_sync();
     }
   }
+  PDT_STAMP(1);
   const int *mt = L.tl_tok + (DENSE ? me : 0) * PDT_WAVE;
   const float *mp = L.tl_p + (DENSE ? me : 0) * PDT_WAVE;
 
@@ -178,6 +207,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     }
   }
   NB = NB + add;
+  PDT_STAMP(2);
 
   // ---- K-way merge of the per-prefix candidate streams ----------------------------------
   // stream 0: available list entries in order, mass (nb + b) * ext[v]
@@ -185,56 +215,72 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // stream 2: not extending, mass NB + B                        (:842-845)
   const float m1 = bm.b * e_last;
   const float m2 = NB + B;
-  float m0 = 0.0f, best = 0.0f;
-  int t0 = 0, kind = -1;
-  unsigned key = 0u;
-  auto refresh = [&]() {
-    const bool has0 = valid_beam && avail != 0ull;
-    if (has0) {
-      const int j = (int)__builtin_ctzll(avail);
-      t0 = mt[j];
-      m0 = tot * mp[j];
-    }
-    kind = -1;
-    best = 0.0f;
-    if (has0) {
-      best = m0;
-      kind = 0;
-    }
-    if (s1_open && (kind < 0 || m1 > best || (m1 == best && lastc < t0))) {
-      best = m1;
-      kind = 1;
-    }
-    if (s2_open && (kind < 0 || m2 > best)) {
-      best = m2;
-      kind = 2;
-    }
+  // head of stream 0 (first available list entry of this prefix)
+  int t0 = 0;
+  float m0 = 0.0f;
+  if (valid_beam && avail != 0ull) {
+    const int j = (int)__builtin_ctzll(avail);
+    t0 = mt[j];
+    m0 = tot * mp[j];
+  }
+  int kind;
+  float best;
+  unsigned key;
+  // branch-free choice among the three streams; ties go to the lowest flat candidate index
+  auto choose = [&]() {
+    // bitwise (not short-circuit) logic keeps this straight-line code
+    const bool has0 = valid_beam & (avail != 0ull);
+    const bool take1 = s1_open & ((!has0) | (m1 > m0) | ((m1 == m0) & (lastc < t0)));
+    best = take1 ? m1 : m0;
+    kind = take1 ? 1 : (has0 ? 0 : -1);
+    const bool take2 = s2_open & ((kind < 0) | (m2 > best));
+    best = take2 ? m2 : best;
+    kind = take2 ? 2 : kind;
     key = kind >= 0 ? fkey(best) : 0u;
   };
-  refresh();
+  choose();
 
   new_src = 0, new_tok = 0, new_kind = -1;
   float new_mass = -PDT_INF;
   for (int i = 0; i < K; ++i) {
-    const unsigned mx = wave_max_u32(key);
+    const unsigned mx = Kp <= 16 ? row0_max_u32(key) : wave_max_u32(key);
     if (mx == 0u) break;  // fewer valid candidates than K: the rest stay invalid (:902-924)
     const int win = (int)__builtin_ctzll(__ballot(key == mx));
     const int wkind = __builtin_amdgcn_readlane(kind, win);
     const int wtok = __builtin_amdgcn_readlane(kind == 0 ? t0 : lastc, win);
-    const float wmass = readlane_f(best, win);
-    if (lane == i) {
-      new_src = win;
-      new_tok = wtok;
-      new_kind = wkind;
-      new_mass = wmass;
+    const int wmass = __builtin_amdgcn_readlane(__float_as_int(best), win);
+    const bool rec = lane == i;
+    new_src = rec ? win : new_src;
+    new_tok = rec ? wtok : new_tok;
+    new_kind = rec ? wkind : new_kind;
+    new_mass = rec ? __int_as_float(wmass) : new_mass;
+    // advance the winner's stream: computed wave-uniformly, applied by the winner lane only
+    u64 av = readlane_u64(avail, win);
+    int nt0 = 0;
+    float np0 = 0.0f;
+    if (wkind == 0) {
+      av &= av - 1ull;
+      if (av != 0ull) {
+        const int j = (int)__builtin_ctzll(av);
+        if (DENSE) {
+          nt0 = L.tl_tok[win * PDT_WAVE + j];
+          np0 = L.tl_p[win * PDT_WAVE + j];
+        } else {
+          nt0 = __builtin_amdgcn_readlane(list_tok, j);
+          np0 = readlane_f(list_p, j);
+        }
+      }
     }
-    if (lane == win) {
-      if (kind == 0) avail &= avail - 1ull;
-      else if (kind == 1) s1_open = false;
-      else s2_open = false;
-      refresh();
-    }
+    const bool me_win = lane == win;
+    avail = me_win ? av : avail;
+    const bool adv0 = me_win & (wkind == 0);
+    t0 = adv0 ? nt0 : t0;
+    m0 = adv0 ? tot * np0 : m0;
+    s1_open = s1_open & !(me_win & (wkind == 1));
+    s2_open = s2_open & !(me_win & (wkind == 2));
+    choose();
   }
+  PDT_STAMP(3);
   if (!DENSE) {
     wave_sync();
     if (lane < M) L.pos[L.tl_tok[lane]] = 0xFF;  // leave the inverse index clean
@@ -256,6 +302,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   if (!DENSE && is_valid && is_ext)
     a.trie[((int64_t)t * a.N + n) * W + lane] = make_int2(node_s, new_tok);
 
+  PDT_STAMP(4);
   // ---- is-prefix relation and next-token table of the new beam (:883-898) ---------------
   // Only pairs (a, b) whose sources were related need work: chm[j] = new entries descending
   // from old entry j, so lane a visits  U_{j in isp(src_a)} chm[j]  (usually 1-3 entries).
@@ -329,6 +376,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   nw.isp = isp_new;
   bm = nw;
   wave_sync();
+  PDT_STAMP(5);
 }
 
 }  // namespace pdt

@@ -45,14 +45,47 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
   bm.node = -1;
   bm.isp = lane == 0 ? 1ull : 0ull;
   int Kp = 1;
+  constexpr int kPrefetch = 8;
+  float pre[kPrefetch];
+  if (Tn > 0) {
+    const float *row0 = a.logits + n * a.lg_sn;
+#pragma unroll
+    for (int i = 0; i < kPrefetch; ++i) {
+      const int v = lane + i * PDT_WAVE;
+      pre[i] = v <= V ? row0[(int64_t)v * a.lg_sv] : 0.0f;
+    }
+  }
+#ifdef PDT_STAMPS
+  unsigned long long pdt_stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int t = 0; t < Tn; ++t) {
-    // softmax statistics of frame t (:1093) -- p[v] = exp(x[v] - max), sum over v in [0, V]
-    const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+    PDT_STAMP_BEGIN;
+    // softmax statistics of frame t (:1093) -- p[v] = exp(x[v] - max), sum over v in [0, V].
+    // The first kPrefetch*64 logits of the frame were fetched into registers one frame ago.
     float mx = -PDT_INF;
-    for (int v = lane; v <= V; v += PDT_WAVE) {
-      const float x = row[(int64_t)v * a.lg_sv];
-      p[v] = x;
-      mx = fmaxf(mx, x);
+#pragma unroll
+    for (int i = 0; i < kPrefetch; ++i) {
+      const int v = lane + i * PDT_WAVE;
+      if (v <= V) {
+        p[v] = pre[i];
+        mx = fmaxf(mx, pre[i]);
+      }
+    }
+    {
+      const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+      for (int v = lane + kPrefetch * PDT_WAVE; v <= V; v += PDT_WAVE) {
+        const float x = row[(int64_t)v * a.lg_sv];
+        p[v] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    if (t + 1 < Tn) {
+      const float *nrow = a.logits + (int64_t)(t + 1) * a.lg_st + n * a.lg_sn;
+#pragma unroll
+      for (int i = 0; i < kPrefetch; ++i) {
+        const int v = lane + i * PDT_WAVE;
+        if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
+      }
     }
     mx = wave_max_f(mx);
     float s = 0.0f;
@@ -63,14 +96,20 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
     }
     s = wave_sum_f(s);
     wave_sync();
+    PDT_STAMP(0);
     int ns, nt, nk;
-    ctc_frame<false>(bm, p, s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk);
+    ctc_frame<false>(bm, p, s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
     int *tmp = L.nxt_old;
     L.nxt_old = L.nxt_new;
     L.nxt_new = tmp;
     Kp = W;
   }
 
+#ifdef PDT_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], pdt_stamp_acc[i]);
+  unsigned long long stamp_last_ = __builtin_readcyclecounter();
+#endif
   // ---- outputs (:1188-1200): probabilities, lengths, and the prefixes read off the trie --
   if (lane < W) {
     a.y_probs[n * W + lane] = bm.nb + bm.b;
@@ -89,6 +128,9 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
       node = par;
     }
   }
+#ifdef PDT_STAMPS
+  if (lane == 0) atomicAdd(&g_stamps[6], __builtin_readcyclecounter() - stamp_last_);
+#endif
 }
 
 size_t ctc_lds_per_wave(int V, int W) {
@@ -144,3 +186,14 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
 }
 
 }  // extern "C"
+
+#ifdef PDT_STAMPS
+extern "C" int pdt_debug_read_stamps(unsigned long long *host16, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host16, HIP_SYMBOL(pdt::g_stamps), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif

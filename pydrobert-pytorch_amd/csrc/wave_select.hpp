@@ -24,41 +24,75 @@ __device__ __forceinline__ u64 pack_key(unsigned key, unsigned idx) {
 __device__ __forceinline__ unsigned key_of(u64 k) { return (unsigned)(k >> 32); }
 __device__ __forceinline__ unsigned idx_of(u64 k) { return 0xffffffffu - (unsigned)k; }
 
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int j) {
-  const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)v, j);
-  const unsigned hi = (unsigned)__shfl_xor((int)(unsigned)(v >> 32), j);
-  return ((u64)hi << 32) | lo;
-}
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
   const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src);
   const unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
   return ((u64)hi << 32) | lo;
 }
 
-template <typename T>
-__device__ __forceinline__ T shfl_xor_any(T v, int j);
-template <>
-__device__ __forceinline__ u64 shfl_xor_any<u64>(u64 v, int j) { return shfl_xor_u64(v, j); }
-template <>
-__device__ __forceinline__ unsigned shfl_xor_any<unsigned>(unsigned v, int j) {
-  return (unsigned)__shfl_xor((int)v, j);
+// value of lane (lane ^ J), J a power of two, WITHOUT touching the LDS crossbar:
+// DPP quad_perm (J = 1, 2), two bank-masked row shifts (J = 4), row_ror:8 (J = 8), and the
+// gfx950 v_permlane16_swap / v_permlane32_swap for J = 16 / 32.
+template <int J>
+__device__ __forceinline__ unsigned xor_shfl(unsigned v) {
+  if constexpr (J == 1) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
+  } else if constexpr (J == 2) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+  } else if constexpr (J == 4) {
+    const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);  // row_shl:4
+    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xa, false);    // row_shr:4
+  } else if constexpr (J == 8) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  } else if constexpr (J == 16) {
+    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    // r[0] = rows (0,0,2,2), r[1] = rows (1,1,3,3) of v
+    return __builtin_amdgcn_inverse_ballot_w64(0x0000FFFF0000FFFFull) ? r[1] : r[0];
+  } else {
+    static_assert(J == 32, "xor_shfl: J must be a power of two <= 32");
+    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    // r[0] = (low half, low half), r[1] = (high half, high half) of v
+    return __builtin_amdgcn_inverse_ballot_w64(0x00000000FFFFFFFFull) ? r[1] : r[0];
+  }
+}
+template <int J>
+__device__ __forceinline__ u64 xor_shfl(u64 v) {
+  return ((u64)xor_shfl<J>((unsigned)(v >> 32)) << 32) | xor_shfl<J>((unsigned)v);
 }
 
-// bitonic sort of one key per lane, DESCENDING (lane 0 ends with the maximum)
+// lanes that keep the LARGER key at bitonic stage (k, j) of a descending sort
+constexpr u64 bitonic_keep_max_mask(int k, int j) {
+  u64 m = 0;
+  for (int l = 0; l < 64; ++l) {
+    const bool up = (k == 64) || ((l & k) == 0);
+    if (((l & j) == 0) == up) m |= 1ull << l;
+  }
+  return m;
+}
+
+template <int K, int J, typename T>
+__device__ __forceinline__ T bitonic_stage(T key) {
+  const T other = xor_shfl<J>(key);
+  const bool keep_max = __builtin_amdgcn_inverse_ballot_w64(bitonic_keep_max_mask(K, J));
+  return ((key > other) == keep_max) ? key : other;
+}
+template <int K, int J, typename T>
+__device__ __forceinline__ T bitonic_merge(T key) {
+  key = bitonic_stage<K, J>(key);
+  if constexpr (J > 1) key = bitonic_merge<K, J / 2>(key);
+  return key;
+}
+
+// bitonic sort of one key per lane, DESCENDING (lane 0 ends with the maximum); 21
+// compare-exchange stages of ~6 (u64) / ~4 (u32) VALU instructions, no LDS
 template <typename T>
 __device__ __forceinline__ T wave_sort_desc(T key) {
-  const int lane = lane_id();
-#pragma unroll
-  for (int k = 2; k <= PDT_WAVE; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const T other = shfl_xor_any<T>(key, j);
-      const bool up = (lane & k) == 0;  // k == 64: always true -> overall descending
-      const bool take_max = ((lane & j) == 0) == up;
-      const T mx = key > other ? key : other, mn = key > other ? other : key;
-      key = take_max ? mx : mn;
-    }
-  }
+  key = bitonic_merge<2, 1>(key);
+  key = bitonic_merge<4, 2>(key);
+  key = bitonic_merge<8, 4>(key);
+  key = bitonic_merge<16, 8>(key);
+  key = bitonic_merge<32, 16>(key);
+  key = bitonic_merge<64, 32>(key);
   return key;
 }
 
@@ -67,15 +101,8 @@ __device__ __forceinline__ u64 wave_merge_top64(u64 cur, u64 add) {
   const int lane = lane_id();
   add = wave_sort_desc<u64>(add);
   const u64 rev = shfl_u64(add, PDT_WAVE - 1 - lane);
-  u64 key = cur > rev ? cur : rev;  // bitonic
-#pragma unroll
-  for (int j = PDT_WAVE >> 1; j > 0; j >>= 1) {
-    const u64 other = shfl_xor_u64(key, j);
-    const bool take_max = (lane & j) == 0;
-    const u64 mx = key > other ? key : other, mn = key > other ? other : key;
-    key = take_max ? mx : mn;
-  }
-  return key;
+  const u64 key = cur > rev ? cur : rev;  // bitonic
+  return bitonic_merge<64, 32>(key);
 }
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
@@ -87,6 +114,15 @@ __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
   v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_BCAST15, 0xa>((int)v, 0));
   v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_BCAST31, 0xc>((int)v, 0));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// max over lanes 0..15 only (one DPP row): 4 steps instead of 6
+__device__ __forceinline__ unsigned row0_max_u32(unsigned x) {
+  unsigned v = x;
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(1)>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(2)>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>((int)v, 0));
+  v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>((int)v, 0));
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
 }
 __device__ __forceinline__ float wave_max_f(float x) { return fkey_inv(wave_max_u32(fkey(x))); }
 __device__ __forceinline__ float wave_sum_f(float x) {

@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "_lib", "libpdt_amd.so")
+LIB_PATH = os.environ.get("PDT_AMD_LIB", os.path.join(_HERE, "_lib", "libpdt_amd.so"))
 
 PDT_OK = 0
 PDT_E_ARG = -1
