@@ -51,9 +51,10 @@ def make_inputs(args, rank, device):
     return ref, hyp
 
 
-def cpu_baseline(args):
-    """The oracle's reference-faithful C restatement (O(H*R^2) per utterance, like
-    _string.py:316-317) timed on ONE host core on a bounded sample of the same workload."""
+def cpu_baseline(args, with_decode):
+    """The oracle's reference-faithful C restatement (O(H*R^2) per utterance like
+    _string.py:316-317; dense candidate tables per frame like _decoding.py:842-846) timed on
+    ONE host core on a bounded sample of the same workload."""
     import oracle
 
     rng = np.random.default_rng(0x5EED0002)
@@ -62,20 +63,26 @@ def cpu_baseline(args):
     while t_used < args.cpu_seconds and done < args.N:
         ref = rng.integers(0, V, (T, n))
         hyp = rng.integers(0, V, (T, n))
+        lg = rng.normal(size=(T, n, V + 1)).astype(np.float32)
+        np.put_along_axis(lg, rng.integers(0, V + 1, (T, n, 1)), 12.0, 2)
         t0 = time.perf_counter()
         oracle.error_rate(ref, hyp)
         oracle.prefix_error_rates(ref, hyp)
         oracle.optimal_completion(ref, hyp)
+        if with_decode:
+            oracle.ctc_prefix_search(lg, args.beam)
         t_used += time.perf_counter() - t0
         done += n
-        n = min(n * 2, 32)
+        n = min(n * 2, 16)
     return {
         "value": done / t_used,
         "unit": "utterances/s",
         "cores": 1,
         "kind": "port",
-        "sample": "{} utterances of T={} V={}: error_rate + prefix_error_rates + "
-        "optimal_completion with the oracle's reference-faithful C restatement".format(done, T, V),
+        "sample": "{} utterances of T={} V={}: the step's operators ({}) with the oracle's "
+        "reference-faithful C restatement".format(
+            done, T, V, "string ops + ctc_prefix_search" if with_decode else "string ops"
+        ),
     }
 
 
@@ -86,6 +93,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -175,6 +183,19 @@ def main():
     }
     dom = max((o for o in ops if o in alg_bytes), key=lambda o: op_ms[o])
     achieved = alg_bytes[dom] * N / (op_ms[dom] * 1e-3) / 1e9
+    kernel_names = {
+        "error_rate": "pdt::lev_skewed_kernel<false>",
+        "prefix_error_rates": "pdt::lev_skewed_kernel<false>",
+        "optimal_completion": "pdt::lev_rowsync_kernel<false,false> + pdt::oc_expand_kernel",
+        "ctc_prefix_search": "pdt::ctc_search_kernel",
+    }
+    # HBM bytes per launch from rocprofv3 PMC passes (profiles/), only for the profiled config
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_ctc_traffic.json")
+    if dom == "ctc_prefix_search" and os.path.exists(tpath):
+        rec = json.load(open(tpath))
+        if rec["config"] == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
+            traffic = rec["hbm_bytes_per_launch"]
 
     if rank == 0:
         out = {
@@ -197,17 +218,20 @@ def main():
             },
             "op_ms": op_ms,
             "roofline": {
-                "kernel": dom,
+                "kernel": kernel_names[dom],
+                "op": dom,
+                "algorithmic_bytes_per_launch": alg_bytes[dom] * N,
+                "avg_launch_ms": op_ms[dom],
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, have_decode)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
