@@ -271,6 +271,91 @@ __global__ void __launch_bounds__(256) spec_augment_apply_kernel(const SpecAugAr
   }
 }
 
+// Fast path of the above for the common SpecAugment setting (no frequency warp, F % 4 == 0,
+// unit stride along F): an output row is a 2-tap blend of two source rows, so a thread moves
+// a float4 -- 16-byte coalesced loads and stores.  Per-row (source row, weights, time mask) and
+// per-column (frequency mask) decisions are made once per workgroup and kept in LDS.
+constexpr int kRowsPerTile = 256;
+__global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArgs a, int tiles) {
+  __shared__ int row_y0[kRowsPerTile];      // source row, or -1 when the row is masked
+  __shared__ float row_w1[kRowsPerTile];    // weight of source row y0 + 1
+  __shared__ unsigned col_keep[64];         // per float4 column: 4 keep bits
+  const int64_t n = blockIdx.x / tiles;
+  const int tile = (int)(blockIdx.x % tiles);
+  const int T = a.T, F4 = a.F >> 2;
+  const int t_begin = tile * kRowsPerTile, t_end = min(T, t_begin + kRowsPerTile);
+  const int tid = (int)threadIdx.x;
+  if (t_begin + tid < t_end) {
+    const int t = t_begin + tid;
+    bool masked = false;
+    for (int m = 0; m < a.MT; ++m) {
+      const int64_t s = a.t0[n * a.MT + m];
+      masked = masked || (t >= s && t < s + a.tl[n * a.MT + m]);
+    }
+    int y0 = t;
+    float w1 = 0.0f;
+    if (a.tgrid) {
+      const float iy = clip_coord(unnormalize(a.tgrid[n * T + t], T), T);
+      const float y0f = floorf(iy);
+      y0 = (int)y0f;
+      w1 = iy - y0f;
+    }
+    row_y0[tid] = masked ? -1 : y0;
+    row_w1[tid] = w1;
+  }
+  for (int c = tid; c < F4; c += 256) {
+    unsigned keep = 0u;
+    for (int j = 0; j < 4; ++j) {
+      const int f = 4 * c + j;
+      bool fm = false;
+      for (int m = 0; m < a.MF; ++m) {
+        const int64_t s = a.f0[n * a.MF + m];
+        fm = fm || (f >= s && f < s + a.fl[n * a.MF + m]);
+      }
+      keep |= fm ? 0u : (1u << j);
+    }
+    col_keep[c] = keep;
+  }
+  __syncthreads();
+  const float *fn = a.feats + n * a.f_sn;
+  float *on = a.out + n * (int64_t)T * a.F;
+  const float inv = 1.0f / (float)F4;
+  const int total = (t_end - t_begin) * F4;
+  for (int idx = tid; idx < total; idx += 256) {
+    int r = (int)(((float)idx + 0.5f) * inv);
+    int f4 = idx - r * F4;
+    if (f4 < 0) { --r; f4 += F4; }
+    if (f4 >= F4) { ++r; f4 -= F4; }
+    const int y0 = row_y0[r];
+    float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (y0 >= 0) {
+      const float w1 = row_w1[r];
+      const float4 r0 = *reinterpret_cast<const float4 *>(fn + (int64_t)y0 * a.f_st + 4 * f4);
+      if (a.tgrid && y0 + 1 < T) {
+        // same arithmetic as the 4-tap form with wx0 = 1, wx1 = 0; a row at y0 + 1 == T lies
+        // outside the image and carries weight 0 under border padding
+        const float w0 = ((float)y0 + 1.0f) - ((float)y0 + w1);
+        const float4 r1 = *reinterpret_cast<const float4 *>(fn + (int64_t)(y0 + 1) * a.f_st + 4 * f4);
+        v.x = r0.x * w0 + r1.x * w1;
+        v.y = r0.y * w0 + r1.y * w1;
+        v.z = r0.z * w0 + r1.z * w1;
+        v.w = r0.w * w0 + r1.w * w1;
+      } else if (a.tgrid) {
+        const float w0 = ((float)y0 + 1.0f) - ((float)y0 + w1);
+        v.x = r0.x * w0; v.y = r0.y * w0; v.z = r0.z * w0; v.w = r0.w * w0;
+      } else {
+        v = r0;
+      }
+      const unsigned keep = col_keep[f4];
+      v.x = (keep & 1u) ? v.x : 0.0f;
+      v.y = (keep & 2u) ? v.y : 0.0f;
+      v.z = (keep & 4u) ? v.z : 0.0f;
+      v.w = (keep & 8u) ? v.w : 0.0f;
+    }
+    *reinterpret_cast<float4 *>(on + (int64_t)(t_begin + r) * a.F + 4 * f4) = v;
+  }
+}
+
 struct WarpArgs {
   const float *image;  // (N,C,H,W) contiguous
   float *out;          // (N,C,H,W)
@@ -436,8 +521,16 @@ int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, 
   // ~16K elements per workgroup keeps >= 8 workgroups per CU in flight at N = 2048
   int tiles = (int)((T * F + 16383) / 16384);
   if (tiles < 1) tiles = 1;
-  hipLaunchKernelGGL(spec_augment_apply_kernel, dim3((unsigned)(N * tiles)), dim3(256), 0,
-                     (hipStream_t)stream, a, tiles);
+  const bool rows_path = !freq_grid && (F % 4 == 0) && f_sf == 1 && (f_st % 4 == 0) &&
+                         (f_sn % 4 == 0) && ((uintptr_t)feats % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (rows_path && F <= 256) {
+    const int rtiles = (int)((T + kRowsPerTile - 1) / kRowsPerTile);
+    hipLaunchKernelGGL(spec_augment_rows_kernel, dim3((unsigned)(N * rtiles)), dim3(256), 0,
+                       (hipStream_t)stream, a, rtiles);
+  }
+  else
+    hipLaunchKernelGGL(spec_augment_apply_kernel, dim3((unsigned)(N * tiles)), dim3(256), 0,
+                       (hipStream_t)stream, a, tiles);
   return (int)hipGetLastError();
 }
 
