@@ -90,6 +90,28 @@ int pdt_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int64_t 
                   int64_t tgt_sh, int64_t tgt_sn, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Hard optimal-completion distillation loss, fused (hard_optimal_completion_distillation_loss,
+ * _string.py:1188-1251).  Consumes pdt_oc_mask's outputs directly (exclude_last = 1, so the
+ * bitmask has H rows) instead of the expanded (H, N, C) targets:
+ *   loss[h*N + n]  = mean over the completion set S of  -weight[t] * log_softmax(logits[h,n])[t]
+ *   count[h*N + n] = |S| (targets equal to ignore_index are skipped), loss uses max(count, 1).
+ * logits (H, N, V) float32 through element strides; weight (V,) or NULL.
+ * Backward: grad_logits (H, N, V) contiguous from grad_loss (H, N).
+ * status (optional) bit 0 is set when a target lies outside [0, V).
+ * ------------------------------------------------------------------------------------- */
+int pdt_ocd_loss_forward(const float *logits, int64_t H, int64_t N, int64_t V, int64_t lg_sh,
+                         int64_t lg_sn, int64_t lg_sv, const uint32_t *bitmask,
+                         const int64_t *class_tokens, int64_t R, const float *weight,
+                         int64_t ignore_index, float *loss, int32_t *count, int32_t *status,
+                         void *stream);
+
+int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, int64_t lg_sh,
+                          int64_t lg_sn, int64_t lg_sv, const uint32_t *bitmask,
+                          const int64_t *class_tokens, int64_t R, const float *weight,
+                          int64_t ignore_index, const float *grad_loss, float *grad_logits,
+                          void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * CTC prefix beam search without a language model: CTCPrefixSearch(width)(logits, lens)
  * (reference _decoding.py:1064-1202; the per-frame step is ctc_prefix_search_advance,
  * :636-934; the softmax of :1093 is fused).

@@ -40,6 +40,12 @@ SIGNATURES = {
         + [_INT, _P, _P, _P, _P, _P],
     ),
     "pdt_oc_expand": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P]),
+    "pdt_ocd_loss_forward": (
+        _INT, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P],
+    ),
+    "pdt_ocd_loss_backward": (
+        _INT, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P],
+    ),
     "pdt_ctc_prefix_search_advance": (
         _INT,
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64]

@@ -17,12 +17,16 @@ __all__ = [
     "EditDistance",
     "ErrorRate",
     "FillAfterEndOfSequence",
+    "HardOptimalCompletionDistillationLoss",
+    "MinimumErrorRateLoss",
     "OptimalCompletion",
     "PrefixEditDistances",
     "PrefixErrorRates",
     "edit_distance",
     "error_rate",
     "fill_after_eos",
+    "hard_optimal_completion_distillation_loss",
+    "minimum_error_rate_loss",
     "optimal_completion",
     "prefix_edit_distances",
     "prefix_error_rates",
@@ -253,26 +257,14 @@ def optimal_completion(
     ``counts.max().item()`` (:511): the DP emits per-prefix class bitmasks plus the
     maximum set size ``C``; the expansion writes the ``(H', N, C)`` int64 targets.
     """
-    device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N = _prep(ref, hyp, batch_first)
-    Hout = H + (0 if exclude_last else 1)
-    if Hout == 0:
-        raise RuntimeError("hyp has no steps to compute prefixes of")
+    device, bitmask, class_tokens, scal, (R, Hout, N) = _oc_mask(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, exclude_last, warn,
+        "pdt_oc_mask",
+    )  # fmt: skip
     L = _cabi.lib()
-    W = int(L.pdt_oc_mask_words(R))
     with torch.cuda.device(device):
-        bitmask = torch.empty((Hout, N, W), device=device, dtype=torch.int32)
-        class_tokens = torch.empty((N, max(R, 1)), device=device, dtype=torch.long)
-        scal = torch.zeros(2, device=device, dtype=torch.int32)  # [max_count, status]
         stream = _cabi.stream_ptr(device)
-        rc = L.pdt_oc_mask(
-            _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
-            int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
-            float(ins_cost), float(del_cost), float(sub_cost), int(exclude_last),
-            _cabi.ptr(bitmask), _cabi.ptr(class_tokens), scal.data_ptr(),
-            scal.data_ptr() + 4, stream,
-        )  # fmt: skip
-        _cabi.check(rc, "pdt_oc_mask")
-        C, flags = (int(x) for x in scal.tolist())  # the one host sync (:511)
+        C, flags = (int(x) for x in scal[:2].tolist())  # the one host sync (:511)
         if warn and flags:
             _emit_warnings(flags, eos, True)
         targets = torch.empty((Hout, N, C), device=device, dtype=torch.long)
@@ -285,6 +277,189 @@ def optimal_completion(
     if batch_first:
         targets = targets.transpose(0, 1)  # _string.py:515-516
     return targets
+
+
+def _oc_mask(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, exclude_last,
+             warn, what):
+    """Phase 1 of optimal completion: (bitmask (H', N, W), class_tokens (N, R), scal, sizes)."""
+    device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N = _prep(ref, hyp, batch_first)
+    Hout = H + (0 if exclude_last else 1)
+    if Hout == 0:
+        raise RuntimeError("hyp has no steps to compute prefixes of")
+    L = _cabi.lib()
+    W = int(L.pdt_oc_mask_words(R))
+    with torch.cuda.device(device):
+        bitmask = torch.empty((Hout, N, W), device=device, dtype=torch.int32)
+        class_tokens = torch.empty((N, max(R, 1)), device=device, dtype=torch.long)
+        scal = torch.zeros(3, device=device, dtype=torch.int32)  # [max_count, status, aux status]
+        rc = L.pdt_oc_mask(
+            _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
+            int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
+            float(ins_cost), float(del_cost), float(sub_cost), int(exclude_last),
+            _cabi.ptr(bitmask), _cabi.ptr(class_tokens), scal.data_ptr(),
+            scal.data_ptr() + 4, _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, what)
+    return device, bitmask, class_tokens, scal, (R, Hout, N)
+
+
+class _OcdLossFn(torch.autograd.Function):
+    """loss[h, n] of the fused distillation kernel; differentiable w.r.t. logits (H, N, V view)."""
+
+    @staticmethod
+    def forward(ctx, logits_hnv, bitmask, class_tokens, weight, ignore_index, R, status):
+        device = logits_hnv.device
+        H, N, V = logits_hnv.shape
+        x = logits_hnv.detach()
+        if x.dtype != torch.float:
+            x = x.float()
+        with torch.cuda.device(device):
+            loss = torch.empty((H, N), device=device, dtype=torch.float)
+            count = torch.empty((H, N), device=device, dtype=torch.int32)
+            rc = _cabi.lib().pdt_ocd_loss_forward(
+                _cabi.ptr(x), H, N, V, x.stride(0), x.stride(1), x.stride(2), _cabi.ptr(bitmask),
+                _cabi.ptr(class_tokens), R, _cabi.ptr(weight), int(ignore_index), _cabi.ptr(loss),
+                _cabi.ptr(count), _cabi.ptr(status), _cabi.stream_ptr(device),
+            )  # fmt: skip
+        _cabi.check(rc, "pdt_ocd_loss_forward")
+        ctx.save_for_backward(x, bitmask, class_tokens, weight)
+        ctx.cfg = (int(ignore_index), R, logits_hnv.dtype)
+        ctx.mark_non_differentiable(count)
+        return loss, count
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_count):
+        x, bitmask, class_tokens, weight = ctx.saved_tensors
+        ignore_index, R, dtype = ctx.cfg
+        H, N, V = x.shape
+        device = x.device
+        g = grad_loss.detach().float().contiguous()
+        with torch.cuda.device(device):
+            grad = torch.empty((H, N, V), device=device, dtype=torch.float)
+            rc = _cabi.lib().pdt_ocd_loss_backward(
+                _cabi.ptr(x), H, N, V, x.stride(0), x.stride(1), x.stride(2), _cabi.ptr(bitmask),
+                _cabi.ptr(class_tokens), R, _cabi.ptr(weight), ignore_index, _cabi.ptr(g),
+                _cabi.ptr(grad), _cabi.stream_ptr(device),
+            )  # fmt: skip
+        _cabi.check(rc, "pdt_ocd_loss_backward")
+        return grad.to(dtype), None, None, None, None, None, None
+
+
+def hard_optimal_completion_distillation_loss(
+    logits: torch.Tensor,
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = True,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    weight: Optional[torch.Tensor] = None,
+    reduction: str = "mean",
+    ignore_index: int = -2,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`HardOptimalCompletionDistillationLoss` (reference
+    _string.py:1188-1251).
+
+    The completion sets never leave their compact form: the DP kernel emits per-prefix class
+    bitmasks and one fused kernel evaluates the mean cross entropy over each set straight from
+    the logits -- no ``(H, N, C)`` target tensor, no ``(H, N, C, V)`` logit expansion, no host
+    read-back.
+    """
+    if logits.dim() != 3:
+        raise RuntimeError("logits must be 3 dimensional")
+    if logits.shape[:-1] != hyp.shape:
+        raise RuntimeError("first two dims of logits must match hyp shape")
+    if include_eos:
+        if eos is not None and ((eos < 0) or (eos >= logits.size(-1))):
+            raise RuntimeError("If include_eos=True, eos ({}) must be a class idx".format(eos))
+        if eos is not None and eos == ignore_index:
+            raise RuntimeError("If include_eos=True, eos cannot equal ignore_index ({}".format(eos))
+    if reduction not in ("mean", "sum", "none"):
+        raise RuntimeError("'{}' is not a valid value for reduction".format(reduction))
+    _cabi.require_hip(logits, weight)
+    device, bitmask, class_tokens, scal, (R, H, N) = _oc_mask(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, True, warn,
+        "pdt_oc_mask",
+    )  # fmt: skip
+    logits_hnv = logits.transpose(0, 1) if batch_first else logits
+    w = None if weight is None else weight.detach().float().contiguous()
+    loss, count = _OcdLossFn.apply(logits_hnv, bitmask, class_tokens, w, ignore_index, max(R, 1), scal[2:])
+    if warn:
+        _, flags, bad = (int(x) for x in scal.tolist())
+        if bad:
+            raise RuntimeError("ref contains tokens that are not class indices of logits")
+        _emit_warnings(flags, eos, True)
+    if reduction == "mean":
+        # per utterance: sum over prefixes / number of prefixes with a non-empty set, then the
+        # batch mean (:1243-1247)
+        loss = (loss.sum(0) / (count > 0).sum(0).clamp_min(1)).mean()
+    elif reduction == "sum":
+        loss = loss.sum()
+    elif batch_first:
+        loss = loss.t()
+    return loss
+
+
+def minimum_error_rate_loss(
+    log_probs: torch.Tensor,
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = True,
+    sub_avg: bool = True,
+    batch_first: bool = False,
+    norm: bool = True,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    reduction: str = "mean",
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`MinimumErrorRateLoss` (reference _string.py:1400-1472):
+    expected error rate of ``samples`` hypotheses per batch element under
+    ``softmax(log_probs)``; the error rates come from one ``pdt_lev`` launch over
+    ``batch * samples`` utterances."""
+    if log_probs.dim() != 2:
+        raise RuntimeError("log_probs must be 2 dimensional")
+    if hyp.dim() != 3:
+        raise RuntimeError("hyp must be 3 dimensional")
+    if ref.dim() not in (2, 3):
+        raise RuntimeError("ref must be 2 or 3 dimensional")
+    if batch_first:
+        batch_size, samples, max_hyp_steps = hyp.shape
+        if ref.dim() == 2:
+            ref = ref.unsqueeze(1).repeat(1, samples, 1)
+        if (ref.shape[:2] != (batch_size, samples)) or (ref.shape[:2] != log_probs.shape):
+            raise RuntimeError("ref and hyp batch_size and sample dimensions must match")
+        ref = ref.reshape(-1, ref.size(-1))
+        hyp = hyp.reshape(-1, max_hyp_steps)
+    else:
+        max_hyp_steps, batch_size, samples = hyp.shape
+        if ref.dim() == 2:
+            ref = ref.unsqueeze(-1).repeat(1, 1, samples)
+        if (ref.shape[1:] != (batch_size, samples)) or (ref.shape[1:] != log_probs.shape):
+            raise RuntimeError("ref and hyp batch_size and sample dimensions must match")
+        ref = ref.reshape(ref.size(0), -1)
+        hyp = hyp.reshape(max_hyp_steps, -1)
+    if samples < 2:
+        raise RuntimeError("Batch must have at least two samples, got {}".format(samples))
+    if reduction not in ("mean", "sum", "none"):
+        raise RuntimeError("'{}' is not a valid value for reduction".format(reduction))
+    er = error_rate(
+        ref, hyp, eos=eos, include_eos=include_eos, norm=norm, batch_first=batch_first,
+        ins_cost=ins_cost, del_cost=del_cost, sub_cost=sub_cost, warn=warn,
+    ).view(batch_size, samples)  # fmt: skip
+    if sub_avg:
+        er = er - er.mean(1, keepdim=True)
+    loss = er * torch.nn.functional.softmax(log_probs, 1)
+    if reduction == "mean":
+        loss = loss.mean()
+    elif reduction == "sum":
+        loss = loss.sum()
+    return loss
 
 
 # ---------------------------------------------------------------------------------------
@@ -483,4 +658,95 @@ class OptimalCompletion(_StringMatching):
         return optimal_completion(
             ref, hyp, self.eos, self.include_eos, self.batch_first, self.ins_cost,
             self.del_cost, self.sub_cost, self.padding, self.exclude_last, self.warn,
+        )  # fmt: skip
+
+
+class HardOptimalCompletionDistillationLoss(torch.nn.Module):
+    """A categorical loss based on how likely a model outputs optimal completions (reference
+    _string.py:1254-1378)."""
+
+    __constants__ = (
+        "eos", "include_eos", "batch_first", "ins_cost", "del_cost", "sub_cost", "reduction",
+        "ignore_index",
+    )  # fmt: skip
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = True,
+        batch_first: bool = False,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        weight: Optional[torch.Tensor] = None,
+        reduction: str = "mean",
+        ignore_index: int = config.INDEX_PAD_VALUE,
+    ):
+        eos = argcheck.is_int(eos, "eos", True)
+        include_eos = argcheck.is_bool(include_eos, "include_eos")
+        batch_first = argcheck.is_bool(batch_first, "batch_first")
+        ins_cost = argcheck.is_float(ins_cost, "ins_cost")
+        del_cost = argcheck.is_float(del_cost, "del_cost")
+        sub_cost = argcheck.is_float(sub_cost, "sub_cost")
+        weight = argcheck.is_tensor(weight, "weight", True)
+        reduction = argcheck.is_in(reduction, ("mean", "sum", "none"), "reduction")
+        ignore_index = argcheck.is_int(ignore_index, "ignore_index")
+        super().__init__()
+        self.eos, self.include_eos, self.batch_first = eos, include_eos, batch_first
+        self.ins_cost, self.del_cost, self.sub_cost = ins_cost, del_cost, sub_cost
+        self.reduction, self.ignore_index = reduction, ignore_index
+        self.register_buffer("weight", weight)
+
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+    def forward(self, logits, ref, hyp, warn: bool = True) -> torch.Tensor:
+        return hard_optimal_completion_distillation_loss(
+            logits, ref, hyp, self.eos, self.include_eos, self.batch_first, self.ins_cost,
+            self.del_cost, self.sub_cost, self.weight, self.reduction, self.ignore_index, warn,
+        )  # fmt: skip
+
+
+class MinimumErrorRateLoss(torch.nn.Module):
+    """Error rate expectation normalized over some number of transcripts (reference
+    _string.py:1475-1646)."""
+
+    __constants__ = (
+        "eos", "include_eos", "sub_avg", "batch_first", "norm", "ins_cost", "del_cost",
+        "sub_cost", "reduction",
+    )  # fmt: skip
+
+    def __init__(
+        self,
+        eos: Optional[int] = None,
+        include_eos: bool = True,
+        sub_avg: bool = True,
+        batch_first: bool = False,
+        norm: bool = True,
+        ins_cost: float = config.DEFT_INS_COST,
+        del_cost: float = config.DEFT_DEL_COST,
+        sub_cost: float = config.DEFT_SUB_COST,
+        reduction: str = "mean",
+    ):
+        eos = argcheck.is_int(eos, "eos", True)
+        include_eos = argcheck.is_bool(include_eos, "include_eos")
+        sub_avg = argcheck.is_bool(sub_avg, "sub_avg")
+        batch_first = argcheck.is_bool(batch_first, "batch_first")
+        norm = argcheck.is_bool(norm, "norm")
+        ins_cost = argcheck.is_float(ins_cost, "ins_cost")
+        del_cost = argcheck.is_float(del_cost, "del_cost")
+        sub_cost = argcheck.is_float(sub_cost, "sub_cost")
+        reduction = argcheck.is_in(reduction, ("mean", "sum", "none"), "reduction")
+        super().__init__()
+        self.eos, self.include_eos, self.sub_avg = eos, include_eos, sub_avg
+        self.batch_first, self.norm, self.reduction = batch_first, norm, reduction
+        self.ins_cost, self.del_cost, self.sub_cost = ins_cost, del_cost, sub_cost
+
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+    def forward(self, log_probs, ref, hyp, warn: bool = True) -> torch.Tensor:
+        return minimum_error_rate_loss(
+            log_probs, ref, hyp, self.eos, self.include_eos, self.sub_avg, self.batch_first,
+            self.norm, self.ins_cost, self.del_cost, self.sub_cost, self.reduction, warn,
         )  # fmt: skip

@@ -16,6 +16,8 @@ from ._img import (
     warp_1d_grid,
 )
 from ._string import (
+    hard_optimal_completion_distillation_loss,
+    minimum_error_rate_loss,
     edit_distance,
     error_rate,
     fill_after_eos,
@@ -25,6 +27,8 @@ from ._string import (
 )
 
 __all__ = [
+    "hard_optimal_completion_distillation_loss",
+    "minimum_error_rate_loss",
     "beam_search_advance",
     "ctc_prefix_search",
     "ctc_prefix_search_advance",

@@ -9,6 +9,8 @@ from ._lm import (
     SequentialLanguageModel,
 )
 from ._string import (
+    HardOptimalCompletionDistillationLoss,
+    MinimumErrorRateLoss,
     EditDistance,
     ErrorRate,
     FillAfterEndOfSequence,
@@ -18,6 +20,8 @@ from ._string import (
 )
 
 __all__ = [
+    "HardOptimalCompletionDistillationLoss",
+    "MinimumErrorRateLoss",
     "BeamSearch",
     "CTCPrefixSearch",
     "ExtractableSequentialLanguageModel",

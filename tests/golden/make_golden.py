@@ -279,8 +279,40 @@ def image_goldens():
     save("image", **d)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") == "":
     string_goldens()
     sclite_golden()
     decoding_goldens()
     image_goldens()
+
+
+def loss_goldens():
+    rng = np.random.default_rng(0x5EED0005)
+    N, R, H, V = 6, 9, 8, 7
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    ref[5, 0] = hyp[4, 1] = 0
+    logits = torch.from_numpy(rng.normal(size=(H, N, V)).astype(np.float32)).requires_grad_(True)
+    w = torch.from_numpy(rng.uniform(0.5, 2.0, V).astype(np.float32))
+    d = dict(ref=ref, hyp=hyp, logits=logits.detach(), weight=w)
+    for tag, kw in {"a": dict(eos=0), "b": dict(eos=None, weight=w), "c": dict(eos=0, include_eos=False, weight=w)}.items():
+        for red in ("mean", "sum", "none"):
+            loss = F.hard_optimal_completion_distillation_loss(
+                logits, torch.from_numpy(ref), torch.from_numpy(hyp), reduction=red, warn=False, **kw)
+            (g,) = torch.autograd.grad(loss.sum(), logits)
+            d["hocd_{}_{}".format(tag, red)] = loss.detach()
+            d["hocd_{}_{}_grad".format(tag, red)] = g
+    S = 3
+    hyp3 = rng.integers(0, V, (H, N, S))
+    lp = torch.from_numpy(rng.normal(size=(N, S)).astype(np.float32))
+    d.update(mer_hyp=hyp3, mer_lp=lp)
+    for red in ("mean", "none"):
+        for sub_avg in (True, False):
+            d["mer_{}_{}".format(red, int(sub_avg))] = F.minimum_error_rate_loss(
+                lp, torch.from_numpy(ref), torch.from_numpy(hyp3), eos=0, sub_avg=sub_avg,
+                reduction=red, warn=False)
+    save("losses", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "losses"):
+    loss_goldens()
