@@ -173,6 +173,31 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
                             float *log_probs_next, int64_t *next_src, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * ctc_greedy_search (reference _decoding.py:507-558).  logits (T, N, V) through element
+ * strides; blank_idx already normalised to [0, V).  max_out (N,): sum of the per-frame maximum
+ * log-probabilities (is_probs: product of the maxima, no normalisation) over frames below
+ * in_lens; paths (T, N) int64 through strides: the first out_lens[n] entries of column n are
+ * the collapsed tokens, the rest the raw per-frame arg-max (as the reference leaves them).
+ *
+ * sequence_log_probs on tensors (_decoding.py:1516-1551).  hyp viewed as (A, S, B) with S the
+ * step axis, logits (A, S, B, V) contiguous; out (A, B) = sum over valid steps of
+ * log_softmax(logits)[hyp]; tokens outside [0, V) and steps after the first eos are skipped.
+ * Backward: grad_logits (same layout) from grad_out (A, B).
+ * ------------------------------------------------------------------------------------- */
+int pdt_ctc_greedy_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st,
+                          int64_t lg_sn, int64_t lg_sv, const int64_t *in_lens, int64_t blank_idx,
+                          int is_probs, float *max_out, int64_t *paths, int64_t pa_st,
+                          int64_t pa_sn, int64_t *out_lens, void *stream);
+
+int pdt_sequence_log_probs_forward(const float *logits, const int64_t *hyp, int64_t A, int64_t S,
+                                   int64_t B, int64_t V, int has_eos, int64_t eos, float *out,
+                                   void *stream);
+
+int pdt_sequence_log_probs_backward(const float *logits, const int64_t *hyp, int64_t A, int64_t S,
+                                    int64_t B, int64_t V, int has_eos, int64_t eos,
+                                    const float *grad_out, float *grad_logits, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Feature augmentation / image warps (reference _img.py).  All tensors float32 and
  * contiguous unless strides are given.
  *

@@ -235,3 +235,4 @@ def optimal_completion(ref, hyp, eos=None, include_eos=True, batch_first=False,
 from ._decoding import *  # noqa: E402,F401,F403
 from ._img import *  # noqa: E402,F401,F403
 from ._losses import *  # noqa: E402,F401,F403
+from ._seqops import *  # noqa: E402,F401,F403

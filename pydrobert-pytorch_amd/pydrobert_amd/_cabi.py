@@ -57,6 +57,13 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
         + [_P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     ),
+    "pdt_ctc_greedy_search": (
+        _INT, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _INT, _P, _P, _I64, _I64, _P, _P],
+    ),
+    "pdt_sequence_log_probs_forward": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _I64, _P, _P]),
+    "pdt_sequence_log_probs_backward": (
+        _INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _I64, _P, _P, _P],
+    ),
     "pdt_spline_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),
     "pdt_polyharmonic_spline": (
         _INT, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _P, _P, _P],

@@ -17,10 +17,16 @@ from ._lm import ExtractableSequentialLanguageModel, MixableSequentialLanguageMo
 
 __all__ = [
     "BeamSearch",
+    "CTCGreedySearch",
     "CTCPrefixSearch",
+    "RandomWalk",
+    "SequenceLogProbabilities",
     "beam_search_advance",
+    "ctc_greedy_search",
     "ctc_prefix_search",
     "ctc_prefix_search_advance",
+    "random_walk_advance",
+    "sequence_log_probs",
 ]
 
 MAX_CTC_WIDTH = 32
@@ -493,3 +499,285 @@ class BeamSearch(torch.nn.Module):
         if batch_size is None:
             y, lens, log_probs = y.squeeze(1), lens.squeeze(0), log_probs.squeeze(0)
         return y, lens, log_probs
+
+
+# ---------------------------------------------------------------------------------------
+# greedy CTC search, sequence log-probabilities, random walk
+# ---------------------------------------------------------------------------------------
+def ctc_greedy_search(
+    logits: torch.Tensor,
+    in_lens: Optional[torch.Tensor] = None,
+    blank_idx: int = -1,
+    batch_first: bool = False,
+    is_probs: bool = False,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Functional version of :class:`CTCGreedySearch` (reference _decoding.py:507-558):
+    returns ``(max_, paths, out_lens)``.  One pass over the logits; ``max_`` carries no gradient."""
+    if logits.dim() != 3:
+        raise RuntimeError("logits must be 3-dimensional")
+    V = logits.size(2)
+    if blank_idx < -V or blank_idx > (V - 1):
+        raise RuntimeError(
+            "Blank index out of range (expected to be in the range of [-{},{}], but got {})".format(
+                V, V - 1, blank_idx
+            )
+        )
+    blank_idx = (blank_idx + V) % V
+    device = _cabi.require_hip(logits, in_lens)
+    x = _f32(logits)
+    if batch_first:
+        N, T = x.shape[:2]
+        st, sn = x.stride(1), x.stride(0)
+    else:
+        T, N = x.shape[:2]
+        st, sn = x.stride(0), x.stride(1)
+    lens = None if in_lens is None else _i64(in_lens).contiguous()
+    with torch.cuda.device(device):
+        max_ = torch.empty((N,), device=device, dtype=torch.float)
+        paths = torch.empty((N, T) if batch_first else (T, N), device=device, dtype=torch.long)
+        out_lens = torch.empty((N,), device=device, dtype=torch.long)
+        pst, psn = (paths.stride(1), paths.stride(0)) if batch_first else (paths.stride(0), paths.stride(1))
+        rc = _cabi.lib().pdt_ctc_greedy_search(
+            _cabi.ptr(x), T, N, V, st, sn, x.stride(2), _cabi.ptr(lens), blank_idx, int(is_probs),
+            _cabi.ptr(max_), _cabi.ptr(paths), pst, psn, _cabi.ptr(out_lens), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_ctc_greedy_search")
+    return max_.to(logits.dtype), paths, out_lens
+
+
+class _SeqLogProbsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, hyp, A, S, B, eos):
+        device = logits.device
+        x = logits.detach()
+        if x.dtype != torch.float:
+            x = x.float()
+        x = x.contiguous()
+        V = x.shape[-1]
+        with torch.cuda.device(device):
+            out = torch.empty((A, B), device=device, dtype=torch.float)
+            rc = _cabi.lib().pdt_sequence_log_probs_forward(
+                _cabi.ptr(x), _cabi.ptr(hyp), A, S, B, V, int(eos is not None),
+                int(eos) if eos is not None else 0, _cabi.ptr(out), _cabi.stream_ptr(device),
+            )  # fmt: skip
+        _cabi.check(rc, "pdt_sequence_log_probs_forward")
+        ctx.save_for_backward(x, hyp)
+        ctx.cfg = (A, S, B, eos, logits.dtype, logits.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, hyp = ctx.saved_tensors
+        A, S, B, eos, dtype, shape = ctx.cfg
+        device = x.device
+        g = grad_out.detach().float().contiguous()
+        with torch.cuda.device(device):
+            grad = torch.empty_like(x)
+            rc = _cabi.lib().pdt_sequence_log_probs_backward(
+                _cabi.ptr(x), _cabi.ptr(hyp), A, S, B, x.shape[-1], int(eos is not None),
+                int(eos) if eos is not None else 0, _cabi.ptr(g), _cabi.ptr(grad),
+                _cabi.stream_ptr(device),
+            )  # fmt: skip
+        _cabi.check(rc, "pdt_sequence_log_probs_backward")
+        return grad.view(shape).to(dtype), None, None, None, None, None
+
+
+def _sequence_log_probs_tensor(logits, hyp, dim, eos):
+    hyp_dim = hyp.dim()
+    if dim < -hyp_dim or dim > hyp_dim - 1:
+        raise RuntimeError(
+            "Dimension out of range (expected to be in range of [{}, {}], but got {})".format(
+                -hyp_dim, hyp_dim - 1, dim
+            )
+        )
+    dim = (hyp_dim + dim) % hyp_dim
+    if logits.shape[:-1] != hyp.shape:
+        raise RuntimeError("logits must have shape hyp.shape + (num_classes,)")
+    _cabi.require_hip(logits, hyp)
+    shape = tuple(hyp.shape)
+    A = int(math.prod(shape[:dim]))
+    S = shape[dim]
+    B = int(math.prod(shape[dim + 1 :]))
+    h = _i64(hyp).contiguous()
+    out = _SeqLogProbsFn.apply(logits, h, A, S, B, eos)
+    return out.view(shape[:dim] + shape[dim + 1 :]).to(logits.dtype)
+
+
+def sequence_log_probs(logits, hyp: torch.Tensor, dim: int = 0, eos: Optional[int] = None) -> torch.Tensor:
+    """Functional version of :class:`SequenceLogProbabilities` (reference
+    _decoding.py:1516-1633): joint log-probability of the token sequences ``hyp`` under
+    ``logits`` (a tensor of shape ``hyp.shape + (V,)`` or a ``PackedSequence``).  Fused
+    log-softmax + gather + masked sum; differentiable w.r.t. ``logits``."""
+    if isinstance(logits, torch.Tensor):
+        return _sequence_log_probs_tensor(logits, hyp, dim, eos)
+    if isinstance(logits, (torch.nn.utils.rnn.PackedSequence, tuple)):
+        # padded view + out-of-range tokens beyond each length: same kernel, same masking rule
+        hyp_dim = hyp.dim()
+        if dim < -hyp_dim or dim > hyp_dim - 1:
+            raise RuntimeError(
+                "Dimension out of range (expected to be in range of [{}, {}], but got {})".format(
+                    -hyp_dim, hyp_dim - 1, dim
+                )
+            )
+        ps = logits if isinstance(logits, torch.nn.utils.rnn.PackedSequence) else torch.nn.utils.rnn.PackedSequence(*logits)
+        padded, lens = torch.nn.utils.rnn.pad_packed_sequence(ps)  # (S, N, V)
+        h = hyp if dim % 2 == 0 else hyp.t()
+        S = padded.shape[0]
+        h = h[:S]
+        beyond = torch.arange(S, device=h.device).unsqueeze(1) >= lens.to(h.device).unsqueeze(0)
+        return _sequence_log_probs_tensor(padded, h.masked_fill(beyond, -1), 0, None)
+    raise RuntimeError("logits must be either a Tensor or PackedSequence")
+
+
+def random_walk_advance(
+    log_probs_t: torch.Tensor,
+    log_probs_prev: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_lens: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Random walk step function (reference _decoding.py:1207-1283).  Sampling uses torch's
+    generator on the tensors' device, as in the reference; a handful of small launches."""
+    if log_probs_t.dim() != 2:
+        raise RuntimeError("log_probs_t must be 2-dimensional")
+    N, V = log_probs_t.shape
+    if log_probs_prev.shape != (N,):
+        raise RuntimeError(
+            "Expected log_probs_prev to be of shape {}, got {}".format((N,), tuple(log_probs_prev.shape))
+        )
+    if y_prev.dim() != 2:
+        raise RuntimeError("y_prev must be 2-dimensional")
+    if y_prev.size(1) != N:
+        raise RuntimeError("Expected dim 1 of y_prev to be {}, got {}".format(N, y_prev.size(-1)))
+    S = y_prev.size(0)
+    if y_prev_lens is not None and y_prev_lens.shape != (N,):
+        raise RuntimeError(
+            "Expected y_prev_lens to have shape {}, got {}".format((N,), tuple(y_prev_lens.shape))
+        )
+    y_t = torch.multinomial(log_probs_t.exp(), 1, True)  # (N, 1)
+    log_probs_next = log_probs_prev + log_probs_t.gather(1, y_t).squeeze(1)
+    y_t = y_t.T
+    if S:
+        if y_prev_lens is None:
+            y_next = torch.cat([y_prev, y_t], 0)
+        else:
+            y_next = torch.cat([y_prev, y_t], 0) if int(y_prev_lens.max().item()) >= S else y_prev
+            y_next = y_next.scatter(0, y_prev_lens.unsqueeze(0), y_t)
+    else:
+        y_next = y_t
+    return y_next, log_probs_next
+
+
+class CTCGreedySearch(torch.nn.Module):
+    """CTC greedy search (reference _decoding.py:561-635)."""
+
+    __constants__ = "blank_idx", "batch_first", "is_probs"
+
+    def __init__(self, blank_idx: int = -1, batch_first: bool = False, is_probs: bool = False):
+        blank_idx = argcheck.is_int(blank_idx, "blank_idx")
+        batch_first = argcheck.is_bool(batch_first, "batch_first")
+        is_probs = argcheck.is_bool(is_probs, "is_probs")
+        super().__init__()
+        self.blank_idx, self.batch_first, self.is_probs = blank_idx, batch_first, is_probs
+
+    def extra_repr(self) -> str:
+        return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
+
+    def forward(self, logits: torch.Tensor, in_lens: Optional[torch.Tensor] = None):
+        return ctc_greedy_search(logits, in_lens, self.blank_idx, self.batch_first, self.is_probs)
+
+
+class SequenceLogProbabilities(torch.nn.Module):
+    """Calculate joint log probability of sequences (reference _decoding.py:1636-1720)."""
+
+    __constants__ = "dim", "eos"
+
+    def __init__(self, dim: int = 0, eos: Optional[int] = None):
+        dim = argcheck.is_int(dim, "dim")
+        eos = argcheck.is_int(eos, "eos", True)
+        super().__init__()
+        self.dim, self.eos = dim, eos
+
+    def extra_repr(self) -> str:
+        s = "dim={}".format(self.dim)
+        if self.eos is not None:
+            s += ", eos={}".format(self.eos)
+        return s
+
+    def forward(self, logits, hyp: torch.Tensor) -> torch.Tensor:
+        return sequence_log_probs(logits, hyp, self.dim, self.eos)
+
+
+class RandomWalk(torch.nn.Module):
+    """Perform a random walk on the outputs of a language model (reference
+    _decoding.py:1286-1513)."""
+
+    __constants__ = ["eos"]
+
+    def __init__(self, lm, eos: Optional[int] = None):
+        eos = argcheck.is_int(eos, "eos", True)
+        super().__init__()
+        if eos is not None:
+            if eos < -lm.vocab_size or eos > lm.vocab_size - 1:
+                raise ValueError(
+                    "Expected eos to be in the range [{}, {}], got {}".format(
+                        -lm.vocab_size, lm.vocab_size - 1, eos
+                    )
+                )
+            eos = (eos + lm.vocab_size) % lm.vocab_size
+        self.lm, self.eos = lm, eos
+        try:
+            device = next(iter(lm.parameters())).device
+        except StopIteration:
+            device = torch.device("cpu")
+        self.register_buffer("device_buffer", torch.empty(0, device=device))
+
+    def reset_parameters(self) -> None:
+        if hasattr(self.lm, "reset_parameters"):
+            self.lm.reset_parameters()
+
+    def extra_repr(self) -> str:
+        return "eos={}".format(self.eos)
+
+    def update_log_probs_for_step(self, log_probs_prev, log_probs_t, y_prev, y_prev_lens, eos_mask):
+        """Hook (reference _decoding.py:1393-1436); identity by default."""
+        return log_probs_prev, log_probs_t
+
+    def forward(
+        self,
+        initial_state: Optional[Dict[str, torch.Tensor]] = None,
+        batch_size: Optional[int] = None,
+        max_iters: Optional[int] = None,
+    ):
+        prev = dict() if initial_state is None else initial_state
+        device = self.device_buffer.device
+        N = 1 if batch_size is None else batch_size
+        if max_iters is None:
+            if self.eos is None:
+                raise RuntimeError("max_iters must be set when eos is unset")
+            max_iters = 1073741824
+        elif max_iters < 0:
+            raise RuntimeError("max_iters must be non-negative, got {}".format(max_iters))
+        y = torch.empty((0, N), device=device, dtype=torch.long)
+        prev = self.lm.update_input(prev, y)
+        y_lens = torch.zeros(N, dtype=torch.long, device=device)
+        eos_mask = torch.zeros(N, device=device, dtype=torch.bool)
+        log_probs = torch.zeros(N, device=device)
+        for t in range(max_iters):
+            if bool(eos_mask.all()):
+                break
+            t_ = torch.tensor(t, device=device)
+            lp_t, prev = self.lm.calc_idx_log_probs(y[:t], prev, t_)
+            lp_t = lp_t.log_softmax(-1)
+            log_probs, lp_t = self.update_log_probs_for_step(log_probs, lp_t, y[:t], y_lens, eos_mask)
+            if self.eos is not None:  # ended paths emit eos for free (:1483-1492)
+                lp_t = lp_t.masked_fill(eos_mask.unsqueeze(1), -float("inf"))
+                lp_t[:, self.eos] = lp_t[:, self.eos].masked_fill(eos_mask, 0.0)
+            y, log_probs = random_walk_advance(lp_t, log_probs, y, y_lens)
+            if self.eos is not None:
+                y_lens = y_lens + (~eos_mask).long()
+                eos_mask = y.gather(0, y_lens.unsqueeze(0) - 1).squeeze(0) == self.eos
+            else:
+                y_lens = y_lens + 1
+        if batch_size is None:
+            y, y_lens, log_probs = y.squeeze(1), y_lens.squeeze(0), log_probs.squeeze(0)
+        return y, y_lens, log_probs

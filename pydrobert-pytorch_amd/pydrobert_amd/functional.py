@@ -6,6 +6,7 @@ from ._decoding import (
     ctc_prefix_search,
     ctc_prefix_search_advance,
 )
+from ._decoding import ctc_greedy_search, random_walk_advance, sequence_log_probs
 from ._img import (
     dense_image_warp,
     polyharmonic_spline,
@@ -27,6 +28,9 @@ from ._string import (
 )
 
 __all__ = [
+    "ctc_greedy_search",
+    "random_walk_advance",
+    "sequence_log_probs",
     "hard_optimal_completion_distillation_loss",
     "minimum_error_rate_loss",
     "beam_search_advance",

@@ -3,6 +3,7 @@ operators on the MI355X hot path."""
 
 from ._decoding import BeamSearch, CTCPrefixSearch
 from ._img import DenseImageWarp, PolyharmonicSpline, SparseImageWarp, SpecAugment, Warp1DGrid
+from ._decoding import CTCGreedySearch, RandomWalk, SequenceLogProbabilities
 from ._lm import (
     ExtractableSequentialLanguageModel,
     MixableSequentialLanguageModel,
@@ -20,6 +21,9 @@ from ._string import (
 )
 
 __all__ = [
+    "CTCGreedySearch",
+    "RandomWalk",
+    "SequenceLogProbabilities",
     "HardOptimalCompletionDistillationLoss",
     "MinimumErrorRateLoss",
     "BeamSearch",
