@@ -141,7 +141,6 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   }
   PDT_STAMP(1);
   const int *mt = L.tl_tok + (DENSE ? me : 0) * PDT_WAVE;
-  const float *mp = L.tl_p + (DENSE ? me : 0) * PDT_WAVE;
 
   // ---- candidate masses that do not depend on the token (:777-794) ----------------------
   const float p_blank = __fdiv_rn(p[V], sum);
@@ -215,70 +214,85 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // stream 2: not extending, mass NB + B                        (:842-845)
   const float m1 = bm.b * e_last;
   const float m2 = NB + B;
-  // head of stream 0 (first available list entry of this prefix)
-  int t0 = 0;
-  float m0 = 0.0f;
-  if (valid_beam && avail != 0ull) {
-    const int j = (int)__builtin_ctzll(avail);
-    t0 = mt[j];
-    m0 = tot * mp[j];
-  }
-  int kind;
-  float best;
-  unsigned key;
-  // branch-free choice among the three streams; ties go to the lowest flat candidate index
-  auto choose = [&]() {
-    // bitwise (not short-circuit) logic keeps this straight-line code
-    const bool has0 = valid_beam & (avail != 0ull);
-    const bool take1 = s1_open & ((!has0) | (m1 > m0) | ((m1 == m0) & (lastc < t0)));
-    best = take1 ? m1 : m0;
-    kind = take1 ? 1 : (has0 ? 0 : -1);
-    const bool take2 = s2_open & ((kind < 0) | (m2 > best));
-    best = take2 ? m2 : best;
-    kind = take2 ? 2 : kind;
-    key = kind >= 0 ? fkey(best) : 0u;
+  // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
+  // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
+  // available list entries of stream 0 in order, entry 3R-2 is stream 1, entry 3R-1 stream 2.
+  // A prefix's resident entries are consumed in order (they are sorted), so a round is just
+  // a wave max + clearing the winning slot; only when a prefix uses up ALL its resident
+  // stream-0 entries are its slots refilled with the next 3R-2.
+  const int G = Kp <= 16 ? 16 : 32, R = PDT_WAVE / G;
+  const int kb = lane & (G - 1), rr = lane / G;
+  const int ksrc = kb < Kp ? kb : 0;
+  const bool kvalid = kb < Kp && (__shfl((int)valid_beam, ksrc) != 0);
+  const float tot_k = shfl_f(tot, ksrc);
+  const int lastc_k = __shfl(lastc, ksrc);
+  unsigned key0 = 0u, key1 = 0u, key2 = 0u;
+  int tk0 = 0, tk1 = 0, tk2 = 0;
+  const int n_main = 3 * R - 2;
+  // fills the stream-0 slots of every lane whose prefix is in `mask_k` from that prefix's
+  // current `avail`
+  auto fill_main = [&](bool mine) {
+    u64 av = shfl_u64(avail, ksrc);
+    const int *lt = L.tl_tok + (DENSE ? ksrc : 0) * PDT_WAVE;
+    const float *lp = L.tl_p + (DENSE ? ksrc : 0) * PDT_WAVE;
+    for (int i = 0; i < rr; ++i) av &= av - 1ull;  // skip to entry rr
+#pragma unroll
+    for (int sl = 0; sl < 3; ++sl) {
+      const int e = rr + R * sl;
+      unsigned key = 0u;
+      int tok = 0;
+      if (e < n_main && av != 0ull && kvalid) {
+        const int j = (int)__builtin_ctzll(av);
+        tok = lt[j];
+        key = fkey(tot_k * lp[j]);
+      }
+      if (mine && e < n_main) {
+        if (sl == 0) { key0 = key; tk0 = tok; }
+        if (sl == 1) { key1 = key; tk1 = tok; }
+        if (sl == 2) { key2 = key; tk2 = tok; }
+      }
+      for (int i = 0; i < R; ++i) av &= av - 1ull;  // next entry of this lane: e + R
+    }
   };
-  choose();
+  fill_main(true);
+  {
+    // stream 1 / stream 2 live in slot 2 of rows R-2 / R-1
+    const float m1_k = shfl_f(m1, ksrc), m2_k = shfl_f(m2, ksrc);
+    const bool o1 = __shfl((int)s1_open, ksrc) != 0, o2 = __shfl((int)s2_open, ksrc) != 0;
+    if (rr == R - 2) { key2 = (kvalid && o1) ? fkey(m1_k) : 0u; tk2 = lastc_k; }
+    if (rr == R - 1) { key2 = (kvalid && o2) ? fkey(m2_k) : 0u; tk2 = lastc_k; }
+  }
 
   new_src = 0, new_tok = 0, new_kind = -1;
   float new_mass = -PDT_INF;
   for (int i = 0; i < K; ++i) {
-    const unsigned mx = Kp <= 16 ? row0_max_u32(key) : wave_max_u32(key);
+    const unsigned lk = max(max(key0, key1), key2);
+    const unsigned mx = wave_max_u32(lk);
     if (mx == 0u) break;  // fewer valid candidates than K: the rest stay invalid (:902-924)
-    const int win = (int)__builtin_ctzll(__ballot(key == mx));
-    const int wkind = __builtin_amdgcn_readlane(kind, win);
-    const int wtok = __builtin_amdgcn_readlane(kind == 0 ? t0 : lastc, win);
-    const int wmass = __builtin_amdgcn_readlane(__float_as_int(best), win);
+    const int win = (int)__builtin_ctzll(__ballot(lk == mx));
+    const int sw_l = key0 == mx ? 0 : (key1 == mx ? 1 : 2);
+    const int tw_l = key0 == mx ? tk0 : (key1 == mx ? tk1 : tk2);
+    const int sw = __builtin_amdgcn_readlane(sw_l, win);
+    const int wtok = __builtin_amdgcn_readlane(tw_l, win);
+    const int wbeam = win & (G - 1);
+    const int e = (win / G) + R * sw;
+    const int wkind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
     const bool rec = lane == i;
-    new_src = rec ? win : new_src;
+    new_src = rec ? wbeam : new_src;
     new_tok = rec ? wtok : new_tok;
     new_kind = rec ? wkind : new_kind;
-    new_mass = rec ? __int_as_float(wmass) : new_mass;
-    // advance the winner's stream: computed wave-uniformly, applied by the winner lane only
-    u64 av = readlane_u64(avail, win);
-    int nt0 = 0;
-    float np0 = 0.0f;
-    if (wkind == 0) {
-      av &= av - 1ull;
-      if (av != 0ull) {
-        const int j = (int)__builtin_ctzll(av);
-        if (DENSE) {
-          nt0 = L.tl_tok[win * PDT_WAVE + j];
-          np0 = L.tl_p[win * PDT_WAVE + j];
-        } else {
-          nt0 = __builtin_amdgcn_readlane(list_tok, j);
-          np0 = readlane_f(list_p, j);
-        }
-      }
-    }
+    new_mass = rec ? fkey_inv(mx) : new_mass;
     const bool me_win = lane == win;
-    avail = me_win ? av : avail;
-    const bool adv0 = me_win & (wkind == 0);
-    t0 = adv0 ? nt0 : t0;
-    m0 = adv0 ? tot * np0 : m0;
-    s1_open = s1_open & !(me_win & (wkind == 1));
-    s2_open = s2_open & !(me_win & (wkind == 2));
-    choose();
+    key0 = (me_win & (sw == 0)) ? 0u : key0;
+    key1 = (me_win & (sw == 1)) ? 0u : key1;
+    key2 = (me_win & (sw == 2)) ? 0u : key2;
+    if (e == n_main - 1) {
+      // the prefix has used all its resident stream-0 entries: drop them from `avail` and
+      // bring in the next ones (rare: one prefix taking more than 3R-2 of the K winners)
+      if (lane == wbeam)
+        for (int q = 0; q < n_main; ++q) avail &= avail - 1ull;
+      fill_main(kb == wbeam);
+    }
   }
   PDT_STAMP(3);
   if (!DENSE) {
