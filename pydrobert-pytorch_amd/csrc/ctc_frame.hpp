@@ -91,6 +91,27 @@ struct FrameLds {
   }
 };
 
+// Number of list entries a frame needs: K + K' (at most K wins + K'-1 merged-away tokens + the
+// prefix's own last token per stream), see ctc_search.hip.
+__device__ __forceinline__ int ctc_list_len(int V, int W, int Kp) {
+  const int K = min(W, Kp * (V + 1));
+  return min(V, K + Kp);
+}
+
+// Shared sorted token list of one frame from the unnormalised row p[0..V) (sum = normaliser):
+// tl_tok / tl_p (normalised) / pos (inverse index; entries of the previous list must be 0xFF).
+__device__ __forceinline__ void build_shared_list(const float *p, float sum, int V, int M, u64 *surv,
+                                                  int *tl_tok, float *tl_p, unsigned char *pos) {
+  const int lane = lane_id();
+  const u64 tk = wave_top_sorted(p, V, M, surv);
+  if (lane < M) {
+    const int tok = (int)idx_of(tk);
+    tl_tok[lane] = tok;
+    tl_p[lane] = __fdiv_rn(p[tok], sum);
+    pos[tok] = (unsigned char)lane;
+  }
+}
+
 // One frame of the search.  `p` holds the (unnormalised) non-extension probabilities of
 // v in [0, V] (index V = blank) and `sum` their normaliser (1 when already normalised).
 // Kp = number of live lanes (1 at t = 0, then W).
@@ -118,18 +139,9 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   PDT_STAMP_BEGIN;
 
   // ---- sorted token list(s): tokens by descending extension probability ----------------
-  int list_tok = 0;      // shared list, entry `lane` (registers; also mirrored in LDS)
-  float list_p = 0.0f;
-  if (!DENSE) {
-    const u64 tk = wave_top_sorted(p, V, M, L.surv);
-    if (lane < M) {
-      list_tok = (int)idx_of(tk);
-      list_p = __fdiv_rn(p[list_tok], sum);
-      L.tl_tok[lane] = list_tok;
-      L.tl_p[lane] = list_p;
-      L.pos[list_tok] = (unsigned char)lane;
-    }
-  } else {
+  // shared form: L.tl_tok / L.tl_p / L.pos were filled by build_shared_list (possibly by
+  // another wave); dense form: one list per prefix, built here
+  if (DENSE) {
     for (int k = 0; k < Kp; ++k) {
       const u64 tk = wave_top_sorted_strided(dc.ext + k * dc.ext_sk, dc.ext_sv, V, M, L.surv);
       if (lane < M) {
@@ -295,11 +307,6 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     }
   }
   PDT_STAMP(3);
-  if (!DENSE) {
-    wave_sync();
-    if (lane < M) L.pos[L.tl_tok[lane]] = 0xFF;  // leave the inverse index clean
-  }
-
   // ---- new beam state of lane i (:868-880) ---------------------------------------------
   const int srcl = new_kind >= 0 ? new_src : lane;
   const float NB_s = shfl_f(NB, srcl), B_s = shfl_f(B, srcl);

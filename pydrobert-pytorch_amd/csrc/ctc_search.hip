@@ -23,20 +23,145 @@
 
 namespace pdt {
 
-__global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
+// LDS ring slot shared by the producer and consumer waves of one utterance.
+struct RingLayout {
+  int row_floats;   // V + 1 padded to 4
+  int pos_bytes;    // V padded to 16
+  int slot_bytes;
+  int nstage;
+  int utt_bytes;    // ring + consumer scratch + producer scratch + flags
+  int utt_per_wg;
+};
+
+__host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int utt_per_wg) {
+  RingLayout r;
+  r.row_floats = (V + 1 + 3) & ~3;
+  r.pos_bytes = (V + 15) & ~15;
+  r.slot_bytes = r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
+  r.nstage = nstage;
+  const int consumer = (W > 0 ? W : 1) * 4 * 3 + 2 * W * W * 4;  // chm + info + nxt tables
+  r.utt_bytes = (r.slot_bytes * nstage + consumer + PDT_SURV_CAP * 8 + 16 + 15) & ~15;
+  r.utt_per_wg = utt_per_wg;
+  return r;
+}
+
+// Workgroup = utt_per_wg x (producer wave, consumer wave).  The producer streams the logits:
+// softmax statistics + sorted top-M token list of frame t go into ring slot t % nstage while
+// the consumer runs the (sequential) beam update of earlier frames -- the two dependency
+// chains overlap instead of adding up.  Hand-off through two LDS counters per utterance
+// (workgroup-scope release / acquire; both waves run exactly Tn iterations).
+__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80)))
+ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
-  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * a.waves_per_wg + wave;
-  if (n >= a.N) return;
+  const int u = wave >> 1;
+  const bool producer = (wave & 1) == 0;
+  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
+  if (u >= rl.utt_per_wg || n >= a.N) return;
   const int V = a.V, W = a.W;
-  unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
-  float *p = reinterpret_cast<float *>(base);
-  FrameLds L;
-  L.carve(base + (size_t)((V + 1 + 3) & ~3) * 4, V, W, W, false);
-  for (int v = lane; v < V; v += PDT_WAVE) L.pos[v] = 0xFF;
-
+  unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
+  unsigned char *ring = ub;
+  unsigned char *cs = ub + (size_t)rl.slot_bytes * rl.nstage;      // consumer scratch
+  u64 *surv = reinterpret_cast<u64 *>(cs + (W * 4 * 3 + 2 * W * W * 4));
+  int *flags = reinterpret_cast<int *>(surv + PDT_SURV_CAP);        // [0] produced, [1] consumed
+  auto slot_row = [&](int sl) { return reinterpret_cast<float *>(ring + (size_t)sl * rl.slot_bytes); };
+  auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(slot_row(sl) + rl.row_floats); };
+  auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
+  auto slot_pos = [&](int sl) { return reinterpret_cast<unsigned char *>(slot_p(sl) + PDT_WAVE); };
+  auto slot_hdr = [&](int sl) { return reinterpret_cast<float *>(slot_pos(sl) + rl.pos_bytes); };
   const int Tn = a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T;
+  const int NS = rl.nstage;
+
+  if (producer) {
+    for (int sl = 0; sl < NS; ++sl)
+      for (int v = lane; v < rl.pos_bytes; v += PDT_WAVE) slot_pos(sl)[v] = 0xFF;
+    if (lane == 0) {
+      __hip_atomic_store(&flags[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_store(&flags[0], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+  }
+  __syncthreads();  // flags / pos tables initialised (the only workgroup barrier)
+
+  if (producer) {
+    constexpr int kPrefetch = 8;
+    float pre[kPrefetch];
+    if (Tn > 0) {
+      const float *row0 = a.logits + n * a.lg_sn;
+#pragma unroll
+      for (int i = 0; i < kPrefetch; ++i) {
+        const int v = lane + i * PDT_WAVE;
+        pre[i] = v <= V ? row0[(int64_t)v * a.lg_sv] : 0.0f;
+      }
+    }
+    for (int t = 0; t < Tn; ++t) {
+      const int sl = t % NS;
+      // wait for the slot to be free: at most NS frames in flight
+      while (t - __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
+        __builtin_amdgcn_s_sleep(2);
+      float *p = slot_row(sl);
+      int *tl_tok = slot_tok(sl);
+      unsigned char *pos = slot_pos(sl);
+      float *hdr = slot_hdr(sl);
+      // un-index the list this slot held NS frames ago
+      if (t >= NS) {
+        const int Mprev = __float_as_int(hdr[2]);
+        if (lane < Mprev) pos[tl_tok[lane]] = 0xFF;
+      }
+      // softmax statistics of frame t (:1093): p[v] = exp(x[v] - max), sum over v in [0, V]
+      float mx = -PDT_INF;
+#pragma unroll
+      for (int i = 0; i < kPrefetch; ++i) {
+        const int v = lane + i * PDT_WAVE;
+        if (v <= V) {
+          p[v] = pre[i];
+          mx = fmaxf(mx, pre[i]);
+        }
+      }
+      {
+        const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+        for (int v = lane + kPrefetch * PDT_WAVE; v <= V; v += PDT_WAVE) {
+          const float x = row[(int64_t)v * a.lg_sv];
+          p[v] = x;
+          mx = fmaxf(mx, x);
+        }
+      }
+      if (t + 1 < Tn) {
+        const float *nrow = a.logits + (int64_t)(t + 1) * a.lg_st + n * a.lg_sn;
+#pragma unroll
+        for (int i = 0; i < kPrefetch; ++i) {
+          const int v = lane + i * PDT_WAVE;
+          if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
+        }
+      }
+      mx = wave_max_f(mx);
+      float s = 0.0f;
+      for (int v = lane; v <= V; v += PDT_WAVE) {
+        const float e = expf(p[v] - mx);
+        p[v] = e;
+        s += e;
+      }
+      s = wave_sum_f(s);
+      wave_sync();
+      const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
+      build_shared_list(p, s, V, M, surv, tl_tok, slot_p(sl), pos);
+      if (lane == 0) {
+        hdr[0] = s;
+        hdr[2] = __int_as_float(M);
+      }
+      wave_sync();
+      if (lane == 0) __hip_atomic_store(&flags[0], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+
+  // ---- consumer: the sequential beam update ----------------------------------------------
+  FrameLds L;
+  L.surv = surv;  // unused by the shared-list form
+  L.chm = reinterpret_cast<unsigned *>(cs);
+  L.info = reinterpret_cast<int *>(L.chm + W);
+  L.nxt_old = L.info + 2 * W;
+  L.nxt_new = L.nxt_old + W * W;
   Beam bm;  // :1097-1105: one empty prefix with all the mass on "ends in blank"
   bm.nb = lane == 0 ? 0.0f : -PDT_INF;
   bm.b = lane == 0 ? 1.0f : -PDT_INF;
@@ -45,64 +170,26 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
   bm.node = -1;
   bm.isp = lane == 0 ? 1ull : 0ull;
   int Kp = 1;
-  constexpr int kPrefetch = 8;
-  float pre[kPrefetch];
-  if (Tn > 0) {
-    const float *row0 = a.logits + n * a.lg_sn;
-#pragma unroll
-    for (int i = 0; i < kPrefetch; ++i) {
-      const int v = lane + i * PDT_WAVE;
-      pre[i] = v <= V ? row0[(int64_t)v * a.lg_sv] : 0.0f;
-    }
-  }
 #ifdef PDT_STAMPS
   unsigned long long pdt_stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
   for (int t = 0; t < Tn; ++t) {
     PDT_STAMP_BEGIN;
-    // softmax statistics of frame t (:1093) -- p[v] = exp(x[v] - max), sum over v in [0, V].
-    // The first kPrefetch*64 logits of the frame were fetched into registers one frame ago.
-    float mx = -PDT_INF;
-#pragma unroll
-    for (int i = 0; i < kPrefetch; ++i) {
-      const int v = lane + i * PDT_WAVE;
-      if (v <= V) {
-        p[v] = pre[i];
-        mx = fmaxf(mx, pre[i]);
-      }
-    }
-    {
-      const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
-      for (int v = lane + kPrefetch * PDT_WAVE; v <= V; v += PDT_WAVE) {
-        const float x = row[(int64_t)v * a.lg_sv];
-        p[v] = x;
-        mx = fmaxf(mx, x);
-      }
-    }
-    if (t + 1 < Tn) {
-      const float *nrow = a.logits + (int64_t)(t + 1) * a.lg_st + n * a.lg_sn;
-#pragma unroll
-      for (int i = 0; i < kPrefetch; ++i) {
-        const int v = lane + i * PDT_WAVE;
-        if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
-      }
-    }
-    mx = wave_max_f(mx);
-    float s = 0.0f;
-    for (int v = lane; v <= V; v += PDT_WAVE) {
-      const float e = expf(p[v] - mx);
-      p[v] = e;
-      s += e;
-    }
-    s = wave_sum_f(s);
-    wave_sync();
+    const int sl = t % NS;
+    while (__hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t)
+      __builtin_amdgcn_s_sleep(2);
     PDT_STAMP(0);
+    L.tl_tok = slot_tok(sl);
+    L.tl_p = slot_p(sl);
+    L.pos = slot_pos(sl);
+    const float s = slot_hdr(sl)[0];
     int ns, nt, nk;
-    ctc_frame<false>(bm, p, s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+    ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
     int *tmp = L.nxt_old;
     L.nxt_old = L.nxt_new;
     L.nxt_new = tmp;
     Kp = W;
+    if (lane == 0) __hip_atomic_store(&flags[1], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 
 #ifdef PDT_STAMPS
@@ -133,27 +220,25 @@ __global__ void __launch_bounds__(256) ctc_search_kernel(const CtcArgs a) {
 #endif
 }
 
-size_t ctc_lds_per_wave(int V, int W) {
-  return (size_t)((V + 1 + 3) & ~3) * 4 + FrameLds::bytes(V, W, W, false);
-}
-
 int launch_ctc_search(CtcArgs a, hipStream_t stream) {
   if (a.W < 1 || a.W > kMaxWidth) return PDT_E_TOO_LONG;
-  const size_t per_wave = ctc_lds_per_wave(a.V, a.W);
+  // ring depth and utterances per workgroup from the LDS budget
+  int nstage = 4, upw = 2;
+  RingLayout rl = ring_layout(a.V, a.W, nstage, upw);
   const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
-  if (per_wave > hard_cap) return PDT_E_TOO_LONG;
-  int wpw = (int)(soft_cap / per_wave);
-  wpw = wpw > 4 ? 4 : (wpw < 1 ? 1 : wpw);
-  a.waves_per_wg = wpw;
-  a.lds_per_wave = (int)per_wave;
-  const size_t smem = per_wave * wpw;
+  while ((size_t)rl.utt_bytes * upw > soft_cap && (upw > 1 || nstage > 2)) {
+    if (upw > 1) upw = 1; else nstage = 2;
+    rl = ring_layout(a.V, a.W, nstage, upw);
+  }
+  const size_t smem = (size_t)rl.utt_bytes * upw;
+  if (smem > hard_cap) return PDT_E_TOO_LONG;
   if (smem > soft_cap) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned grid = (unsigned)((a.N + wpw - 1) / wpw);
-  hipLaunchKernelGGL(ctc_search_kernel, dim3(grid), dim3(64 * wpw), smem, stream, a);
+  const unsigned grid = (unsigned)((a.N + upw - 1) / upw);
+  hipLaunchKernelGGL(ctc_search_kernel, dim3(grid), dim3(128 * upw), smem, stream, a, rl);
   return (int)hipGetLastError();
 }
 
