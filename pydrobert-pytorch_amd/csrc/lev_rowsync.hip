@@ -373,21 +373,27 @@ int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream) {
 }
 
 // ---- phase 2: class bitmasks -> padded ascending token lists (_string.py:509-514) --------
+// One workgroup per utterance: the class-token table is staged once in LDS, the four waves take
+// rows h = wave, wave + 4, ... and keep the next row's bitmask word in flight while the current
+// row is expanded and written (C * 8 contiguous bytes per row).
 __global__ void __launch_bounds__(256)
 oc_expand_kernel(const uint32_t *__restrict__ bitmask, const int64_t *__restrict__ class_tokens,
                  int R, int W, int Hout, int64_t N, int C, int64_t padding,
-                 int64_t *__restrict__ targets, int64_t tgt_sh, int64_t tgt_sn, int lds_per_wave) {
+                 int64_t *__restrict__ targets, int64_t tgt_sh, int64_t tgt_sn) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
-  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  if (n >= N) return;
-  int64_t *ctok = reinterpret_cast<int64_t *>(smem + (size_t)wave * lds_per_wave);
-  int64_t *stage = ctok + R;
-  for (int k = lane; k < R; k += PDT_WAVE) ctok[k] = class_tokens[n * (int64_t)R + k];
-  wave_sync();
-  for (int h = 0; h < Hout; ++h) {
-    unsigned w = lane < W ? bitmask[((int64_t)h * N + n) * W + lane] : 0u;
+  const int64_t n = xcd_remap(blockIdx.x, gridDim.x);
+  int64_t *ctok = reinterpret_cast<int64_t *>(smem);
+  int64_t *stage = ctok + R + (size_t)wave * W * 32;
+  for (int k = (int)threadIdx.x; k < R; k += 256) ctok[k] = class_tokens[n * (int64_t)R + k];
+  __syncthreads();
+  const bool wide = (C & 1) == 0 && ((tgt_sh | tgt_sn) & 1) == 0 &&
+                    (reinterpret_cast<uintptr_t>(targets) & 15) == 0;
+  unsigned w_next = (wave < Hout && lane < W) ? bitmask[((int64_t)wave * N + n) * W + lane] : 0u;
+  for (int h = wave; h < Hout; h += 4) {
+    unsigned w = w_next;
+    if (h + 4 < Hout && lane < W) w_next = bitmask[((int64_t)(h + 4) * N + n) * W + lane];
     const int cnt = __popc(w);
     const int incl = wave_incl_scan_add(cnt);
     const int total = __builtin_amdgcn_readlane(incl, PDT_WAVE - 1);
@@ -399,7 +405,16 @@ oc_expand_kernel(const uint32_t *__restrict__ bitmask, const int64_t *__restrict
     }
     wave_sync();
     int64_t *dst = targets + (int64_t)h * tgt_sh + n * tgt_sn;
-    for (int i = lane; i < C; i += PDT_WAVE) dst[i] = i < total ? stage[i] : padding;
+    if (wide) {  // 16-byte stores: two targets per lane
+      for (int i = lane; i < (C >> 1); i += PDT_WAVE) {
+        longlong2 v;
+        v.x = 2 * i < total ? stage[2 * i] : padding;
+        v.y = 2 * i + 1 < total ? stage[2 * i + 1] : padding;
+        *reinterpret_cast<longlong2 *>(dst + 2 * i) = v;
+      }
+    } else {
+      for (int i = lane; i < C; i += PDT_WAVE) dst[i] = i < total ? stage[i] : padding;
+    }
     wave_sync();
   }
 }
@@ -409,17 +424,15 @@ int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R
                      int64_t tgt_sn, hipStream_t stream) {
   const int W = (int)pdt_oc_mask_words(R);
   if (W > PDT_WAVE) return PDT_E_TOO_LONG;
-  const size_t per_wave = (((size_t)R + (size_t)W * 32) * 8 + 15) & ~(size_t)15;
-  const size_t smem = per_wave * 4;
+  const size_t smem = (((size_t)R + (size_t)4 * W * 32) * 8 + 15) & ~(size_t)15;
   if (smem > 160 * 1024) return PDT_E_TOO_LONG;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(oc_expand_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned grid = (unsigned)((N + 3) / 4);
-  hipLaunchKernelGGL(oc_expand_kernel, dim3(grid), dim3(256), smem, stream, bitmask, class_tokens,
-                     R, W, Hout, N, C, padding, targets, tgt_sh, tgt_sn, (int)per_wave);
+  hipLaunchKernelGGL(oc_expand_kernel, dim3((unsigned)N), dim3(256), smem, stream, bitmask,
+                     class_tokens, R, W, Hout, N, C, padding, targets, tgt_sh, tgt_sn);
   return (int)hipGetLastError();
 }
 
