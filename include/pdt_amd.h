@@ -219,6 +219,11 @@ int pdt_sequence_log_probs_backward(const float *logits, const int64_t *hyp, int
  *   (values_are_grid = 1, the include_flow=False form).  flow_out (N,H,W,2) optional
  *   (flow form only), stored (h, w)-ordered when flow_out_is_hw.
  *   workspace: pdt_spline_workspace_bytes(N, M, 2, 2) bytes.
+ * pdt_*_backward: adjoints of the three resampling operators with respect to the features /
+ *   image (what autograd derives through grid_sample in the reference, _img.py:436, :1203):
+ *   grad_out has the forward output's shape, contiguous; grad_feats / grad_image (contiguous)
+ *   is overwritten.  The sampling arguments are the forward call's.  Accumulation uses the
+ *   hardware float atomic, so sums are not bit-reproducible from run to run.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_spline_workspace_bytes(int64_t N, int64_t T, int64_t I, int64_t O);
 
@@ -245,6 +250,22 @@ int pdt_sparse_image_warp(const float *image, const float *train_points,
                           int64_t M, int order, float regularization_weight, int values_are_grid,
                           int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
                           void *workspace, void *stream);
+
+int pdt_spec_augment_apply_backward(const float *grad_out, int64_t N, int64_t T, int64_t F,
+                                    const float *time_grid, const float *freq_grid,
+                                    const int64_t *t_0, const int64_t *t_len, int64_t MT,
+                                    const int64_t *f_0, const int64_t *f_len, int64_t MF,
+                                    float *grad_feats, void *stream);
+
+int pdt_dense_image_warp_backward(const float *grad_out, const float *flow, int64_t N, int64_t C,
+                                  int64_t H, int64_t W, int flow_is_hw, int mode, int padding,
+                                  float *grad_image, void *stream);
+
+int pdt_sparse_image_warp_backward(const float *grad_out, const float *train_points,
+                                   const float *train_values, int64_t N, int64_t C, int64_t H,
+                                   int64_t W, int64_t M, int order, float regularization_weight,
+                                   int values_are_grid, int mode, int padding, float *grad_image,
+                                   void *workspace, void *stream);
 
 #ifdef __cplusplus
 }

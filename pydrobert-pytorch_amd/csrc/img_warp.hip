@@ -356,6 +356,50 @@ __global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArg
   }
 }
 
+// Adjoint of the two kernels above with respect to the features: every unmasked output element
+// scatters its gradient to its (up to) four taps.  grad_feats is zeroed by the caller; the
+// accumulation uses the hardware float atomic (order of addition is not fixed, like
+// grid_sample's own backward).
+__global__ void __launch_bounds__(256)
+spec_augment_backward_kernel(const SpecAugArgs a, const float *__restrict__ grad_out,
+                             float *__restrict__ grad_feats, int tiles) {
+  const int64_t n = blockIdx.x / tiles;
+  const int tile = (int)(blockIdx.x % tiles);
+  const int T = a.T, F = a.F;
+  const int rows_per_tile = (T + tiles - 1) / tiles;
+  const int t_begin = tile * rows_per_tile, t_end = min(T, t_begin + rows_per_tile);
+  float *gn = grad_feats + n * (int64_t)T * F;
+  for (int idx = t_begin * F + (int)threadIdx.x; idx < t_end * F; idx += 256) {
+    const int t = idx / F, f = idx - t * F;
+    bool masked = false;
+    for (int m = 0; m < a.MT; ++m) {
+      const int64_t s = a.t0[n * a.MT + m];
+      masked = masked || (t >= s && t < s + a.tl[n * a.MT + m]);
+    }
+    for (int m = 0; m < a.MF; ++m) {
+      const int64_t s = a.f0[n * a.MF + m];
+      masked = masked || (f >= s && f < s + a.fl[n * a.MF + m]);
+    }
+    if (masked) continue;
+    const float g = grad_out[(n * T + t) * (int64_t)F + f];
+    if (!a.tgrid && !a.fgrid) {
+      gn[(int64_t)t * F + f] = g;  // one-to-one: no other writer
+      continue;
+    }
+    const float gy = a.tgrid ? a.tgrid[n * T + t] : (2.0f * (float)t + 1.0f) / (float)T - 1.0f;
+    const float gx = a.fgrid ? a.fgrid[n * F + f] : (2.0f * (float)f + 1.0f) / (float)F - 1.0f;
+    const float iy = clip_coord(unnormalize(gy, T), T), ix = clip_coord(unnormalize(gx, F), F);
+    const float y0f = floorf(iy), x0f = floorf(ix);
+    const int y0 = (int)y0f, x0 = (int)x0f, y1 = y0 + 1, x1 = x0 + 1;
+    const float wy1 = iy - y0f, wx1 = ix - x0f, wy0 = (y0f + 1.0f) - iy, wx0 = (x0f + 1.0f) - ix;
+    float *r0 = gn + (int64_t)y0 * F, *r1 = gn + (int64_t)min(y1, T - 1) * F;
+    unsafeAtomicAdd(r0 + x0, g * (wx0 * wy0));
+    if (x1 < F && wx1 != 0.0f) unsafeAtomicAdd(r0 + x1, g * (wx1 * wy0));
+    if (y1 < T && wy1 != 0.0f) unsafeAtomicAdd(r1 + x0, g * (wx0 * wy1));
+    if (x1 < F && y1 < T && wx1 != 0.0f && wy1 != 0.0f) unsafeAtomicAdd(r1 + x1, g * (wx1 * wy1));
+  }
+}
+
 struct WarpArgs {
   const float *image;  // (N,C,H,W) contiguous
   float *out;          // (N,C,H,W)
@@ -369,8 +413,12 @@ struct WarpArgs {
   int M, order, as_grid;  // as_grid: the spline yields the normalised grid itself (no-flow form)
   float *flow_out;     // sparse, optional (N,H,W,2)
   int flow_out_flip;
+  float *grad_image;   // BACKWARD: (N,C,H,W), zeroed by the caller; `out` then holds grad_out
 };
 
+// BACKWARD = adjoint with respect to the image: the same sampling positions, each pixel scatters
+// its gradient to its taps with the hardware float atomic.
+template <bool BACKWARD>
 __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   float *lk = reinterpret_cast<float *>(smem);  // knots (M,2) then weights (M+3,2)
@@ -400,7 +448,7 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
       gx = sx;
       gy = sy;
     } else {
-      if (a.flow_out) {
+      if (!BACKWARD && a.flow_out) {
         float *fo = a.flow_out + ((n * H + h) * (int64_t)W + w) * 2;
         fo[0] = a.flow_out_flip ? sy : sx;
         fo[1] = a.flow_out_flip ? sx : sy;
@@ -418,9 +466,15 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
   const int64_t plane = (int64_t)H * W;
   const float *img = a.image + n * a.C * plane;
   float *o = a.out + n * a.C * plane + pix;
+  float *gi = a.grad_image + n * a.C * plane;
   if (a.mode == INTERP_NEAREST) {
     const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
     const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
+    if (BACKWARD) {
+      if (ok)
+        for (int c = 0; c < a.C; ++c) unsafeAtomicAdd(gi + c * plane + (int64_t)yn * W + xn, o[c * plane]);
+      return;
+    }
     for (int c = 0; c < a.C; ++c) o[c * plane] = ok ? img[c * plane + (int64_t)yn * W + xn] : 0.0f;
     return;
   }
@@ -429,6 +483,17 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
   const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
   const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
   const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+  if (BACKWARD) {
+    for (int c = 0; c < a.C; ++c) {
+      float *pl = gi + c * plane;
+      const float g = o[c * plane];
+      if (vx0 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x0, g * (wx0 * wy0));
+      if (vx1 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x1, g * (wx1 * wy0));
+      if (vx0 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x0, g * (wx0 * wy1));
+      if (vx1 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x1, g * (wx1 * wy1));
+    }
+    return;
+  }
   for (int c = 0; c < a.C; ++c) {
     const float *pl = img + c * plane;
     float v = 0.0f;
@@ -534,34 +599,81 @@ int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, 
   return (int)hipGetLastError();
 }
 
-int pdt_dense_image_warp(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
-                         int64_t W, int flow_is_hw, int mode, int padding, float *out,
-                         void *stream) {
+int pdt_spec_augment_apply_backward(const float *grad_out, int64_t N, int64_t T, int64_t F,
+                                    const float *time_grid, const float *freq_grid,
+                                    const int64_t *t_0, const int64_t *t_len, int64_t MT,
+                                    const int64_t *f_0, const int64_t *f_len, int64_t MF,
+                                    float *grad_feats, void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 0 || F < 0 || MT < 0 || MF < 0) return PDT_E_ARG;
+  if (N == 0 || T == 0 || F == 0) return PDT_OK;
+  if (!grad_out || !grad_feats || (MT > 0 && (!t_0 || !t_len)) || (MF > 0 && (!f_0 || !f_len)))
+    return PDT_E_ARG;
+  if (T * F >= (1ll << 31)) return PDT_E_TOO_LONG;
+  SpecAugArgs a{};
+  a.tgrid = time_grid; a.fgrid = freq_grid;
+  a.t0 = t_0; a.tl = t_len; a.f0 = f_0; a.fl = f_len;
+  a.N = (int)N; a.T = (int)T; a.F = (int)F; a.MT = (int)MT; a.MF = (int)MF;
+  hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)(N * T * F) * sizeof(float), (hipStream_t)stream);
+  if (e != hipSuccess) return (int)e;
+  int tiles = (int)((T * F + 16383) / 16384);
+  if (tiles < 1) tiles = 1;
+  hipLaunchKernelGGL(spec_augment_backward_kernel, dim3((unsigned)(N * tiles)), dim3(256), 0,
+                     (hipStream_t)stream, a, grad_out, grad_feats, tiles);
+  return (int)hipGetLastError();
+}
+
+static int dense_warp_launch(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                             int64_t W, int flow_is_hw, int mode, int padding, float *out,
+                             float *grad_image, void *stream) {
   using namespace pdt;
   if (N < 0 || C < 0 || H < 0 || W < 0 || mode < 0 || mode > 1 || padding < 0 || padding > 2)
     return PDT_E_ARG;
   if (N == 0 || C == 0 || H == 0 || W == 0) return PDT_OK;
-  if (!image || !flow || !out) return PDT_E_ARG;
+  if ((!image && !grad_image) || !flow || !out) return PDT_E_ARG;
   if (H * W >= (1ll << 31) || N > 65535) return PDT_E_TOO_LONG;
   WarpArgs a{};
   a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
   a.mode = mode; a.padding = padding; a.flow = flow; a.flip = flow_is_hw;
-  hipLaunchKernelGGL(image_warp_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N),
-                     dim3(256), 0, (hipStream_t)stream, a);
+  a.grad_image = grad_image;
+  const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)N);
+  if (grad_image) {
+    hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(float),
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(image_warp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
 }
 
-int pdt_sparse_image_warp(const float *image, const float *train_points,
-                          const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
-                          int64_t M, int order, float regularization_weight, int values_are_grid,
-                          int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
-                          void *workspace, void *stream) {
+int pdt_dense_image_warp(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                         int64_t W, int flow_is_hw, int mode, int padding, float *out,
+                         void *stream) {
+  return dense_warp_launch(image, flow, N, C, H, W, flow_is_hw, mode, padding, out, nullptr, stream);
+}
+
+int pdt_dense_image_warp_backward(const float *grad_out, const float *flow, int64_t N, int64_t C,
+                                  int64_t H, int64_t W, int flow_is_hw, int mode, int padding,
+                                  float *grad_image, void *stream) {
+  if (!grad_image && N && C && H && W) return PDT_E_ARG;
+  return dense_warp_launch(nullptr, flow, N, C, H, W, flow_is_hw, mode, padding,
+                           const_cast<float *>(grad_out), grad_image, stream);
+}
+
+static int sparse_warp_launch(const float *image, const float *train_points,
+                              const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
+                              int64_t M, int order, float regularization_weight, int values_are_grid,
+                              int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
+                              float *grad_image, void *workspace, void *stream) {
   using namespace pdt;
   if (N < 0 || C < 0 || H < 0 || W < 0 || M < 1 || order < 1 || mode < 0 || mode > 1 ||
       padding < 0 || padding > 2)
     return PDT_E_ARG;
   if (N == 0 || C == 0 || H == 0 || W == 0) return PDT_OK;
-  if (!image || !train_points || !train_values || !out || !workspace) return PDT_E_ARG;
+  if ((!image && !grad_image) || !train_points || !train_values || !out || !workspace)
+    return PDT_E_ARG;
   if (H * W >= (1ll << 31) || N > 65535) return PDT_E_TOO_LONG;
   double *wv = reinterpret_cast<double *>(workspace);
   int rc = spline_solve(train_points, train_values, N, M, 2, 2, order, regularization_weight, wv,
@@ -576,10 +688,39 @@ int pdt_sparse_image_warp(const float *image, const float *train_points,
   a.mode = mode; a.padding = padding;
   a.knots = train_points; a.wv = wvf; a.M = (int)M; a.order = order; a.as_grid = values_are_grid;
   a.flow_out = flow_out; a.flow_out_flip = flow_out_is_hw;
+  a.grad_image = grad_image;
   const size_t smem = (size_t)(2 * M + 2 * (M + 3)) * sizeof(float);
-  hipLaunchKernelGGL(image_warp_kernel, dim3((unsigned)((H * W + 255) / 256), (unsigned)N),
-                     dim3(256), smem, (hipStream_t)stream, a);
+  const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)N);
+  if (grad_image) {
+    hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(float),
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  } else {
+    hipLaunchKernelGGL(image_warp_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  }
   return (int)hipGetLastError();
+}
+
+int pdt_sparse_image_warp(const float *image, const float *train_points,
+                          const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
+                          int64_t M, int order, float regularization_weight, int values_are_grid,
+                          int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
+                          void *workspace, void *stream) {
+  return sparse_warp_launch(image, train_points, train_values, N, C, H, W, M, order,
+                            regularization_weight, values_are_grid, mode, padding, out, flow_out,
+                            flow_out_is_hw, nullptr, workspace, stream);
+}
+
+int pdt_sparse_image_warp_backward(const float *grad_out, const float *train_points,
+                                   const float *train_values, int64_t N, int64_t C, int64_t H,
+                                   int64_t W, int64_t M, int order, float regularization_weight,
+                                   int values_are_grid, int mode, int padding, float *grad_image,
+                                   void *workspace, void *stream) {
+  if (!grad_image && N && C && H && W) return PDT_E_ARG;
+  return sparse_warp_launch(nullptr, train_points, train_values, N, C, H, W, M, order,
+                            regularization_weight, values_are_grid, mode, padding,
+                            const_cast<float *>(grad_out), nullptr, 0, grad_image, workspace, stream);
 }
 
 }  // extern "C"

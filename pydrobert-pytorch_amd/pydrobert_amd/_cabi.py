@@ -78,6 +78,18 @@ SIGNATURES = {
         _INT,
         [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _INT, _P, _P],
     ),
+    "pdt_spec_augment_apply_backward": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P],
+    ),
+    "pdt_dense_image_warp_backward": (
+        _INT,
+        [_P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P, _P],
+    ),
+    "pdt_sparse_image_warp_backward": (
+        _INT,
+        [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _P],
+    ),
     "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_ctc_prefix_search": (
         _INT,

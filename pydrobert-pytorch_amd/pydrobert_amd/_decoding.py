@@ -8,9 +8,10 @@ Host-side mirror of the reference's ``_decoding.py`` for the operators on the ho
 user-supplied language model.
 """
 import math
-from typing import Dict, Optional, Tuple
+from typing import Any, Dict, Optional, Tuple
 
 import torch
+from torch.library import custom_op, register_autograd
 
 from . import _cabi, argcheck, config
 from ._lm import ExtractableSequentialLanguageModel, MixableSequentialLanguageModel
@@ -43,17 +44,14 @@ def _i64(t: torch.Tensor) -> torch.Tensor:
     return t if t.dtype == torch.long else t.long()
 
 
-def beam_search_advance(
+@custom_op("pydrobert_amd::beam_search_advance", mutates_args=())
+def _beam_search_advance_op(
     log_probs_t: torch.Tensor,
     width: int,
     log_probs_prev: torch.Tensor,
     y_prev: torch.Tensor,
-    y_prev_lens: Optional[torch.Tensor] = None,
+    y_prev_lens: Optional[torch.Tensor],
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Beam search step function (reference _decoding.py:41-155).
-
-    Returns ``(y_next, y_next_lens, log_probs_next, next_src)``.
-    """
     if log_probs_t.dim() != 3:
         raise RuntimeError("log_probs_t must be 3 dimensional")
     N, Kp, V = log_probs_t.shape
@@ -106,23 +104,56 @@ def beam_search_advance(
     return y_next, y_next_lens, lp_next.to(log_probs_t.dtype), next_src
 
 
-def ctc_prefix_search_advance(
-    probs_t: Tuple[torch.Tensor, torch.Tensor, torch.Tensor],
+@_beam_search_advance_op.register_fake
+def _(log_probs_t, width, log_probs_prev, y_prev, y_prev_lens):
+    N = log_probs_t.shape[0]
+    S = y_prev.shape[0]
+    if y_prev_lens is not None:  # data dependent: S or S + 1 (:133-135)
+        S_out = torch.library.get_ctx().new_dynamic_size()
+    else:
+        S_out = S + 1
+    return (
+        y_prev.new_empty((S_out, N, width), dtype=torch.long),
+        y_prev.new_empty((N, width), dtype=torch.long),
+        log_probs_t.new_empty((N, width)),
+        y_prev.new_empty((N, width), dtype=torch.long),
+    )
+
+
+def beam_search_advance(
+    log_probs_t: torch.Tensor,
     width: int,
-    probs_prev: Tuple[torch.Tensor, torch.Tensor],
+    log_probs_prev: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_lens: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Beam search step function (reference _decoding.py:41-155).
+
+    Returns ``(y_next, y_next_lens, log_probs_next, next_src)``.
+    """
+    return torch.ops.pydrobert_amd.beam_search_advance(
+        log_probs_t, width, log_probs_prev, y_prev, y_prev_lens
+    )
+
+
+@custom_op("pydrobert_amd::ctc_prefix_search_advance", mutates_args=())
+def _ctc_prefix_search_advance_op(
+    ext: torch.Tensor,
+    nonext: torch.Tensor,
+    blank: torch.Tensor,
+    width: int,
+    nb: torch.Tensor,
+    b: torch.Tensor,
     y_prev: torch.Tensor,
     y_prev_last: torch.Tensor,
     y_prev_lens: torch.Tensor,
     prev_is_prefix: torch.Tensor,
-):
-    """CTC prefix search step function (reference _decoding.py:636-934).
-
-    Returns ``(y_next, y_next_last, y_next_lens, (nb_probs_next, b_probs_next),
-    next_is_prefix, next_src, next_is_nonext)``.
-    """
+) -> Tuple[
+    torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+    torch.Tensor, torch.Tensor,
+]:  # fmt: skip
     if width < 1:
         raise RuntimeError("width must be positive")
-    ext, nonext, blank = probs_t
     if ext.dim() != 3:
         raise RuntimeError("ext_probs_t must be 3 dimensional")
     N, Kp, V = ext.shape
@@ -134,7 +165,6 @@ def ctc_prefix_search_advance(
         raise RuntimeError(
             "expected blank_probs_t to have shape {}, got {}".format((N,), tuple(blank.shape))
         )
-    nb, b = probs_prev
     if nb.shape != (N, Kp):
         raise RuntimeError(
             "expected nb_probs_prev to have shape {}, got {}".format((N, Kp), tuple(nb.shape))
@@ -201,18 +231,47 @@ def ctc_prefix_search_advance(
                 _cabi.stream_ptr(device),
             )  # fmt: skip
             _cabi.check(rc, "pdt_ctc_prefix_search_advance")
-    return y_next, o_last, o_lens, (o_nb.to(dtype), o_b.to(dtype)), o_isp, o_src, o_non
+    return y_next, o_last, o_lens, o_nb.to(dtype), o_b.to(dtype), o_isp, o_src, o_non
 
 
-def ctc_prefix_search(
-    logits: torch.Tensor, width: int, lens: Optional[torch.Tensor] = None
-) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """``CTCPrefixSearch(width)(logits, lens)`` without a language model, as ONE kernel.
+@_ctc_prefix_search_advance_op.register_fake
+def _(ext, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix):
+    N, W, S = ext.shape[0], width, y_prev.shape[0]
+    i64 = lambda *s: y_prev.new_empty(s, dtype=torch.long)  # noqa: E731
+    return (
+        i64(S + 1, N, W), i64(N, W), i64(N, W), ext.new_empty((N, W)), ext.new_empty((N, W)),
+        ext.new_empty((N, W, W), dtype=torch.bool), i64(N, W), ext.new_empty((N, W), dtype=torch.bool),
+    )  # fmt: skip
 
-    Reference: ``CTCPrefixSearch.forward`` (_decoding.py:1064-1202) with ``lm=None``.
-    Returns ``(y (S, N, width) int64, y_lens (N, width) int64, y_probs (N, width))``; rows of
-    ``y`` beyond ``y_lens`` are zero (the reference leaves them undefined).
+
+def ctc_prefix_search_advance(
+    probs_t: Tuple[torch.Tensor, torch.Tensor, torch.Tensor],
+    width: int,
+    probs_prev: Tuple[torch.Tensor, torch.Tensor],
+    y_prev: torch.Tensor,
+    y_prev_last: torch.Tensor,
+    y_prev_lens: torch.Tensor,
+    prev_is_prefix: torch.Tensor,
+) -> Tuple[
+    torch.Tensor, torch.Tensor, torch.Tensor, Tuple[torch.Tensor, torch.Tensor], torch.Tensor,
+    torch.Tensor, torch.Tensor,
+]:  # fmt: skip
+    """CTC prefix search step function (reference _decoding.py:636-934).
+
+    Returns ``(y_next, y_next_last, y_next_lens, (nb_probs_next, b_probs_next),
+    next_is_prefix, next_src, next_is_nonext)``.
     """
+    y_next, last, lens, nb, b, isp, src, non = torch.ops.pydrobert_amd.ctc_prefix_search_advance(
+        probs_t[0], probs_t[1], probs_t[2], width, probs_prev[0], probs_prev[1], y_prev,
+        y_prev_last, y_prev_lens, prev_is_prefix,
+    )  # fmt: skip
+    return y_next, last, lens, (nb, b), isp, src, non
+
+
+@custom_op("pydrobert_amd::ctc_prefix_search", mutates_args=())
+def _ctc_prefix_search_op(
+    logits: torch.Tensor, width: int, lens: Optional[torch.Tensor]
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     if logits.dim() != 3:
         raise RuntimeError("logits must be 3 dimensional")  # :1073-1074
     device = _cabi.require_hip(logits, lens)
@@ -252,6 +311,29 @@ def ctc_prefix_search(
         )  # fmt: skip
     _cabi.check(rc, "pdt_ctc_prefix_search")
     return y, y_lens, y_probs.to(dtype)
+
+
+@_ctc_prefix_search_op.register_fake
+def _(logits, width, lens):
+    T, N = logits.shape[0], logits.shape[1]
+    S = T if lens is None else torch.library.get_ctx().new_dynamic_size()  # lens.max() (:1089)
+    return (
+        logits.new_empty((S, N, width), dtype=torch.long),
+        logits.new_empty((N, width), dtype=torch.long),
+        logits.new_empty((N, width)),
+    )
+
+
+def ctc_prefix_search(
+    logits: torch.Tensor, width: int, lens: Optional[torch.Tensor] = None
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """``CTCPrefixSearch(width)(logits, lens)`` without a language model, as ONE kernel.
+
+    Reference: ``CTCPrefixSearch.forward`` (_decoding.py:1064-1202) with ``lm=None``.
+    Returns ``(y (S, N, width) int64, y_lens (N, width) int64, y_probs (N, width))``; rows of
+    ``y`` beyond ``y_lens`` are zero (the reference leaves them undefined).
+    """
+    return torch.ops.pydrobert_amd.ctc_prefix_search(logits, width, lens)
 
 
 class CTCPrefixSearch(torch.nn.Module):
@@ -298,42 +380,51 @@ class CTCPrefixSearch(torch.nn.Module):
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         if logits.dim() != 3:
             raise RuntimeError("logits must be 3 dimensional")
-        T, N, Vp1 = logits.shape
-        V = Vp1 - 1
-        if self.lm is not None and self.lm.vocab_size != V:
-            raise RuntimeError(
-                "Expected dim 2 of logits to be {}, got {}".format(self.lm.vocab_size + 1, Vp1)
-            )
-        if self.lm is None or not self.beta:
+        if self.lm is None:
             return ctc_prefix_search(logits, self.width, lens)
-        return self._fused_with_lm(logits, lens, dict() if initial_state is None else initial_state)
+        else:
+            Vp1 = logits.size(2)
+            if self.lm.vocab_size != Vp1 - 1:
+                raise RuntimeError(
+                    "Expected dim 2 of logits to be {}, got {}".format(self.lm.vocab_size + 1, Vp1)
+                )
+            if self.beta == 0.0:
+                return ctc_prefix_search(logits, self.width, lens)
+            prev: Dict[str, torch.Tensor] = dict()
+            if initial_state is not None:
+                prev = initial_state
+            return self._fused_with_lm(logits, lens, prev)
 
-    def _fused_with_lm(self, logits, lens, prev):
+    def _fused_with_lm(
+        self, logits: torch.Tensor, lens: Optional[torch.Tensor], prev: Dict[str, torch.Tensor]
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         # reference _decoding.py:1083-1202, frame loop around the user's language model
-        T, N, Vp1 = logits.shape
+        T, N, Vp1 = logits.size(0), logits.size(1), logits.size(2)
         V, W = Vp1 - 1, self.width
         device, dtype = logits.device, logits.dtype
         if lens is None:
-            lens = torch.full((N,), T, device=device, dtype=torch.long)
+            lens_ = torch.full((N,), T, device=device, dtype=torch.long)
             len_min = len_max = T
-        elif lens.dim() != 1:
-            raise RuntimeError("lens must be 1 dimensional")
-        elif lens.size(0) != N:
-            raise RuntimeError("expected dim 0 of lens to be {}, got {}".format(N, lens.size(0)))
         else:
+            if lens.dim() != 1:
+                raise RuntimeError("lens must be 1 dimensional")
+            if lens.size(0) != N:
+                raise RuntimeError("expected dim 0 of lens to be {}, got {}".format(N, lens.size(0)))
+            lens_ = lens
             len_min, len_max = int(lens.min().item()), int(lens.max().item())
         probs = logits.softmax(2)
         blank_probs, nonext_probs = probs[..., V], probs[..., :V]
         nb = torch.zeros((N, 1), device=device, dtype=dtype)
         b = torch.ones((N, 1), device=device, dtype=dtype)
         y = torch.empty((0, N, 1), dtype=torch.long, device=device)
-        y_lens = y_last = torch.zeros((N, 1), dtype=torch.long, device=device)
+        y_lens = torch.zeros((N, 1), dtype=torch.long, device=device)
+        y_last = y_lens
         is_prefix = torch.ones((N, 1, 1), device=device, dtype=torch.bool)
+        assert self.lm is not None
         prev = self.lm.update_input(prev, y)
         Kp = 1
         pad_y = torch.zeros((1, N, W), device=device, dtype=torch.long)
         for t in range(len_max):
-            valid = None if t < len_min else (t < lens).unsqueeze(1)
             nonext_t, blank_t = nonext_probs[t], blank_probs[t]
             lm_lp, in_next = self.lm.calc_idx_log_probs(y.flatten(1), prev, y_lens.flatten())
             if self.valid_mixture:  # :1120-1128
@@ -342,17 +433,19 @@ class CTCPrefixSearch(torch.nn.Module):
             else:  # :1130-1135
                 lm_p = (self.beta * lm_lp.log_softmax(-1)).exp().view(N, Kp, V)
                 ext_t = lm_p * nonext_t.unsqueeze(1)
-            (y_next, last_next, lens_next, (nb_next, b_next), isp_next, src, is_nonext) = \
+            (y_next, last_next, lens_next, probs_next, isp_next, src, is_nonext) = \
                 ctc_prefix_search_advance(
                     (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
                 )  # fmt: skip
+            nb_next, b_next = probs_next
             flat = (torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1) + src).flatten()
             prev = self.lm.extract_by_src(prev, flat)  # :1154-1163
             in_next = self.lm.extract_by_src(in_next, flat)
             prev = self.lm.mix_by_mask(prev, in_next, is_nonext.flatten())
-            if valid is None:
+            if t < len_min:
                 y_lens, nb, b = lens_next, nb_next, b_next
             else:  # :1165-1181 freeze finished batch elements
+                valid = (t < lens_).unsqueeze(1)
                 y = torch.cat([y.expand(-1, -1, W), pad_y], 0)
                 y_next = torch.where(valid.unsqueeze(0), y_next, y)
                 y_lens = torch.where(valid, lens_next, y_lens)
@@ -363,7 +456,7 @@ class CTCPrefixSearch(torch.nn.Module):
                 b = torch.where(valid, b_next, b)
             y, y_last, is_prefix, Kp = y_next, last_next, isp_next, W
         probs_out = nb + b
-        if Kp == 1 != W:  # :1190-1200
+        if Kp == 1 and W != 1:  # :1190-1200
             y = y.repeat(1, 1, W)
             y_lens = y_lens.repeat(1, W)
             probs_out = torch.cat([probs_out, probs_out.new_full((N, W - 1), -float("inf"))], 1)
@@ -504,15 +597,14 @@ class BeamSearch(torch.nn.Module):
 # ---------------------------------------------------------------------------------------
 # greedy CTC search, sequence log-probabilities, random walk
 # ---------------------------------------------------------------------------------------
-def ctc_greedy_search(
+@custom_op("pydrobert_amd::ctc_greedy_search", mutates_args=())
+def _ctc_greedy_search_op(
     logits: torch.Tensor,
-    in_lens: Optional[torch.Tensor] = None,
-    blank_idx: int = -1,
-    batch_first: bool = False,
-    is_probs: bool = False,
+    in_lens: Optional[torch.Tensor],
+    blank_idx: int,
+    batch_first: bool,
+    is_probs: bool,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """Functional version of :class:`CTCGreedySearch` (reference _decoding.py:507-558):
-    returns ``(max_, paths, out_lens)``.  One pass over the logits; ``max_`` carries no gradient."""
     if logits.dim() != 3:
         raise RuntimeError("logits must be 3-dimensional")
     V = logits.size(2)
@@ -545,44 +637,29 @@ def ctc_greedy_search(
     return max_.to(logits.dtype), paths, out_lens
 
 
-class _SeqLogProbsFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, logits, hyp, A, S, B, eos):
-        device = logits.device
-        x = logits.detach()
-        if x.dtype != torch.float:
-            x = x.float()
-        x = x.contiguous()
-        V = x.shape[-1]
-        with torch.cuda.device(device):
-            out = torch.empty((A, B), device=device, dtype=torch.float)
-            rc = _cabi.lib().pdt_sequence_log_probs_forward(
-                _cabi.ptr(x), _cabi.ptr(hyp), A, S, B, V, int(eos is not None),
-                int(eos) if eos is not None else 0, _cabi.ptr(out), _cabi.stream_ptr(device),
-            )  # fmt: skip
-        _cabi.check(rc, "pdt_sequence_log_probs_forward")
-        ctx.save_for_backward(x, hyp)
-        ctx.cfg = (A, S, B, eos, logits.dtype, logits.shape)
-        return out
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        x, hyp = ctx.saved_tensors
-        A, S, B, eos, dtype, shape = ctx.cfg
-        device = x.device
-        g = grad_out.detach().float().contiguous()
-        with torch.cuda.device(device):
-            grad = torch.empty_like(x)
-            rc = _cabi.lib().pdt_sequence_log_probs_backward(
-                _cabi.ptr(x), _cabi.ptr(hyp), A, S, B, x.shape[-1], int(eos is not None),
-                int(eos) if eos is not None else 0, _cabi.ptr(g), _cabi.ptr(grad),
-                _cabi.stream_ptr(device),
-            )  # fmt: skip
-        _cabi.check(rc, "pdt_sequence_log_probs_backward")
-        return grad.view(shape).to(dtype), None, None, None, None, None
+@_ctc_greedy_search_op.register_fake
+def _(logits, in_lens, blank_idx, batch_first, is_probs):
+    N = logits.shape[0] if batch_first else logits.shape[1]
+    return (
+        logits.new_empty((N,)),
+        logits.new_empty(logits.shape[:2], dtype=torch.long),
+        logits.new_empty((N,), dtype=torch.long),
+    )
 
 
-def _sequence_log_probs_tensor(logits, hyp, dim, eos):
+def ctc_greedy_search(
+    logits: torch.Tensor,
+    in_lens: Optional[torch.Tensor] = None,
+    blank_idx: int = -1,
+    batch_first: bool = False,
+    is_probs: bool = False,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Functional version of :class:`CTCGreedySearch` (reference _decoding.py:507-558):
+    returns ``(max_, paths, out_lens)``.  One pass over the logits; ``max_`` carries no gradient."""
+    return torch.ops.pydrobert_amd.ctc_greedy_search(logits, in_lens, blank_idx, batch_first, is_probs)
+
+
+def _slp_dims(hyp: torch.Tensor, dim: int) -> Tuple[int, int, int, int]:
     hyp_dim = hyp.dim()
     if dim < -hyp_dim or dim > hyp_dim - 1:
         raise RuntimeError(
@@ -591,41 +668,115 @@ def _sequence_log_probs_tensor(logits, hyp, dim, eos):
             )
         )
     dim = (hyp_dim + dim) % hyp_dim
+    shape = tuple(hyp.shape)
+    return dim, int(math.prod(shape[:dim])), shape[dim], int(math.prod(shape[dim + 1 :]))
+
+
+@custom_op("pydrobert_amd::sequence_log_probs", mutates_args=())
+def _sequence_log_probs_op(
+    logits: torch.Tensor, hyp: torch.Tensor, dim: int, eos: Optional[int]
+) -> torch.Tensor:
+    """Fused log-softmax + gather + masked sum over ``dim`` (csrc/seq_ops.hip)."""
+    dim, A, S, B = _slp_dims(hyp, dim)
     if logits.shape[:-1] != hyp.shape:
         raise RuntimeError("logits must have shape hyp.shape + (num_classes,)")
-    _cabi.require_hip(logits, hyp)
-    shape = tuple(hyp.shape)
-    A = int(math.prod(shape[:dim]))
-    S = shape[dim]
-    B = int(math.prod(shape[dim + 1 :]))
+    device = _cabi.require_hip(logits, hyp)
+    x = _f32(logits).contiguous()
     h = _i64(hyp).contiguous()
-    out = _SeqLogProbsFn.apply(logits, h, A, S, B, eos)
+    with torch.cuda.device(device):
+        out = torch.empty((A, B), device=device, dtype=torch.float)
+        rc = _cabi.lib().pdt_sequence_log_probs_forward(
+            _cabi.ptr(x), _cabi.ptr(h), A, S, B, x.shape[-1], int(eos is not None),
+            int(eos) if eos is not None else 0, _cabi.ptr(out), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_sequence_log_probs_forward")
+    shape = tuple(hyp.shape)
     return out.view(shape[:dim] + shape[dim + 1 :]).to(logits.dtype)
 
 
-def sequence_log_probs(logits, hyp: torch.Tensor, dim: int = 0, eos: Optional[int] = None) -> torch.Tensor:
+@_sequence_log_probs_op.register_fake
+def _(logits, hyp, dim, eos):
+    d = dim % hyp.dim()
+    return logits.new_empty(tuple(hyp.shape[:d]) + tuple(hyp.shape[d + 1 :]))
+
+
+@custom_op("pydrobert_amd::sequence_log_probs_backward", mutates_args=())
+def _sequence_log_probs_backward_op(
+    logits: torch.Tensor, hyp: torch.Tensor, dim: int, eos: Optional[int], grad_out: torch.Tensor
+) -> torch.Tensor:
+    dim, A, S, B = _slp_dims(hyp, dim)
+    device = logits.device
+    x = _f32(logits).contiguous()
+    h = _i64(hyp).contiguous()
+    g = grad_out.detach().float().contiguous()
+    with torch.cuda.device(device):
+        grad = torch.empty_like(x)
+        rc = _cabi.lib().pdt_sequence_log_probs_backward(
+            _cabi.ptr(x), _cabi.ptr(h), A, S, B, x.shape[-1], int(eos is not None),
+            int(eos) if eos is not None else 0, _cabi.ptr(g), _cabi.ptr(grad),
+            _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_sequence_log_probs_backward")
+    return grad.view(logits.shape).to(logits.dtype)
+
+
+@_sequence_log_probs_backward_op.register_fake
+def _(logits, hyp, dim, eos, grad_out):
+    return torch.empty_like(logits)
+
+
+def _slp_setup_context(ctx, inputs, output):
+    logits, hyp, dim, eos = inputs
+    ctx.save_for_backward(logits, hyp)
+    ctx.cfg = (dim, eos)
+
+
+def _slp_backward(ctx, grad_out):
+    logits, hyp = ctx.saved_tensors
+    dim, eos = ctx.cfg
+    grad = torch.ops.pydrobert_amd.sequence_log_probs_backward(logits, hyp, dim, eos, grad_out)
+    return grad, None, None, None
+
+
+register_autograd(
+    "pydrobert_amd::sequence_log_probs", _slp_backward, setup_context=_slp_setup_context
+)
+
+
+def _sequence_log_probs_ps(
+    logits: Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]],
+    hyp: torch.Tensor,
+    dim: int,
+) -> torch.Tensor:
+    # padded view + out-of-range tokens beyond each length: same kernel, same masking rule
+    if dim < -2 or dim > 1:
+        raise RuntimeError(
+            "Dimension out of range (expected to be in range of [-2, 1], but got {})".format(dim)
+        )
+    data, batch_sizes, unsorted = logits[0], logits[1], logits[3]
+    S = batch_sizes.size(0)
+    padded, lens = torch._pad_packed_sequence(data, batch_sizes, False, 0.0, S)  # (S, N, V)
+    if unsorted is not None:
+        padded, lens = padded.index_select(1, unsorted), lens.index_select(0, unsorted.cpu())
+    h = hyp if dim % 2 == 0 else hyp.t()
+    h = h[:S]
+    beyond = torch.arange(S, device=h.device).unsqueeze(1) >= lens.to(h.device).unsqueeze(0)
+    return torch.ops.pydrobert_amd.sequence_log_probs(padded, h.masked_fill(beyond, -1), 0, None)
+
+
+def sequence_log_probs(
+    logits: Any, hyp: torch.Tensor, dim: int = 0, eos: Optional[int] = None
+) -> torch.Tensor:
     """Functional version of :class:`SequenceLogProbabilities` (reference
     _decoding.py:1516-1633): joint log-probability of the token sequences ``hyp`` under
     ``logits`` (a tensor of shape ``hyp.shape + (V,)`` or a ``PackedSequence``).  Fused
     log-softmax + gather + masked sum; differentiable w.r.t. ``logits``."""
     if isinstance(logits, torch.Tensor):
-        return _sequence_log_probs_tensor(logits, hyp, dim, eos)
-    if isinstance(logits, (torch.nn.utils.rnn.PackedSequence, tuple)):
-        # padded view + out-of-range tokens beyond each length: same kernel, same masking rule
-        hyp_dim = hyp.dim()
-        if dim < -hyp_dim or dim > hyp_dim - 1:
-            raise RuntimeError(
-                "Dimension out of range (expected to be in range of [{}, {}], but got {})".format(
-                    -hyp_dim, hyp_dim - 1, dim
-                )
-            )
-        ps = logits if isinstance(logits, torch.nn.utils.rnn.PackedSequence) else torch.nn.utils.rnn.PackedSequence(*logits)
-        padded, lens = torch.nn.utils.rnn.pad_packed_sequence(ps)  # (S, N, V)
-        h = hyp if dim % 2 == 0 else hyp.t()
-        S = padded.shape[0]
-        h = h[:S]
-        beyond = torch.arange(S, device=h.device).unsqueeze(1) >= lens.to(h.device).unsqueeze(0)
-        return _sequence_log_probs_tensor(padded, h.masked_fill(beyond, -1), 0, None)
+        return torch.ops.pydrobert_amd.sequence_log_probs(logits, hyp, dim, eos)
+    elif torch.jit.isinstance(
+        logits, Tuple[torch.Tensor, torch.Tensor, Optional[torch.Tensor], Optional[torch.Tensor]]
+    ):
+        return _sequence_log_probs_ps(logits, hyp, dim)
     raise RuntimeError("logits must be either a Tensor or PackedSequence")
 
 
@@ -639,19 +790,19 @@ def random_walk_advance(
     generator on the tensors' device, as in the reference; a handful of small launches."""
     if log_probs_t.dim() != 2:
         raise RuntimeError("log_probs_t must be 2-dimensional")
-    N, V = log_probs_t.shape
-    if log_probs_prev.shape != (N,):
+    N = log_probs_t.size(0)
+    if log_probs_prev.dim() != 1 or log_probs_prev.size(0) != N:
         raise RuntimeError(
-            "Expected log_probs_prev to be of shape {}, got {}".format((N,), tuple(log_probs_prev.shape))
+            "Expected log_probs_prev to be of shape ({},), got {}".format(N, log_probs_prev.shape)
         )
     if y_prev.dim() != 2:
         raise RuntimeError("y_prev must be 2-dimensional")
     if y_prev.size(1) != N:
         raise RuntimeError("Expected dim 1 of y_prev to be {}, got {}".format(N, y_prev.size(-1)))
     S = y_prev.size(0)
-    if y_prev_lens is not None and y_prev_lens.shape != (N,):
+    if y_prev_lens is not None and (y_prev_lens.dim() != 1 or y_prev_lens.size(0) != N):
         raise RuntimeError(
-            "Expected y_prev_lens to have shape {}, got {}".format((N,), tuple(y_prev_lens.shape))
+            "Expected y_prev_lens to have shape ({},), got {}".format(N, y_prev_lens.shape)
         )
     y_t = torch.multinomial(log_probs_t.exp(), 1, True)  # (N, 1)
     log_probs_next = log_probs_prev + log_probs_t.gather(1, y_t).squeeze(1)
@@ -682,7 +833,9 @@ class CTCGreedySearch(torch.nn.Module):
     def extra_repr(self) -> str:
         return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
 
-    def forward(self, logits: torch.Tensor, in_lens: Optional[torch.Tensor] = None):
+    def forward(
+        self, logits: torch.Tensor, in_lens: Optional[torch.Tensor] = None
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         return ctc_greedy_search(logits, in_lens, self.blank_idx, self.batch_first, self.is_probs)
 
 
@@ -703,7 +856,7 @@ class SequenceLogProbabilities(torch.nn.Module):
             s += ", eos={}".format(self.eos)
         return s
 
-    def forward(self, logits, hyp: torch.Tensor) -> torch.Tensor:
+    def forward(self, logits: Any, hyp: torch.Tensor) -> torch.Tensor:
         return sequence_log_probs(logits, hyp, self.dim, self.eos)
 
 

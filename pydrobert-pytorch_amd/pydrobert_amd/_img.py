@@ -10,6 +10,7 @@ import math
 from typing import Any, Optional, Tuple
 
 import torch
+from torch.library import custom_op, register_autograd
 
 from . import _cabi, argcheck
 
@@ -31,7 +32,10 @@ __all__ = [
 _MODES = {"bilinear": 0, "nearest": 1}
 _PADDINGS = {"zeros": 0, "border": 1, "reflection": 2}
 _INDEXINGS = ("hw", "wh")
-SpecAugmentParams = Tuple[torch.Tensor, ...]
+SpecAugmentParams = Tuple[
+    torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+    torch.Tensor, torch.Tensor,
+]  # fmt: skip
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -41,19 +45,14 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.contiguous()
 
 
-def polyharmonic_spline(
+@custom_op("pydrobert_amd::polyharmonic_spline", mutates_args=())
+def _polyharmonic_spline_op(
     train_points: torch.Tensor,
     train_values: torch.Tensor,
     query_points: torch.Tensor,
     order: int,
-    regularization_weight: float = 0.0,
-    full_matrix: bool = True,
+    regularization_weight: float,
 ) -> torch.Tensor:
-    """Functional version of :class:`PolyharmonicSpline` (reference _img.py:133-150).
-
-    ``full_matrix`` is accepted for signature parity: the bordered system is solved exactly in
-    float64, which both of the reference's float32 evaluation orders approximate.
-    """
     if train_points.dim() != 3 or train_values.dim() != 3 or query_points.dim() != 3:
         raise RuntimeError("train_points, train_values and query_points must be 3 dimensional")
     N, T, I = train_points.shape
@@ -76,14 +75,39 @@ def polyharmonic_spline(
     return out.to(train_values.dtype)
 
 
-def warp_1d_grid(
+@_polyharmonic_spline_op.register_fake
+def _(train_points, train_values, query_points, order, regularization_weight):
+    return train_values.new_empty(
+        (train_points.shape[0], query_points.shape[1], train_values.shape[2])
+    )
+
+
+def polyharmonic_spline(
+    train_points: torch.Tensor,
+    train_values: torch.Tensor,
+    query_points: torch.Tensor,
+    order: int,
+    regularization_weight: float = 0.0,
+    full_matrix: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`PolyharmonicSpline` (reference _img.py:133-150).
+
+    ``full_matrix`` is accepted for signature parity: the bordered system is solved exactly in
+    float64, which both of the reference's float32 evaluation orders approximate.
+    """
+    return torch.ops.pydrobert_amd.polyharmonic_spline(
+        train_points, train_values, query_points, order, regularization_weight
+    )
+
+
+@custom_op("pydrobert_amd::warp_1d_grid", mutates_args=())
+def _warp_1d_grid_op(
     src: torch.Tensor,
     flow: torch.Tensor,
     lengths: torch.Tensor,
-    max_length: Optional[int] = None,
-    interpolation_order: int = 1,
+    max_length: Optional[int],
+    interpolation_order: int,
 ) -> torch.Tensor:
-    """Functional version of :class:`Warp1DGrid` (reference _img.py:268-303)."""
     device = _cabi.require_hip(src, flow, lengths)
     N = src.shape[0]
     if max_length is None:
@@ -101,50 +125,91 @@ def warp_1d_grid(
     return grid
 
 
-class _DenseWarpFn(torch.autograd.Function):
+@_warp_1d_grid_op.register_fake
+def _(src, flow, lengths, max_length, interpolation_order):
+    T = torch.library.get_ctx().new_dynamic_size() if max_length is None else max_length
+    return src.new_empty((src.shape[0], T), dtype=torch.float)
+
+
+def warp_1d_grid(
+    src: torch.Tensor,
+    flow: torch.Tensor,
+    lengths: torch.Tensor,
+    max_length: Optional[int] = None,
+    interpolation_order: int = 1,
+) -> torch.Tensor:
+    """Functional version of :class:`Warp1DGrid` (reference _img.py:268-303)."""
+    return torch.ops.pydrobert_amd.warp_1d_grid(src, flow, lengths, max_length, interpolation_order)
+
+
+@custom_op("pydrobert_amd::dense_image_warp", mutates_args=())
+def _dense_image_warp_op(
+    image: torch.Tensor, flow: torch.Tensor, indexing: str, mode: str, padding_mode: str
+) -> torch.Tensor:
     """dense_image_warp with a gradient for the image (bilinear taps are linear in it)."""
-
-    @staticmethod
-    def forward(ctx, image, flow, flow_is_hw, mode, padding):
-        device = image.device
-        img, fl = _f32c(image), _f32c(flow)
-        N, C, H, W = img.shape
-        with torch.cuda.device(device):
-            out = torch.empty_like(img)
-            rc = _cabi.lib().pdt_dense_image_warp(
-                _cabi.ptr(img), _cabi.ptr(fl), N, C, H, W, int(flow_is_hw), mode, padding,
-                _cabi.ptr(out), _cabi.stream_ptr(device),
-            )  # fmt: skip
-        _cabi.check(rc, "pdt_dense_image_warp")
-        ctx.save_for_backward(fl)
-        ctx.cfg = (flow_is_hw, mode, padding, image.dtype)
-        return out.to(image.dtype)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        (fl,) = ctx.saved_tensors
-        flow_is_hw, mode, padding, dtype = ctx.cfg
-        grad_image = _grid_sample_image_grad(grad_out, fl, flow_is_hw, mode, padding)
-        return grad_image.to(dtype), None, None, None, None
+    if indexing not in _INDEXINGS:
+        raise ValueError("Invalid indexing! must be one of 'wh' or 'hw'")
+    if image.dim() != 4 or flow.dim() != 4:
+        raise RuntimeError("image and flow must be 4 dimensional")
+    N, C, H, W = image.shape
+    if flow.shape != (N, H, W, 2):
+        raise RuntimeError("expected flow to have shape {}, got {}".format((N, H, W, 2), tuple(flow.shape)))
+    device = _cabi.require_hip(image, flow)
+    img, fl = _f32c(image), _f32c(flow)
+    with torch.cuda.device(device):
+        out = torch.empty_like(img)
+        rc = _cabi.lib().pdt_dense_image_warp(
+            _cabi.ptr(img), _cabi.ptr(fl), N, C, H, W, int(indexing == "hw"), _MODES[mode],
+            _PADDINGS[padding_mode], _cabi.ptr(out), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_dense_image_warp")
+    return out.to(image.dtype)
 
 
-def _grid_sample_image_grad(grad_out, flow, flow_is_hw, mode, padding):
-    # adjoint of the gather w.r.t. the image, via autograd on the equivalent grid_sample
-    N, C, H, W = grad_out.shape
-    fl = flow.flip(-1) if flow_is_hw else flow
-    h = torch.arange(H, dtype=torch.float, device=flow.device)
-    w = torch.arange(W, dtype=torch.float, device=flow.device)
-    hh, ww = torch.meshgrid(h, w, indexing="ij")
-    hw = torch.stack((ww, hh), 2).unsqueeze(0)
-    HW = torch.tensor([[[[W, H]]]], dtype=torch.float, device=flow.device)
-    grid = (2 * hw - 2 * fl + 1.0) / HW - 1.0
-    with torch.enable_grad():
-        probe = torch.zeros((N, C, H, W), device=flow.device, dtype=torch.float, requires_grad=True)
-        mode_s = [k for k, v in _MODES.items() if v == mode][0]
-        pad_s = [k for k, v in _PADDINGS.items() if v == padding][0]
-        out = torch.nn.functional.grid_sample(probe, grid, mode=mode_s, padding_mode=pad_s, align_corners=False)
-        (g,) = torch.autograd.grad(out, probe, grad_out.float())
-    return g
+@_dense_image_warp_op.register_fake
+def _(image, flow, indexing, mode, padding_mode):
+    return image.new_empty(image.shape)
+
+
+@custom_op("pydrobert_amd::dense_image_warp_backward", mutates_args=())
+def _dense_image_warp_backward_op(
+    grad_out: torch.Tensor, flow: torch.Tensor, indexing: str, mode: str, padding_mode: str
+) -> torch.Tensor:
+    """Adjoint of the gather with respect to the image (csrc/img_warp.hip, BACKWARD)."""
+    device = _cabi.require_hip(grad_out, flow)
+    g, fl = _f32c(grad_out), _f32c(flow)
+    N, C, H, W = g.shape
+    with torch.cuda.device(device):
+        grad = torch.empty_like(g)
+        rc = _cabi.lib().pdt_dense_image_warp_backward(
+            _cabi.ptr(g), _cabi.ptr(fl), N, C, H, W, int(indexing == "hw"), _MODES[mode],
+            _PADDINGS[padding_mode], _cabi.ptr(grad), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_dense_image_warp_backward")
+    return grad.to(grad_out.dtype)
+
+
+@_dense_image_warp_backward_op.register_fake
+def _(grad_out, flow, indexing, mode, padding_mode):
+    return grad_out.new_empty(grad_out.shape)
+
+
+def _dense_setup_context(ctx, inputs, output):
+    _, flow, indexing, mode, padding_mode = inputs
+    ctx.save_for_backward(flow)
+    ctx.cfg = (indexing, mode, padding_mode)
+
+
+def _dense_backward(ctx, grad_out):
+    (flow,) = ctx.saved_tensors
+    indexing, mode, padding_mode = ctx.cfg
+    g = torch.ops.pydrobert_amd.dense_image_warp_backward(grad_out, flow, indexing, mode, padding_mode)
+    return g, None, None, None, None
+
+
+register_autograd(
+    "pydrobert_amd::dense_image_warp", _dense_backward, setup_context=_dense_setup_context
+)
 
 
 def dense_image_warp(
@@ -156,15 +221,7 @@ def dense_image_warp(
 ) -> torch.Tensor:
     """Functional version of :class:`DenseImageWarp` (reference _img.py:393-439):
     ``output[n, c, h, w] = image[n, c, h - flow[n, h, w, 0], w - flow[n, h, w, 1]]``."""
-    if indexing not in _INDEXINGS:
-        raise ValueError("Invalid indexing! must be one of 'wh' or 'hw'")
-    if image.dim() != 4 or flow.dim() != 4:
-        raise RuntimeError("image and flow must be 4 dimensional")
-    N, C, H, W = image.shape
-    if flow.shape != (N, H, W, 2):
-        raise RuntimeError("expected flow to have shape {}, got {}".format((N, H, W, 2), tuple(flow.shape)))
-    _cabi.require_hip(image, flow)
-    return _DenseWarpFn.apply(image, flow, indexing == "hw", _MODES[mode], _PADDINGS[padding_mode])
+    return torch.ops.pydrobert_amd.dense_image_warp(image, flow, indexing, mode, padding_mode)
 
 
 def _pinned_points(k: int, W: int, H: int, N: int, device) -> torch.Tensor:
@@ -182,6 +239,146 @@ def _pinned_points(k: int, W: int, H: int, N: int, device) -> torch.Tensor:
         0,
     )
     return pts.unsqueeze(0).expand(N, -1, -1)
+
+
+def _sparse_prepare(image, source_points, dest_points, indexing, pinned_boundary_points,
+                    include_flow):  # fmt: skip
+    """(device, points, values, M') in the C ABI's conventions: (x=w, y=h) order, pinned
+    boundary points appended, values = dest - source (flow form) or the normalised source grid."""
+    if indexing not in _INDEXINGS:
+        raise ValueError("Invalid indexing! must be one of 'wh' or 'hw'")
+    if image.dim() != 4:
+        raise RuntimeError("image must be 4 dimensional")
+    device = _cabi.require_hip(image, source_points, dest_points)
+    N, C, H, W = image.shape
+    src, dst = source_points.detach().float(), dest_points.detach().float()
+    if indexing == "hw":
+        src, dst = src.flip(-1), dst.flip(-1)
+    if src.shape[1] == 0:
+        return device, None, None, 0
+    if pinned_boundary_points > 0:
+        pp = _pinned_points(pinned_boundary_points, W, H, N, device)
+        src, dst = torch.cat([src, pp], 1), torch.cat([dst, pp], 1)
+    Mp = src.shape[1]
+    if Mp + 3 > 100:
+        raise RuntimeError("sparse_image_warp: more than 97 control points")
+    if include_flow:
+        vals = dst - src  # :561-562
+    else:
+        WH = torch.tensor([W, H], dtype=torch.float, device=device)
+        vals = (2.0 * src + 1.0) / WH - 1.0  # :633
+    return device, dst.contiguous(), vals.contiguous(), Mp
+
+
+@custom_op("pydrobert_amd::sparse_image_warp", mutates_args=())
+def _sparse_image_warp_op(
+    image: torch.Tensor,
+    source_points: torch.Tensor,
+    dest_points: torch.Tensor,
+    indexing: str,
+    field_interpolation_order: int,
+    field_regularization_weight: float,
+    pinned_boundary_points: int,
+    dense_interpolation_mode: str,
+    dense_padding_mode: str,
+    include_flow: bool,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(warped, flow); ``flow`` is an empty tensor unless ``include_flow``.  Differentiable
+    with respect to ``image``."""
+    device, pts, vals, Mp = _sparse_prepare(
+        image, source_points, dest_points, indexing, pinned_boundary_points, include_flow
+    )
+    N, C, H, W = image.shape
+    if Mp == 0:  # :543-548
+        return image.clone(), torch.zeros(
+            (N, H, W, 2) if include_flow else (0,), dtype=torch.float, device=device
+        )
+    img = _f32c(image)
+    L = _cabi.lib()
+    with torch.cuda.device(device):
+        out = torch.empty_like(img)
+        flow = torch.empty((N, H, W, 2) if include_flow else (0,), device=device, dtype=torch.float)
+        ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, Mp, 2, 2)),), device=device, dtype=torch.uint8)
+        rc = L.pdt_sparse_image_warp(
+            _cabi.ptr(img), _cabi.ptr(pts), _cabi.ptr(vals), N, C, H, W, Mp,
+            int(field_interpolation_order), float(field_regularization_weight),
+            int(not include_flow), _MODES[dense_interpolation_mode], _PADDINGS[dense_padding_mode],
+            _cabi.ptr(out), _cabi.ptr(flow) if include_flow else None, int(indexing == "hw"),
+            _cabi.ptr(ws), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_sparse_image_warp")
+    return out.to(image.dtype), flow
+
+
+@custom_op("pydrobert_amd::sparse_image_warp_backward", mutates_args=())
+def _sparse_image_warp_backward_op(
+    grad_out: torch.Tensor,
+    source_points: torch.Tensor,
+    dest_points: torch.Tensor,
+    indexing: str,
+    field_interpolation_order: int,
+    field_regularization_weight: float,
+    pinned_boundary_points: int,
+    dense_interpolation_mode: str,
+    dense_padding_mode: str,
+    include_flow: bool,
+) -> torch.Tensor:
+    """Adjoint of ``sparse_image_warp`` with respect to the image."""
+    device, pts, vals, Mp = _sparse_prepare(
+        grad_out, source_points, dest_points, indexing, pinned_boundary_points, include_flow
+    )
+    if Mp == 0:
+        return grad_out.clone()
+    g = _f32c(grad_out)
+    N, C, H, W = g.shape
+    L = _cabi.lib()
+    with torch.cuda.device(device):
+        grad = torch.empty_like(g)
+        ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, Mp, 2, 2)),), device=device, dtype=torch.uint8)
+        rc = L.pdt_sparse_image_warp_backward(
+            _cabi.ptr(g), _cabi.ptr(pts), _cabi.ptr(vals), N, C, H, W, Mp,
+            int(field_interpolation_order), float(field_regularization_weight),
+            int(not include_flow), _MODES[dense_interpolation_mode], _PADDINGS[dense_padding_mode],
+            _cabi.ptr(grad), _cabi.ptr(ws), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_sparse_image_warp_backward")
+    return grad.to(grad_out.dtype)
+
+
+@_sparse_image_warp_backward_op.register_fake
+def _(grad_out, source_points, dest_points, indexing, field_interpolation_order,
+      field_regularization_weight, pinned_boundary_points, dense_interpolation_mode,
+      dense_padding_mode, include_flow):  # fmt: skip
+    return grad_out.new_empty(grad_out.shape)
+
+
+def _sparse_setup_context(ctx, inputs, output):
+    ctx.save_for_backward(inputs[1], inputs[2])
+    ctx.cfg = tuple(inputs[3:])
+
+
+def _sparse_backward(ctx, grad_warped, _grad_flow):
+    source_points, dest_points = ctx.saved_tensors
+    g = torch.ops.pydrobert_amd.sparse_image_warp_backward(
+        grad_warped, source_points, dest_points, *ctx.cfg
+    )
+    return (g,) + (None,) * 9
+
+
+register_autograd(
+    "pydrobert_amd::sparse_image_warp", _sparse_backward, setup_context=_sparse_setup_context
+)
+
+
+@_sparse_image_warp_op.register_fake
+def _(image, source_points, dest_points, indexing, field_interpolation_order,
+      field_regularization_weight, pinned_boundary_points, dense_interpolation_mode,
+      dense_padding_mode, include_flow):  # fmt: skip
+    N, _, H, W = image.shape
+    return (
+        image.new_empty(image.shape),
+        image.new_empty((N, H, W, 2) if include_flow else (0,), dtype=torch.float),
+    )
 
 
 def sparse_image_warp(
@@ -202,55 +399,22 @@ def sparse_image_warp(
     The spline over the control points is evaluated per pixel inside the gather kernel; the
     dense flow field is only written when ``include_flow``.
     """
-    if indexing not in _INDEXINGS:
-        raise ValueError("Invalid indexing! must be one of 'wh' or 'hw'")
-    if image.dim() != 4:
-        raise RuntimeError("image must be 4 dimensional")
-    device = _cabi.require_hip(image, source_points, dest_points)
-    N, C, H, W = image.shape
-    src, dst = source_points.detach().float(), dest_points.detach().float()
-    if indexing == "hw":
-        src, dst = src.flip(-1), dst.flip(-1)
-    M = src.shape[1]
-    if M == 0:  # :543-548
-        if include_flow:
-            return image, torch.zeros((N, H, W, 2), dtype=torch.float, device=device)
-        return image
-    if pinned_boundary_points > 0:
-        pp = _pinned_points(pinned_boundary_points, W, H, N, device)
-        src, dst = torch.cat([src, pp], 1), torch.cat([dst, pp], 1)
-    Mp = src.shape[1]
-    if Mp + 3 > 100:
-        raise RuntimeError("sparse_image_warp: more than 97 control points")
+    warped, flow = torch.ops.pydrobert_amd.sparse_image_warp(
+        image, source_points, dest_points, indexing, field_interpolation_order,
+        field_regularization_weight, pinned_boundary_points, dense_interpolation_mode,
+        dense_padding_mode, include_flow,
+    )  # fmt: skip
     if include_flow:
-        vals = dst - src  # :561-562
+        return warped, flow
     else:
-        WH = torch.tensor([W, H], dtype=torch.float, device=device)
-        vals = (2.0 * src + 1.0) / WH - 1.0  # :633
-    img = _f32c(image)
-    pts, vals = dst.contiguous(), vals.contiguous()
-    L = _cabi.lib()
-    with torch.cuda.device(device):
-        out = torch.empty_like(img)
-        flow = torch.empty((N, H, W, 2), device=device, dtype=torch.float) if include_flow else None
-        ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, Mp, 2, 2)),), device=device, dtype=torch.uint8)
-        rc = L.pdt_sparse_image_warp(
-            _cabi.ptr(img), _cabi.ptr(pts), _cabi.ptr(vals), N, C, H, W, Mp,
-            int(field_interpolation_order), float(field_regularization_weight),
-            int(not include_flow), _MODES[dense_interpolation_mode], _PADDINGS[dense_padding_mode],
-            _cabi.ptr(out), _cabi.ptr(flow), int(indexing == "hw"), _cabi.ptr(ws),
-            _cabi.stream_ptr(device),
-        )  # fmt: skip
-    _cabi.check(rc, "pdt_sparse_image_warp")
-    out = out.to(image.dtype)
-    return (out, flow) if include_flow else out
+        return warped
 
 
 def _spec_augment_check_input(feats: torch.Tensor, lengths: Optional[torch.Tensor] = None):
     # reference _img.py:1020-1041
     if feats.dim() != 3:
         raise RuntimeError("Expected feats to have three dimensions, got {}".format(feats.dim()))
-    N, T, _ = feats.shape
+    N, T = feats.size(0), feats.size(1)
     if lengths is not None:
         if lengths.dim() != 1:
             raise RuntimeError("Expected lengths to be one dimensional, got {}".format(lengths.dim()))
@@ -280,43 +444,43 @@ def spec_augment_draw_parameters(
     (w_0, w, v_0, v, t, t_0, f, f_0); six tiny launches, not on the bandwidth path.
     """
     _spec_augment_check_input(feats, lengths)
-    N, T, F = feats.shape
+    N, T, F = feats.size(0), feats.size(1), feats.size(2)
     device = feats.device
-    eps = torch.finfo(feats.dtype if feats.dtype.is_floating_point else torch.float).eps
+    eps = 1.1920928955078125e-07  # torch.finfo(torch.float).eps
+    if feats.dtype == torch.double:
+        eps = 2.220446049250313e-16
     omeps = 1 - eps
     if lengths is None:
-        lengths = torch.full((N,), T, dtype=torch.float, device=device)
+        lengths_ = torch.full((N,), T, dtype=torch.float, device=device)
     else:
-        lengths = lengths.to(device).float()
+        lengths_ = lengths.to(device).float()
     empty = torch.empty(0)
-    if max_time_warp:
-        Wt = (lengths / 2 - eps).clamp(0, max_time_warp)
-        w_0 = torch.rand((N,), device=device) * (lengths - 2 * Wt) + Wt
+    w_0, w, v_0, v, t_0, t, f_0, f = empty, empty, empty, empty, empty, empty, empty, empty
+    if max_time_warp != 0.0:
+        Wt = (lengths_ / 2 - eps).clamp(0, max_time_warp)
+        w_0 = torch.rand((N,), device=device) * (lengths_ - 2 * Wt) + Wt
         w = torch.rand((N,), device=device) * (2 * Wt) - Wt
-    else:
-        w_0 = w = empty
-    if max_freq_warp:
-        Vf = min(max(F / 2 - eps, 0), max_freq_warp)
+    if max_freq_warp != 0.0:
+        Vf = min(max(F / 2 - eps, 0.0), max_freq_warp)
         v_0 = torch.rand((N,), device=device) * (F - 2 * Vf) + Vf
         v = torch.rand((N,), device=device) * (2 * Vf) - Vf
-    else:
-        v_0 = v = empty
-    if max_time_mask and max_time_mask_proportion and num_time_mask and num_time_mask_proportion:
-        max_ = torch.clamp(lengths * max_time_mask_proportion, max=max_time_mask).floor()
-        nums_ = torch.clamp(lengths * num_time_mask_proportion, max=num_time_mask).floor()
+    if (
+        max_time_mask != 0
+        and max_time_mask_proportion != 0.0
+        and num_time_mask != 0
+        and num_time_mask_proportion != 0.0
+    ):
+        max_ = torch.clamp(lengths_ * max_time_mask_proportion, max=max_time_mask).floor()
+        nums_ = torch.clamp(lengths_ * num_time_mask_proportion, max=num_time_mask).floor()
         t = (torch.rand((N, num_time_mask), device=device) * (max_ + omeps).unsqueeze(1)).long()
         t = t.masked_fill(
-            nums_.unsqueeze(1) <= torch.arange(num_time_mask, dtype=lengths.dtype, device=device), 0
+            nums_.unsqueeze(1) <= torch.arange(num_time_mask, dtype=lengths_.dtype, device=device), 0
         )
-        t_0 = (torch.rand((N, num_time_mask), device=device) * (lengths.unsqueeze(1) - t + omeps)).long()
-    else:
-        t = t_0 = empty
-    if max_freq_mask and num_freq_mask:
-        max_ = min(max_freq_mask, F)
-        f = (torch.rand((N, num_freq_mask), device=device) * (max_ + omeps)).long()
+        t_0 = (torch.rand((N, num_time_mask), device=device) * (lengths_.unsqueeze(1) - t + omeps)).long()
+    if max_freq_mask != 0 and num_freq_mask != 0:
+        maxf_ = min(max_freq_mask, F)
+        f = (torch.rand((N, num_freq_mask), device=device) * (maxf_ + omeps)).long()
         f_0 = (torch.rand((N, num_freq_mask), device=device) * (F - f + omeps)).long()
-    else:
-        f = f_0 = empty
     return w_0, w, v_0, v, t_0, t, f_0, f
 
 
@@ -324,8 +488,19 @@ def _has(a: Optional[torch.Tensor], b: Optional[torch.Tensor]) -> bool:
     return a is not None and a.numel() > 0 and b is not None and b.numel() > 0
 
 
-def _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f):
-    device = feats.device
+@custom_op("pydrobert_amd::spec_augment_apply", mutates_args=())
+def _spec_augment_apply_op(
+    feats: torch.Tensor,
+    tgrid: Optional[torch.Tensor],
+    fgrid: Optional[torch.Tensor],
+    t_0: Optional[torch.Tensor],
+    t: Optional[torch.Tensor],
+    f_0: Optional[torch.Tensor],
+    f: Optional[torch.Tensor],
+) -> torch.Tensor:
+    """Time / frequency resampling through the 1-D grids, then band masks: ONE pass over
+    ``feats`` (csrc/img_warp.hip)."""
+    device = _cabi.require_hip(feats, tgrid, fgrid, t_0, t, f_0, f)
     N, T, F = feats.shape
     x = feats.detach()
     if x.dtype != torch.float:
@@ -340,42 +515,59 @@ def _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f):
             _cabi.ptr(f_0), _cabi.ptr(f), mf, _cabi.ptr(out), _cabi.stream_ptr(device),
         )  # fmt: skip
     _cabi.check(rc, "pdt_spec_augment_apply")
-    return out
+    return out.to(feats.dtype)
 
 
-class _SpecApplyFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, feats, tgrid, fgrid, t_0, t, f_0, f):
-        out = _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f)
-        ctx.grids = (tgrid, fgrid, t_0, t, f_0, f)
-        ctx.dtype = feats.dtype
-        return out.to(feats.dtype)
+@_spec_augment_apply_op.register_fake
+def _(feats, tgrid, fgrid, t_0, t, f_0, f):
+    return feats.new_empty(feats.shape)
 
-    @staticmethod
-    def backward(ctx, grad_out):
-        tgrid, fgrid, t_0, t, f_0, f = ctx.grids
-        N, T, F = grad_out.shape
-        dev = grad_out.device
-        g = grad_out.float()
-        # masked positions carry no gradient
-        if t_0 is not None:
-            ar = torch.arange(T, device=dev).view(1, T, 1)
-            m = ((ar >= t_0.unsqueeze(1)) & (ar < (t_0 + t).unsqueeze(1))).any(2, keepdim=True)
-            g = g.masked_fill(m, 0.0)
-        if f_0 is not None:
-            ar = torch.arange(F, device=dev).view(1, F, 1)
-            m = ((ar >= f_0.unsqueeze(1)) & (ar < (f_0 + f).unsqueeze(1))).any(2).unsqueeze(1)
-            g = g.masked_fill(m, 0.0)
-        if tgrid is None and fgrid is None:
-            return g.to(ctx.dtype), None, None, None, None, None, None
-        tg = tgrid if tgrid is not None else ((2 * torch.arange(T, device=dev, dtype=torch.float) + 1) / T - 1).expand(N, T)
-        fg = fgrid if fgrid is not None else ((2 * torch.arange(F, device=dev, dtype=torch.float) + 1) / F - 1).expand(N, F)
-        grid = torch.stack([fg.unsqueeze(1).expand(N, T, F), tg.unsqueeze(2).expand(N, T, F)], 3)
-        with torch.enable_grad():
-            probe = torch.zeros((N, 1, T, F), device=dev, dtype=torch.float, requires_grad=True)
-            o = torch.nn.functional.grid_sample(probe, grid, mode="bilinear", padding_mode="border", align_corners=False)
-            (gi,) = torch.autograd.grad(o, probe, g.unsqueeze(1))
-        return gi.squeeze(1).to(ctx.dtype), None, None, None, None, None, None
+
+@custom_op("pydrobert_amd::spec_augment_apply_backward", mutates_args=())
+def _spec_augment_apply_backward_op(
+    grad_out: torch.Tensor,
+    tgrid: Optional[torch.Tensor],
+    fgrid: Optional[torch.Tensor],
+    t_0: Optional[torch.Tensor],
+    t: Optional[torch.Tensor],
+    f_0: Optional[torch.Tensor],
+    f: Optional[torch.Tensor],
+) -> torch.Tensor:
+    """Adjoint of ``spec_augment_apply`` with respect to the features (masked positions carry
+    no gradient; the others scatter theirs to their taps)."""
+    device = _cabi.require_hip(grad_out, tgrid, fgrid, t_0, t, f_0, f)
+    g = _f32c(grad_out)
+    N, T, F = g.shape
+    mt = 0 if t_0 is None else t_0.shape[1]
+    mf = 0 if f_0 is None else f_0.shape[1]
+    with torch.cuda.device(device):
+        grad = torch.empty_like(g)
+        rc = _cabi.lib().pdt_spec_augment_apply_backward(
+            _cabi.ptr(g), N, T, F, _cabi.ptr(tgrid), _cabi.ptr(fgrid), _cabi.ptr(t_0),
+            _cabi.ptr(t), mt, _cabi.ptr(f_0), _cabi.ptr(f), mf, _cabi.ptr(grad),
+            _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_spec_augment_apply_backward")
+    return grad.to(grad_out.dtype)
+
+
+@_spec_augment_apply_backward_op.register_fake
+def _(grad_out, tgrid, fgrid, t_0, t, f_0, f):
+    return grad_out.new_empty(grad_out.shape)
+
+
+def _spec_setup_context(ctx, inputs, output):
+    ctx.grids = tuple(inputs[1:])
+
+
+def _spec_backward(ctx, grad_out):
+    g = torch.ops.pydrobert_amd.spec_augment_apply_backward(grad_out, *ctx.grids)
+    return g, None, None, None, None, None, None
+
+
+register_autograd(
+    "pydrobert_amd::spec_augment_apply", _spec_backward, setup_context=_spec_setup_context
+)
 
 
 def spec_augment_apply_parameters(
@@ -388,33 +580,33 @@ def spec_augment_apply_parameters(
     _img.py:1142-1211): time / frequency warp by bilinear resampling, then band masks, as ONE
     pass over ``feats`` (plus two tiny grid kernels)."""
     _spec_augment_check_input(feats, lengths)
-    device = _cabi.require_hip(feats)
-    N, T, F = feats.shape
+    device = feats.device
+    N, T, F = feats.size(0), feats.size(1), feats.size(2)
     if lengths is None:
-        lengths = torch.full((N,), T, dtype=torch.long, device=device)
-    lengths = lengths.to(device)
+        lengths_ = torch.full((N,), T, dtype=torch.long, device=device)
+    else:
+        lengths_ = lengths.to(device)
     w_0, w, v_0, v, t_0, t, f_0, f = params
-    tgrid = fgrid = None
+    tgrid: Optional[torch.Tensor] = None
+    fgrid: Optional[torch.Tensor] = None
+    t0_: Optional[torch.Tensor] = None
+    t_: Optional[torch.Tensor] = None
+    f0_: Optional[torch.Tensor] = None
+    f_: Optional[torch.Tensor] = None
     if _has(w_0, w):
-        tgrid = warp_1d_grid(w_0.to(device), w.to(device), lengths, T, interpolation_order)
+        tgrid = warp_1d_grid(w_0.to(device), w.to(device), lengths_, T, interpolation_order)
     if _has(v_0, v):
         fgrid = warp_1d_grid(
             v_0.to(device), v.to(device), torch.full((N,), F, dtype=torch.long, device=device), F,
             interpolation_order,
         )  # fmt: skip
     if _has(t_0, t):
-        t_0, t = t_0.to(device).long().contiguous(), t.to(device).long().contiguous()
-    else:
-        t_0 = t = None
+        t0_, t_ = t_0.to(device).long().contiguous(), t.to(device).long().contiguous()
     if _has(f_0, f):
-        f_0, f = f_0.to(device).long().contiguous(), f.to(device).long().contiguous()
-    else:
-        f_0 = f = None
-    if tgrid is None and fgrid is None and t_0 is None and f_0 is None:
+        f0_, f_ = f_0.to(device).long().contiguous(), f.to(device).long().contiguous()
+    if tgrid is None and fgrid is None and t0_ is None and f0_ is None:
         return feats
-    if feats.requires_grad and torch.is_grad_enabled():
-        return _SpecApplyFn.apply(feats, tgrid, fgrid, t_0, t, f_0, f)
-    return _spec_apply_raw(feats, tgrid, fgrid, t_0, t, f_0, f).to(feats.dtype)
+    return torch.ops.pydrobert_amd.spec_augment_apply(feats, tgrid, fgrid, t0_, t_, f0_, f_)
 
 
 def spec_augment(
@@ -460,7 +652,9 @@ class PolyharmonicSpline(_ReprMixin, torch.nn.Module):
         super().__init__()
         self.order, self.regularization_weight, self.full_matrix = order, regularization_weight, full_matrix
 
-    def forward(self, train_points, train_values, query_points) -> torch.Tensor:
+    def forward(
+        self, train_points: torch.Tensor, train_values: torch.Tensor, query_points: torch.Tensor
+    ) -> torch.Tensor:
         return polyharmonic_spline(
             train_points, train_values, query_points, self.order, self.regularization_weight,
             self.full_matrix,
@@ -485,7 +679,7 @@ class Warp1DGrid(torch.nn.Module):
             s = "max_length={}, ".format(self.max_length) + s
         return s
 
-    def forward(self, src, flow, lengths) -> torch.Tensor:
+    def forward(self, src: torch.Tensor, flow: torch.Tensor, lengths: torch.Tensor) -> torch.Tensor:
         return warp_1d_grid(src, flow, lengths, self.max_length, self.interpolation_order)
 
 
@@ -544,7 +738,9 @@ class SparseImageWarp(_ReprMixin, torch.nn.Module):
         self.dense_padding_mode = dense_padding_mode
         self.include_flow = include_flow
 
-    def forward(self, image, source_points, dest_points) -> Any:
+    def forward(
+        self, image: torch.Tensor, source_points: torch.Tensor, dest_points: torch.Tensor
+    ) -> Any:
         return sparse_image_warp(
             image, source_points, dest_points, self.indexing, self.field_interpolation_order,
             self.field_regularization_weight, self.field_full_matrix, self.pinned_boundary_points,
@@ -599,16 +795,23 @@ class SpecAugment(torch.nn.Module):
             s += ",warp_f={}".format(self.max_freq_warp)
         return s
 
-    def draw_parameters(self, feats, lengths: Optional[torch.Tensor] = None) -> SpecAugmentParams:
+    @torch.jit.export
+    def draw_parameters(
+        self, feats: torch.Tensor, lengths: Optional[torch.Tensor] = None
+    ) -> SpecAugmentParams:
         return spec_augment_draw_parameters(
             feats, self.max_time_warp, self.max_freq_warp, self.max_time_mask, self.max_freq_mask,
             self.max_time_mask_proportion, self.num_time_mask, self.num_time_mask_proportion,
             self.num_freq_mask, lengths,
         )  # fmt: skip
 
-    def apply_parameters(self, feats, params, lengths: Optional[torch.Tensor] = None) -> torch.Tensor:
+    @torch.jit.export
+    def apply_parameters(
+        self, feats: torch.Tensor, params: SpecAugmentParams, lengths: Optional[torch.Tensor] = None
+    ) -> torch.Tensor:
         return spec_augment_apply_parameters(feats, params, self.interpolation_order, lengths)
 
+    @torch.jit.export
     def reset_parameters(self) -> None:
         pass
 

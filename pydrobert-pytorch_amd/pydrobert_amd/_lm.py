@@ -69,32 +69,38 @@ class SequentialLanguageModel(torch.nn.Module, metaclass=abc.ABCMeta):
         prev: Optional[Dict[str, torch.Tensor]] = None,
         idx: Optional[Any] = None,
     ) -> Any:
-        if prev is None:
-            prev = dict()
+        prev_: Dict[str, torch.Tensor] = dict()
+        if prev is not None:
+            prev_ = prev
         if hist.dim() != 2:
             raise RuntimeError("hist must be 2 dimensional")
-        S, N = hist.shape
-        idx_ = None
-        if idx is not None:
-            idx_ = torch.as_tensor(idx, dtype=torch.long, device=hist.device)
-            if not idx_.numel():
-                raise RuntimeError("idx_ must be at least one element")
-            if idx_.dim() == 1:
-                if idx_.size(0) == 1:
-                    idx_ = idx_.squeeze(0)
-                elif idx_.size(0) != N:
-                    raise RuntimeError(
-                        "Expected dim 0 of idx_ to be of size {}, got {}".format(N, idx_.size(0))
-                    )
-            if bool(((idx_ < -S - 1) | (idx_ > S)).any()):
+        prev_ = self.update_input(prev_, hist)
+        if idx is None:
+            return self.calc_full_log_probs(hist, prev_)
+        if isinstance(idx, int):
+            return self._at(hist, prev_, torch.as_tensor(idx, dtype=torch.long, device=hist.device))
+        elif isinstance(idx, torch.Tensor):
+            return self._at(hist, prev_, idx.to(device=hist.device, dtype=torch.long))
+        else:
+            raise RuntimeError("idx must be an int or a tensor")
+
+    def _at(
+        self, hist: torch.Tensor, prev: Dict[str, torch.Tensor], idx: torch.Tensor
+    ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        S, N = hist.size(0), hist.size(1)
+        if not idx.numel():
+            raise RuntimeError("idx_ must be at least one element")
+        if idx.dim() == 1:
+            if idx.size(0) == 1:
+                idx = idx.squeeze(0)
+            elif idx.size(0) != N:
                 raise RuntimeError(
-                    "All values in idx_ must be between ({}, {})".format(-S - 1, S)
+                    "Expected dim 0 of idx_ to be of size {}, got {}".format(N, idx.size(0))
                 )
-            idx_ = (idx_ + S + 1) % (S + 1)
-        prev = self.update_input(prev, hist)
-        if idx_ is None:
-            return self.calc_full_log_probs(hist, prev)
-        return self.calc_idx_log_probs(hist, prev, idx_)
+        if bool(((idx < -S - 1) | (idx > S)).any()):
+            raise RuntimeError("All values in idx_ must be between ({}, {})".format(-S - 1, S))
+        idx = (idx + S + 1) % (S + 1)
+        return self.calc_idx_log_probs(hist, prev, idx)
 
 
 class ExtractableSequentialLanguageModel(SequentialLanguageModel, metaclass=abc.ABCMeta):

@@ -7,9 +7,10 @@ runs in ``csrc/lev_skewed.hip`` / ``csrc/lev_rowsync.hip`` through ``pdt_lev``,
 """
 
 import warnings
-from typing import Optional
+from typing import Optional, Tuple
 
 import torch
+from torch.library import custom_op, register_autograd
 
 from . import _cabi, argcheck, config
 
@@ -101,7 +102,8 @@ def _emit_warnings(flags: int, eos, prefix: bool):
             )
 
 
-def _string_matching(
+@custom_op("pydrobert_amd::string_matching", mutates_args=())
+def _string_matching_op(
     ref: torch.Tensor,
     hyp: torch.Tensor,
     eos: Optional[int],
@@ -111,11 +113,11 @@ def _string_matching(
     del_cost: float,
     sub_cost: float,
     warn: bool,
-    norm: bool = False,
-    return_prf_dsts: bool = False,
-    exclude_last: bool = False,
-    padding: int = config.INDEX_PAD_VALUE,
-    return_mistakes: bool = False,
+    norm: bool,
+    return_prf_dsts: bool,
+    exclude_last: bool,
+    padding: int,
+    return_mistakes: bool,
 ) -> torch.Tensor:
     """FINAL / PREFIX flavours of the reference's ``_string_matching`` (_string.py:146-406)."""
     device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N = _prep(ref, hyp, batch_first)
@@ -155,6 +157,40 @@ def _string_matching(
     if return_prf_dsts and batch_first:
         out = out.t()  # _string.py:387-388
     return out
+
+
+@_string_matching_op.register_fake
+def _(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn, norm,
+      return_prf_dsts, exclude_last, padding, return_mistakes):  # fmt: skip
+    N = ref.shape[0] if batch_first else ref.shape[1]
+    if not return_prf_dsts:
+        return ref.new_empty((N,), dtype=torch.float)
+    Hout = (hyp.shape[1] if batch_first else hyp.shape[0]) + (0 if exclude_last else 1)
+    out = ref.new_empty((Hout, N), dtype=torch.float)
+    return out.t() if batch_first else out
+
+
+def _string_matching(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int],
+    include_eos: bool,
+    batch_first: bool,
+    ins_cost: float,
+    del_cost: float,
+    sub_cost: float,
+    warn: bool,
+    norm: bool = False,
+    return_prf_dsts: bool = False,
+    exclude_last: bool = False,
+    padding: int = config.INDEX_PAD_VALUE,
+    return_mistakes: bool = False,
+) -> torch.Tensor:
+    """TorchScript-visible entry: one opaque ``pydrobert_amd::string_matching`` node."""
+    return torch.ops.pydrobert_amd.string_matching(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, warn, norm,
+        return_prf_dsts, exclude_last, padding, return_mistakes,
+    )  # fmt: skip
 
 
 def error_rate(
@@ -238,25 +274,23 @@ def prefix_edit_distances(
     )  # fmt: skip
 
 
-def optimal_completion(
+@custom_op("pydrobert_amd::optimal_completion", mutates_args=())
+def _optimal_completion_op(
     ref: torch.Tensor,
     hyp: torch.Tensor,
-    eos: Optional[int] = None,
-    include_eos: bool = True,
-    batch_first: bool = False,
-    ins_cost: float = config.DEFT_INS_COST,
-    del_cost: float = config.DEFT_DEL_COST,
-    sub_cost: float = config.DEFT_SUB_COST,
-    padding: int = config.INDEX_PAD_VALUE,
-    exclude_last: bool = False,
-    warn: bool = True,
+    eos: Optional[int],
+    include_eos: bool,
+    batch_first: bool,
+    ins_cost: float,
+    del_cost: float,
+    sub_cost: float,
+    padding: int,
+    exclude_last: bool,
+    warn: bool,
 ) -> torch.Tensor:
-    """Functional version of :class:`OptimalCompletion` (reference _string.py:464-517).
-
-    Two kernels with one host read-back in between, like the reference's
-    ``counts.max().item()`` (:511): the DP emits per-prefix class bitmasks plus the
-    maximum set size ``C``; the expansion writes the ``(H', N, C)`` int64 targets.
-    """
+    """Two kernels with one host read-back in between, like the reference's
+    ``counts.max().item()`` (_string.py:511): the DP emits per-prefix class bitmasks plus the
+    maximum set size ``C``; the expansion writes the ``(H', N, C)`` int64 targets."""
     device, bitmask, class_tokens, scal, (R, Hout, N) = _oc_mask(
         ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, exclude_last, warn,
         "pdt_oc_mask",
@@ -277,6 +311,36 @@ def optimal_completion(
     if batch_first:
         targets = targets.transpose(0, 1)  # _string.py:515-516
     return targets
+
+
+@_optimal_completion_op.register_fake
+def _(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, padding,
+      exclude_last, warn):  # fmt: skip
+    N = ref.shape[0] if batch_first else ref.shape[1]
+    Hout = (hyp.shape[1] if batch_first else hyp.shape[0]) + (0 if exclude_last else 1)
+    C = torch.library.get_ctx().new_dynamic_size()  # the data-dependent set size (:511)
+    out = ref.new_empty((Hout, N, C), dtype=torch.long)
+    return out.transpose(0, 1) if batch_first else out
+
+
+def optimal_completion(
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int] = None,
+    include_eos: bool = True,
+    batch_first: bool = False,
+    ins_cost: float = config.DEFT_INS_COST,
+    del_cost: float = config.DEFT_DEL_COST,
+    sub_cost: float = config.DEFT_SUB_COST,
+    padding: int = config.INDEX_PAD_VALUE,
+    exclude_last: bool = False,
+    warn: bool = True,
+) -> torch.Tensor:
+    """Functional version of :class:`OptimalCompletion` (reference _string.py:464-517)."""
+    return torch.ops.pydrobert_amd.optimal_completion(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, padding,
+        exclude_last, warn,
+    )  # fmt: skip
 
 
 def _oc_mask(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, exclude_last,
@@ -303,46 +367,132 @@ def _oc_mask(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_co
     return device, bitmask, class_tokens, scal, (R, Hout, N)
 
 
-class _OcdLossFn(torch.autograd.Function):
-    """loss[h, n] of the fused distillation kernel; differentiable w.r.t. logits (H, N, V view)."""
+@custom_op("pydrobert_amd::ocd_loss_rows", mutates_args=())
+def _ocd_loss_rows_op(
+    logits: torch.Tensor,
+    ref: torch.Tensor,
+    hyp: torch.Tensor,
+    eos: Optional[int],
+    include_eos: bool,
+    batch_first: bool,
+    ins_cost: float,
+    del_cost: float,
+    sub_cost: float,
+    weight: Optional[torch.Tensor],
+    ignore_index: int,
+    warn: bool,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    """(loss (H, N), count (H, N), bitmask, class_tokens): the DP kernel's class bitmasks go
+    straight into the fused cross-entropy kernel; the last two outputs are what the backward
+    kernel needs.  Differentiable w.r.t. ``logits``."""
+    if logits.dim() != 3:
+        raise RuntimeError("logits must be 3 dimensional")
+    if logits.shape[:-1] != hyp.shape:
+        raise RuntimeError("first two dims of logits must match hyp shape")
+    if include_eos:
+        if eos is not None and ((eos < 0) or (eos >= logits.size(-1))):
+            raise RuntimeError("If include_eos=True, eos ({}) must be a class idx".format(eos))
+        if eos is not None and eos == ignore_index:
+            raise RuntimeError("If include_eos=True, eos cannot equal ignore_index ({}".format(eos))
+    _cabi.require_hip(logits, weight)
+    device, bitmask, class_tokens, scal, (R, H, N) = _oc_mask(
+        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, True, warn,
+        "pdt_oc_mask",
+    )  # fmt: skip
+    x = logits.detach()
+    if batch_first:
+        x = x.transpose(0, 1)
+    if x.dtype != torch.float:
+        x = x.float()
+    V = x.shape[2]
+    w = None if weight is None else weight.detach().float().contiguous()
+    with torch.cuda.device(device):
+        loss = torch.empty((H, N), device=device, dtype=torch.float)
+        count = torch.empty((H, N), device=device, dtype=torch.int32)
+        rc = _cabi.lib().pdt_ocd_loss_forward(
+            _cabi.ptr(x), H, N, V, x.stride(0), x.stride(1), x.stride(2), _cabi.ptr(bitmask),
+            _cabi.ptr(class_tokens), max(R, 1), _cabi.ptr(w), int(ignore_index), _cabi.ptr(loss),
+            _cabi.ptr(count), scal.data_ptr() + 8, _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_ocd_loss_forward")
+    if warn:
+        _, flags, bad = (int(x) for x in scal.tolist())
+        if bad:
+            raise RuntimeError("ref contains tokens that are not class indices of logits")
+        _emit_warnings(flags, eos, True)
+    return loss, count, bitmask, class_tokens
 
-    @staticmethod
-    def forward(ctx, logits_hnv, bitmask, class_tokens, weight, ignore_index, R, status):
-        device = logits_hnv.device
-        H, N, V = logits_hnv.shape
-        x = logits_hnv.detach()
-        if x.dtype != torch.float:
-            x = x.float()
-        with torch.cuda.device(device):
-            loss = torch.empty((H, N), device=device, dtype=torch.float)
-            count = torch.empty((H, N), device=device, dtype=torch.int32)
-            rc = _cabi.lib().pdt_ocd_loss_forward(
-                _cabi.ptr(x), H, N, V, x.stride(0), x.stride(1), x.stride(2), _cabi.ptr(bitmask),
-                _cabi.ptr(class_tokens), R, _cabi.ptr(weight), int(ignore_index), _cabi.ptr(loss),
-                _cabi.ptr(count), _cabi.ptr(status), _cabi.stream_ptr(device),
-            )  # fmt: skip
-        _cabi.check(rc, "pdt_ocd_loss_forward")
-        ctx.save_for_backward(x, bitmask, class_tokens, weight)
-        ctx.cfg = (int(ignore_index), R, logits_hnv.dtype)
-        ctx.mark_non_differentiable(count)
-        return loss, count
 
-    @staticmethod
-    def backward(ctx, grad_loss, _grad_count):
-        x, bitmask, class_tokens, weight = ctx.saved_tensors
-        ignore_index, R, dtype = ctx.cfg
-        H, N, V = x.shape
-        device = x.device
-        g = grad_loss.detach().float().contiguous()
-        with torch.cuda.device(device):
-            grad = torch.empty((H, N, V), device=device, dtype=torch.float)
-            rc = _cabi.lib().pdt_ocd_loss_backward(
-                _cabi.ptr(x), H, N, V, x.stride(0), x.stride(1), x.stride(2), _cabi.ptr(bitmask),
-                _cabi.ptr(class_tokens), R, _cabi.ptr(weight), ignore_index, _cabi.ptr(g),
-                _cabi.ptr(grad), _cabi.stream_ptr(device),
-            )  # fmt: skip
-        _cabi.check(rc, "pdt_ocd_loss_backward")
-        return grad.to(dtype), None, None, None, None, None, None
+@_ocd_loss_rows_op.register_fake
+def _(logits, ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, weight,
+      ignore_index, warn):  # fmt: skip
+    N, H = (hyp.shape[0], hyp.shape[1]) if batch_first else (hyp.shape[1], hyp.shape[0])
+    R = max(ref.shape[1] if batch_first else ref.shape[0], 1)
+    return (
+        logits.new_empty((H, N), dtype=torch.float),
+        logits.new_empty((H, N), dtype=torch.int32),
+        logits.new_empty((H, N, (R + 31) // 32), dtype=torch.int32),
+        logits.new_empty((N, R), dtype=torch.long),
+    )
+
+
+@custom_op("pydrobert_amd::ocd_loss_rows_backward", mutates_args=())
+def _ocd_loss_rows_backward_op(
+    logits: torch.Tensor,
+    bitmask: torch.Tensor,
+    class_tokens: torch.Tensor,
+    weight: Optional[torch.Tensor],
+    ignore_index: int,
+    batch_first: bool,
+    grad_loss: torch.Tensor,
+) -> torch.Tensor:
+    """d loss / d logits of ``ocd_loss_rows`` (csrc/ocd_loss.hip, BACKWARD)."""
+    device = logits.device
+    x = logits.detach()
+    if batch_first:
+        x = x.transpose(0, 1)
+    if x.dtype != torch.float:
+        x = x.float()
+    H, N, V = x.shape
+    w = None if weight is None else weight.detach().float().contiguous()
+    g = grad_loss.detach().float().contiguous()
+    with torch.cuda.device(device):
+        grad = torch.empty((H, N, V), device=device, dtype=torch.float)
+        rc = _cabi.lib().pdt_ocd_loss_backward(
+            _cabi.ptr(x), H, N, V, x.stride(0), x.stride(1), x.stride(2), _cabi.ptr(bitmask),
+            _cabi.ptr(class_tokens), class_tokens.shape[1], _cabi.ptr(w), int(ignore_index),
+            _cabi.ptr(g), _cabi.ptr(grad), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_ocd_loss_backward")
+    if batch_first:
+        grad = grad.transpose(0, 1)
+    return grad.to(logits.dtype)
+
+
+@_ocd_loss_rows_backward_op.register_fake
+def _(logits, bitmask, class_tokens, weight, ignore_index, batch_first, grad_loss):
+    return torch.empty_like(logits)
+
+
+def _ocd_setup_context(ctx, inputs, output):
+    logits, _, _, _, _, batch_first, _, _, _, weight, ignore_index, _ = inputs
+    _, _, bitmask, class_tokens = output
+    ctx.save_for_backward(logits, bitmask, class_tokens, weight)
+    ctx.cfg = (ignore_index, batch_first)
+
+
+def _ocd_backward(ctx, grad_loss, _gc, _gb, _gt):
+    logits, bitmask, class_tokens, weight = ctx.saved_tensors
+    ignore_index, batch_first = ctx.cfg
+    grad = torch.ops.pydrobert_amd.ocd_loss_rows_backward(
+        logits, bitmask, class_tokens, weight, ignore_index, batch_first, grad_loss
+    )
+    return (grad,) + (None,) * 11
+
+
+register_autograd(
+    "pydrobert_amd::ocd_loss_rows", _ocd_backward, setup_context=_ocd_setup_context
+)
 
 
 def hard_optimal_completion_distillation_loss(
@@ -365,33 +515,14 @@ def hard_optimal_completion_distillation_loss(
 
     The completion sets never leave their compact form: the DP kernel emits per-prefix class
     bitmasks and one fused kernel evaluates the mean cross entropy over each set straight from
-    the logits -- no ``(H, N, C)`` target tensor, no ``(H, N, C, V)`` logit expansion, no host
-    read-back.
+    the logits -- no ``(H, N, C)`` target tensor, no ``(H, N, C, V)`` logit expansion.
     """
-    if logits.dim() != 3:
-        raise RuntimeError("logits must be 3 dimensional")
-    if logits.shape[:-1] != hyp.shape:
-        raise RuntimeError("first two dims of logits must match hyp shape")
-    if include_eos:
-        if eos is not None and ((eos < 0) or (eos >= logits.size(-1))):
-            raise RuntimeError("If include_eos=True, eos ({}) must be a class idx".format(eos))
-        if eos is not None and eos == ignore_index:
-            raise RuntimeError("If include_eos=True, eos cannot equal ignore_index ({}".format(eos))
-    if reduction not in ("mean", "sum", "none"):
+    if reduction != "mean" and reduction != "sum" and reduction != "none":
         raise RuntimeError("'{}' is not a valid value for reduction".format(reduction))
-    _cabi.require_hip(logits, weight)
-    device, bitmask, class_tokens, scal, (R, H, N) = _oc_mask(
-        ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, True, warn,
-        "pdt_oc_mask",
+    loss, count, _, _ = torch.ops.pydrobert_amd.ocd_loss_rows(
+        logits, ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, weight,
+        ignore_index, warn,
     )  # fmt: skip
-    logits_hnv = logits.transpose(0, 1) if batch_first else logits
-    w = None if weight is None else weight.detach().float().contiguous()
-    loss, count = _OcdLossFn.apply(logits_hnv, bitmask, class_tokens, w, ignore_index, max(R, 1), scal[2:])
-    if warn:
-        _, flags, bad = (int(x) for x in scal.tolist())
-        if bad:
-            raise RuntimeError("ref contains tokens that are not class indices of logits")
-        _emit_warnings(flags, eos, True)
     if reduction == "mean":
         # per utterance: sum over prefixes / number of prefixes with a non-empty set, then the
         # batch mean (:1243-1247)
@@ -426,27 +557,37 @@ def minimum_error_rate_loss(
         raise RuntimeError("log_probs must be 2 dimensional")
     if hyp.dim() != 3:
         raise RuntimeError("hyp must be 3 dimensional")
-    if ref.dim() not in (2, 3):
+    if ref.dim() != 2 and ref.dim() != 3:
         raise RuntimeError("ref must be 2 or 3 dimensional")
     if batch_first:
-        batch_size, samples, max_hyp_steps = hyp.shape
+        batch_size, samples, max_hyp_steps = hyp.size(0), hyp.size(1), hyp.size(2)
         if ref.dim() == 2:
             ref = ref.unsqueeze(1).repeat(1, samples, 1)
-        if (ref.shape[:2] != (batch_size, samples)) or (ref.shape[:2] != log_probs.shape):
+        if (
+            ref.size(0) != batch_size
+            or ref.size(1) != samples
+            or log_probs.size(0) != batch_size
+            or log_probs.size(1) != samples
+        ):
             raise RuntimeError("ref and hyp batch_size and sample dimensions must match")
         ref = ref.reshape(-1, ref.size(-1))
         hyp = hyp.reshape(-1, max_hyp_steps)
     else:
-        max_hyp_steps, batch_size, samples = hyp.shape
+        max_hyp_steps, batch_size, samples = hyp.size(0), hyp.size(1), hyp.size(2)
         if ref.dim() == 2:
             ref = ref.unsqueeze(-1).repeat(1, 1, samples)
-        if (ref.shape[1:] != (batch_size, samples)) or (ref.shape[1:] != log_probs.shape):
+        if (
+            ref.size(1) != batch_size
+            or ref.size(2) != samples
+            or log_probs.size(0) != batch_size
+            or log_probs.size(1) != samples
+        ):
             raise RuntimeError("ref and hyp batch_size and sample dimensions must match")
         ref = ref.reshape(ref.size(0), -1)
         hyp = hyp.reshape(max_hyp_steps, -1)
     if samples < 2:
         raise RuntimeError("Batch must have at least two samples, got {}".format(samples))
-    if reduction not in ("mean", "sum", "none"):
+    if reduction != "mean" and reduction != "sum" and reduction != "none":
         raise RuntimeError("'{}' is not a valid value for reduction".format(reduction))
     er = error_rate(
         ref, hyp, eos=eos, include_eos=include_eos, norm=norm, batch_first=batch_first,
@@ -700,7 +841,9 @@ class HardOptimalCompletionDistillationLoss(torch.nn.Module):
     def extra_repr(self) -> str:
         return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
 
-    def forward(self, logits, ref, hyp, warn: bool = True) -> torch.Tensor:
+    def forward(
+        self, logits: torch.Tensor, ref: torch.Tensor, hyp: torch.Tensor, warn: bool = True
+    ) -> torch.Tensor:
         return hard_optimal_completion_distillation_loss(
             logits, ref, hyp, self.eos, self.include_eos, self.batch_first, self.ins_cost,
             self.del_cost, self.sub_cost, self.weight, self.reduction, self.ignore_index, warn,
@@ -745,7 +888,9 @@ class MinimumErrorRateLoss(torch.nn.Module):
     def extra_repr(self) -> str:
         return ", ".join("{}={}".format(x, getattr(self, x)) for x in self.__constants__)
 
-    def forward(self, log_probs, ref, hyp, warn: bool = True) -> torch.Tensor:
+    def forward(
+        self, log_probs: torch.Tensor, ref: torch.Tensor, hyp: torch.Tensor, warn: bool = True
+    ) -> torch.Tensor:
         return minimum_error_rate_loss(
             log_probs, ref, hyp, self.eos, self.include_eos, self.sub_avg, self.batch_first,
             self.norm, self.ins_cost, self.del_cost, self.sub_cost, self.reduction, warn,

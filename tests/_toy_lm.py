@@ -26,3 +26,43 @@ class BigramLM(MixableSequentialLanguageModel):
 
     def mix_by_mask(self, prev_true, prev_false, mask):
         return prev_true
+
+
+from typing import Dict, Tuple  # noqa: E402
+
+
+class ScriptableBigramLM(MixableSequentialLanguageModel):
+    """The same model with the type annotations / exports TorchScript needs."""
+
+    def __init__(self, table: torch.Tensor):
+        super().__init__(table.shape[1])
+        self.register_buffer("table", table)
+
+    @torch.jit.export
+    def calc_idx_log_probs(
+        self, hist: torch.Tensor, prev: Dict[str, torch.Tensor], idx: torch.Tensor
+    ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        V = self.vocab_size
+        N = hist.shape[1]
+        if idx.dim() == 0:
+            idx = idx.expand(N)
+        prev_tok = torch.full((N,), V, dtype=torch.long, device=hist.device)
+        if hist.shape[0]:
+            last = hist.gather(0, (idx - 1).clamp(min=0).unsqueeze(0)).squeeze(0).clamp(0, V - 1)
+            prev_tok = torch.where(idx > 0, last, prev_tok)
+        return self.table[prev_tok], prev
+
+    @torch.jit.export
+    def extract_by_src(
+        self, prev: Dict[str, torch.Tensor], src: torch.Tensor
+    ) -> Dict[str, torch.Tensor]:
+        return prev
+
+    @torch.jit.export
+    def mix_by_mask(
+        self,
+        prev_true: Dict[str, torch.Tensor],
+        prev_false: Dict[str, torch.Tensor],
+        mask: torch.Tensor,
+    ) -> Dict[str, torch.Tensor]:
+        return prev_true

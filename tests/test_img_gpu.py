@@ -172,3 +172,108 @@ def test_sparse_image_warp(device, pinned, include_flow):
     e = torch.zeros((N, 0, 2), device=device)
     out = F.sparse_image_warp(_t(img, device), e, e, include_flow=False)
     assert torch.equal(out.cpu(), torch.from_numpy(img))
+
+
+def _adjoint_gap(op, x):
+    """<op(x + d) - op(x), g> vs <d, op^T g> for an operator that is linear in x."""
+    x = x.clone().requires_grad_(True)
+    y = op(x)
+    g = torch.randn_like(y)
+    (gx,) = torch.autograd.grad(y, x, g)
+    d = torch.randn_like(x)
+    lhs = ((op(x.detach() + d) - y.detach()) * g).sum()
+    rhs = (gx * d).sum()
+    return lhs.item(), rhs.item(), gx
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+@pytest.mark.parametrize("padding", ["border", "zeros", "reflection"])
+def test_dense_image_warp_backward(device, mode, padding):
+    """HIP adjoint kernel against autograd through torch's own grid_sample (what the reference
+    differentiates, _img.py:436)."""
+    torch.manual_seed(11)
+    N, C, H, W = 3, 2, 14, 11
+    img = torch.randn(N, C, H, W, device=device)
+    flow = torch.randn(N, H, W, 2, device=device) * 3
+    if mode == "nearest":
+        flow = (flow * 4).round() / 4 + 0.1
+    lhs, rhs, gx = _adjoint_gap(lambda x: F.dense_image_warp(x, flow, "hw", mode, padding), img)
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs)), (lhs, rhs)
+    # direct comparison with grid_sample's backward
+    x = img.clone().requires_grad_(True)
+    hh, ww = torch.meshgrid(torch.arange(H, device=device), torch.arange(W, device=device), indexing="ij")
+    base = torch.stack((ww, hh), 2).unsqueeze(0).float()
+    grid = (2 * base - 2 * flow.flip(-1) + 1.0) / torch.tensor([W, H], device=device).float() - 1.0
+    y = torch.nn.functional.grid_sample(x, grid, mode=mode, padding_mode=padding, align_corners=False)
+    torch.manual_seed(12)
+    g = torch.randn_like(y)
+    (exp,) = torch.autograd.grad(y, x, g)
+    x2 = img.clone().requires_grad_(True)
+    (act,) = torch.autograd.grad(F.dense_image_warp(x2, flow, "hw", mode, padding), x2, g)
+    assert torch.allclose(exp, act, atol=1e-4), (exp - act).abs().max().item()
+
+
+@pytest.mark.parametrize("include_flow", [True, False])
+def test_sparse_image_warp_backward(device, include_flow):
+    torch.manual_seed(13)
+    N, C, H, W, Mp = 2, 3, 12, 10, 5
+    img = torch.rand(N, C, H, W, device=device)
+    src = torch.rand(N, Mp, 2, device=device) * torch.tensor([H - 1.0, W - 1.0], device=device)
+    dst = src + torch.randn(N, Mp, 2, device=device)
+
+    def op(x):
+        out = F.sparse_image_warp(x, src, dst, pinned_boundary_points=1, include_flow=include_flow)
+        return out[0] if include_flow else out
+
+    lhs, rhs, _ = _adjoint_gap(op, img)
+    assert abs(lhs - rhs) <= 1e-3 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
+def test_spec_augment_backward_matches_grid_sample(device):
+    """Gradient of the fused apply kernel's adjoint against autograd through the reference's
+    formulation: grid_sample over the outer product of the two 1-D grids, then masks."""
+    torch.manual_seed(14)
+    N, T, Fq = 5, 60, 12
+    feats = torch.randn(N, T, Fq, device=device)
+    lens = torch.tensor([60, 45, 33, 60, 20], device=device)
+    for params in (
+        (torch.tensor([20.0, 10, 15, 30, 8], device=device), torch.tensor([3.0, -2, 1.5, -4, 2], device=device),
+         torch.tensor([5.0, 6, 4, 7, 5], device=device), torch.tensor([1.0, -1, 0.5, 1.5, -0.5], device=device),
+         torch.tensor([[3], [0], [10], [50], [2]], device=device), torch.tensor([[4], [2], [0], [5], [3]], device=device),
+         torch.tensor([[1], [8], [3], [0], [6]], device=device), torch.tensor([[2], [3], [1], [0], [4]], device=device)),
+        (torch.tensor([20.0, 10, 15, 30, 8], device=device), torch.tensor([3.0, -2, 1.5, -4, 2], device=device),
+         torch.empty(0), torch.empty(0), torch.empty(0), torch.empty(0), torch.empty(0), torch.empty(0)),
+        (torch.empty(0), torch.empty(0), torch.empty(0), torch.empty(0),
+         torch.tensor([[3], [0], [10], [50], [2]], device=device), torch.tensor([[4], [2], [0], [5], [3]], device=device),
+         torch.empty(0), torch.empty(0)),
+    ):  # fmt: skip
+        w_0, w, v_0, v, t_0, t, f_0, f = params
+        x = feats.clone().requires_grad_(True)
+        y = F.spec_augment_apply_parameters(x, params, 1, lens)
+        g = torch.randn_like(y)
+        (act,) = torch.autograd.grad(y, x, g)
+        # the reference's graph
+        x2 = feats.clone().requires_grad_(True)
+        tg = (2 * torch.arange(T, device=device).float() + 1) / T - 1
+        fg = (2 * torch.arange(Fq, device=device).float() + 1) / Fq - 1
+        tgrid = F.warp_1d_grid(w_0, w, lens, T, 1) if w_0.numel() else tg.expand(N, T)
+        fgrid = (
+            F.warp_1d_grid(v_0, v, torch.full((N,), Fq, device=device), Fq, 1) if v_0.numel() else fg.expand(N, Fq)
+        )
+        y2 = x2
+        if w_0.numel() or v_0.numel():
+            grid = torch.stack([fgrid.unsqueeze(1).expand(N, T, Fq), tgrid.unsqueeze(2).expand(N, T, Fq)], 3)
+            y2 = torch.nn.functional.grid_sample(
+                x2.unsqueeze(1), grid, mode="bilinear", padding_mode="border", align_corners=False
+            ).squeeze(1)
+        if t_0.numel():
+            ar = torch.arange(T, device=device).view(1, T, 1)
+            m = ((ar >= t_0.unsqueeze(1)) & (ar < (t_0 + t).unsqueeze(1))).any(2, keepdim=True)
+            y2 = y2.masked_fill(m, 0.0)
+        if f_0.numel():
+            ar = torch.arange(Fq, device=device).view(1, Fq, 1)
+            m = ((ar >= f_0.unsqueeze(1)) & (ar < (f_0 + f).unsqueeze(1))).any(2).unsqueeze(1)
+            y2 = y2.masked_fill(m, 0.0)
+        assert torch.allclose(y, y2, atol=1e-5)
+        (exp,) = torch.autograd.grad(y2, x2, g)
+        assert torch.allclose(exp, act, atol=1e-4), (exp - act).abs().max().item()

@@ -1,0 +1,249 @@
+"""Scripted and traced Modules give the eager Modules' results on the GPU (the reference's
+``jit_type`` parametrisation, tests/test_string.py:39-42 etc.), and the operator
+registrations (fake kernels, autograd formulas) pass ``torch.library.opcheck``."""
+import pytest
+import torch
+
+from pydrobert_amd import functional as F
+from pydrobert_amd import modules as M
+
+from _toy_lm import ScriptableBigramLM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _same(a, b):
+    if isinstance(a, (tuple, list)):
+        assert len(a) == len(b)
+        for x, y in zip(a, b):
+            _same(x, y)
+    elif a.dtype.is_floating_point:
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6, equal_nan=True)
+    else:
+        assert torch.equal(a, b)
+
+
+def _tokens(T, N, V, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randint(0, V, (T, N), generator=g).to(DEV)
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+@pytest.mark.parametrize(
+    "cls, kwargs",
+    [
+        (M.EditDistance, dict(eos=1, ins_cost=0.5)),
+        (M.ErrorRate, dict(eos=0, include_eos=True, warn=False)),
+        (M.PrefixEditDistances, dict(eos=2, batch_first=True, warn=False)),
+        (M.PrefixErrorRates, dict(exclude_last=True)),
+        (M.OptimalCompletion, dict(eos=3, warn=False)),
+    ],
+)
+def test_string_modules(jit_type, cls, kwargs):
+    T, N, V = 23, 9, 6
+    ref, hyp = _tokens(T, N, V, 1), _tokens(T + 3, N, V, 2)
+    if kwargs.get("batch_first"):
+        ref, hyp = ref.t().contiguous(), hyp.t().contiguous()
+    mod = cls(**kwargs)
+    exp = mod(ref, hyp)
+    if jit_type == "script":
+        jit = torch.jit.script(mod)
+    else:
+        jit = torch.jit.trace(mod, (ref[:2, :2].contiguous(), hyp[:2, :2].contiguous()), check_trace=False)
+    _same(exp, jit(ref, hyp))
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_fill_after_eos(jit_type):
+    tok = _tokens(11, 5, 4, 3)
+    mod = M.FillAfterEndOfSequence(1, 0, -7.0)
+    exp = mod(tok)
+    jit = torch.jit.script(mod) if jit_type == "script" else torch.jit.trace(mod, (tok[:3],))
+    _same(exp, jit(tok))
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_ocd_loss(jit_type):
+    T, N, V = 12, 7, 8
+    ref, hyp = _tokens(T, N, V, 4), _tokens(T - 1, N, V, 5)
+    logits = torch.randn((T - 1, N, V), device=DEV, generator=torch.Generator(DEV).manual_seed(6))
+    mod = M.HardOptimalCompletionDistillationLoss(eos=0, weight=torch.rand(V, device=DEV) + 0.5).to(DEV)
+    l1 = logits.clone().requires_grad_(True)
+    exp = mod(l1, ref, hyp)
+    (g1,) = torch.autograd.grad(exp, l1)
+    if jit_type == "script":
+        jit = torch.jit.script(mod)
+    else:
+        jit = torch.jit.trace(mod, (logits, ref, hyp), check_trace=False)
+    l2 = logits.clone().requires_grad_(True)
+    act = jit(l2, ref, hyp)
+    (g2,) = torch.autograd.grad(act, l2)
+    _same(exp, act)
+    _same(g1, g2)
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_mer_loss(jit_type):
+    T, N, S, V = 9, 4, 5, 6
+    g = torch.Generator().manual_seed(7)
+    ref = torch.randint(0, V, (T, N), generator=g).to(DEV)
+    hyp = torch.randint(0, V, (T + 1, N, S), generator=g).to(DEV)
+    lp = torch.randn((N, S), generator=g).to(DEV)
+    mod = M.MinimumErrorRateLoss(eos=1)
+    exp = mod(lp, ref, hyp, False)
+    if jit_type == "script":
+        jit = torch.jit.script(mod)
+        act = jit(lp, ref, hyp, False)
+    else:
+        jit = torch.jit.trace(mod, (lp, ref, hyp, torch.tensor(False)), check_trace=False)
+        act = jit(lp, ref, hyp, torch.tensor(False))
+    _same(exp, act)
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_ctc_prefix_search(jit_type):
+    T, N, V, W = 30, 6, 7, 5
+    logits = torch.randn((T, N, V + 1), device=DEV, generator=torch.Generator(DEV).manual_seed(8))
+    lens = torch.tensor([30, 12, 1, 29, 30, 17], device=DEV)
+    mod = M.CTCPrefixSearch(W)
+    exp = mod(logits, lens)
+    if jit_type == "script":
+        jit = torch.jit.script(mod)
+    else:
+        jit = torch.jit.trace(mod, (logits, lens), check_trace=False)
+    _same(exp, jit(logits, lens))
+
+
+def test_scripted_searches_with_lm():
+    T, N, V, W = 12, 3, 5, 4
+    gen = torch.Generator(DEV).manual_seed(9)
+    lm = ScriptableBigramLM(torch.randn((V + 1, V), device=DEV, generator=gen).log_softmax(-1))
+    logits = torch.randn((T, N, V + 1), device=DEV, generator=gen)
+    lens = torch.tensor([12, 5, 9], device=DEV)
+    mod = M.CTCPrefixSearch(W, 0.3, lm)
+    _same(mod(logits, lens), torch.jit.script(mod)(logits, lens))
+    beam = M.BeamSearch(lm, W, eos=0).to(DEV)
+    _same(beam(None, N, 8), torch.jit.script(beam)(None, N, 8))
+    walk = M.RandomWalk(lm, eos=0).to(DEV)
+    torch.manual_seed(10)
+    exp = walk(None, N, 6)
+    torch.manual_seed(10)
+    _same(exp, torch.jit.script(walk)(None, N, 6))
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_greedy_and_sequence_log_probs(jit_type):
+    T, N, V = 14, 5, 6
+    gen = torch.Generator(DEV).manual_seed(11)
+    logits = torch.randn((T, N, V), device=DEV, generator=gen)
+    lens = torch.tensor([14, 3, 9, 1, 14], device=DEV)
+    hyp = _tokens(T, N, V, 12)
+    greedy, slp = M.CTCGreedySearch(), M.SequenceLogProbabilities(0, 2)
+    if jit_type == "script":
+        jg, js = torch.jit.script(greedy), torch.jit.script(slp)
+    else:
+        jg = torch.jit.trace(greedy, (logits, lens), check_trace=False)
+        js = torch.jit.trace(slp, (logits, hyp), check_trace=False)
+    _same(greedy(logits, lens), jg(logits, lens))
+    l1, l2 = logits.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+    a, b = slp(l1, hyp), js(l2, hyp)
+    _same(a, b)
+    _same(torch.autograd.grad(a.sum(), l1), torch.autograd.grad(b.sum(), l2))
+
+
+def test_scripted_sequence_log_probs_packed():
+    T, N, V = 8, 4, 5
+    gen = torch.Generator(DEV).manual_seed(13)
+    logits = torch.randn((T, N, V), device=DEV, generator=gen)
+    lens = torch.tensor([8, 2, 5, 7])
+    hyp = _tokens(T, N, V, 14)
+    ps = torch.nn.utils.rnn.pack_padded_sequence(logits, lens, enforce_sorted=False)
+    slp = M.SequenceLogProbabilities(0)
+    exp = slp(ps, hyp)
+    _same(exp, torch.jit.script(slp)(ps, hyp))
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_image_modules(jit_type):
+    N, C, H, W = 3, 2, 17, 13
+    gen = torch.Generator(DEV).manual_seed(15)
+    img = torch.rand((N, C, H, W), device=DEV, generator=gen)
+    flow = torch.randn((N, H, W, 2), device=DEV, generator=gen)
+    src = torch.rand((N, 4, 2), device=DEV, generator=gen) * 10
+    dst = src + torch.randn((N, 4, 2), device=DEV, generator=gen)
+    cases = [
+        (M.DenseImageWarp(), (img, flow)),
+        (M.SparseImageWarp(pinned_boundary_points=1), (img, src, dst)),
+        (M.SparseImageWarp(include_flow=False), (img, src, dst)),
+        (M.PolyharmonicSpline(2), (src, dst, torch.rand((N, 9, 2), device=DEV, generator=gen) * 10)),
+        (
+            M.Warp1DGrid(20),
+            (torch.tensor([3.0, 8.0, 5.5], device=DEV), torch.tensor([1.0, -2.0, 0.5], device=DEV),
+             torch.tensor([20, 15, 11], device=DEV)),
+        ),
+    ]  # fmt: skip
+    for mod, args in cases:
+        exp = mod(*args)
+        jit = torch.jit.script(mod) if jit_type == "script" else torch.jit.trace(mod, args, check_trace=False)
+        _same(exp, jit(*args))
+
+
+@pytest.mark.parametrize("jit_type", ["script", "trace"])
+def test_spec_augment(jit_type):
+    N, T, Fq = 4, 50, 16
+    feats = torch.rand((N, T, Fq), device=DEV, generator=torch.Generator(DEV).manual_seed(16))
+    lengths = torch.tensor([50, 31, 44, 12], device=DEV)
+    mod = M.SpecAugment(max_time_warp=10.0, max_freq_warp=2.0, max_time_mask=8, max_freq_mask=3)
+    if jit_type == "script":
+        jit = torch.jit.script(mod)
+    else:
+        jit = torch.jit.trace(mod, (feats, lengths), check_trace=False)
+        params = mod.draw_parameters(feats, lengths)
+        _same(mod.apply_parameters(feats, params, lengths), F.spec_augment_apply_parameters(feats, params, 1, lengths))
+        return
+    torch.manual_seed(17)
+    exp = mod(feats, lengths)
+    torch.manual_seed(17)
+    _same(exp, jit(feats, lengths))
+    params = mod.draw_parameters(feats, lengths)
+    f1, f2 = feats.clone().requires_grad_(True), feats.clone().requires_grad_(True)
+    a, b = mod.apply_parameters(f1, params, lengths), jit.apply_parameters(f2, params, lengths)
+    _same(a, b)
+    _same(torch.autograd.grad(a.square().sum(), f1), torch.autograd.grad(b.square().sum(), f2))
+
+
+def test_opcheck_registrations():
+    """Schemas, fake kernels and autograd registrations are consistent (torch.library.opcheck)."""
+    from torch.library import opcheck
+
+    T, N, V = 10, 4, 6
+    ref, hyp = _tokens(T, N, V, 20), _tokens(T, N, V, 21)
+    tests = ("test_schema", "test_faketensor", "test_autograd_registration")
+    opcheck(
+        torch.ops.pydrobert_amd.string_matching.default,
+        (ref, hyp, 1, False, False, 1.0, 1.0, 1.0, False, True, True, False, -1, True),
+        test_utils=tests,
+    )
+    logits = torch.randn((T, N, V), device=DEV, requires_grad=True)
+    opcheck(torch.ops.pydrobert_amd.sequence_log_probs.default, (logits, hyp, 0, None), test_utils=tests)
+    opcheck(
+        torch.ops.pydrobert_amd.ocd_loss_rows.default,
+        (logits, ref, hyp, None, True, False, 1.0, 1.0, 1.0, None, -2, False),
+        test_utils=tests,
+    )
+    opcheck(torch.ops.pydrobert_amd.ctc_prefix_search.default, (logits.detach(), 3, None), test_utils=tests)
+    feats = torch.rand((N, 20, 8), device=DEV, requires_grad=True)
+    tgrid = torch.linspace(-1, 1, 20, device=DEV).expand(N, 20).contiguous()
+    opcheck(
+        torch.ops.pydrobert_amd.spec_augment_apply.default,
+        (feats, tgrid, None, None, None, None, None),
+        test_utils=tests,
+    )
+    img = torch.rand((2, 3, 9, 7), device=DEV, requires_grad=True)
+    flow = torch.randn((2, 9, 7, 2), device=DEV)
+    opcheck(
+        torch.ops.pydrobert_amd.dense_image_warp.default,
+        (img, flow, "hw", "bilinear", "border"),
+        test_utils=tests,
+    )
