@@ -267,6 +267,30 @@ int pdt_sparse_image_warp_backward(const float *grad_out, const float *train_poi
                                    int values_are_grid, int mode, int padding, float *grad_image,
                                    void *workspace, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Back-off n-gram language model scoring (reference _lm.py:403-515, LookupLanguageModel
+ * :518-1110), the on-device LM of CTCPrefixSearch / BeamSearch with shallow fusion.
+ *
+ * The model is the reference's reverse trie (:609-677) in widened form: logps [P] and
+ * logbs [O] float32 as stored; child_start [O] int32 = node index + offsets[node] (absolute
+ * index of the node's first child; the children of i are [child_start[i], child_start[i+1]));
+ * ids [I] int32 = labels of the nodes >= U (index node - U).  V vocabulary size, N >= 2 the
+ * n-gram order, U = V + shift + 1 the unigram count + dummy (shift = 1 when sos is not a
+ * vocabulary id; it is then stored as unigram V).
+ *
+ * hist (S, B) int64 through element strides.  idx != NULL: rows == B, row b is queried at
+ * position idx[b * idx_stride] in [0, S] (idx_stride 0 = one shared position) --
+ * calc_idx_log_probs (:769-790).  idx == NULL: rows == (S + 1) * B, row t * B + b is batch
+ * element b at position t -- calc_full_log_probs (:793-848).  Positions before the start of
+ * the history read sos (:452-461).  out (rows, V) float32: log P(v | the N - 1 tokens before
+ * the position).  status bit 0: a position outside [0, S] (clamped).
+ * ------------------------------------------------------------------------------------- */
+int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h_ss, int64_t h_sb,
+                            const int64_t *idx, int64_t idx_stride, int64_t rows,
+                            const float *logps, const float *logbs, const int32_t *child_start,
+                            const int32_t *ids, int64_t V, int64_t N, int64_t U, int64_t sos,
+                            float *out, int32_t *status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

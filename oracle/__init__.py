@@ -236,3 +236,4 @@ from ._decoding import *  # noqa: E402,F401,F403
 from ._img import *  # noqa: E402,F401,F403
 from ._losses import *  # noqa: E402,F401,F403
 from ._seqops import *  # noqa: E402,F401,F403
+from ._lm import backoff_log_probs, trie_log_probs  # noqa: E402,F401

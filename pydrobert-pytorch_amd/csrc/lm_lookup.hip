@@ -1,0 +1,141 @@
+// Back-off n-gram scoring over the reference's reverse-trie buffers (reference _lm.py:403-515,
+// trie layout :609-677).
+//
+// For every query row (one history position of one batch element) and every vocabulary entry v
+// the reference walks two paths per step of a Python loop over the n-gram order, holding
+// (M + B, S) index / mask tensors (M = rows * V, S = max direct descendants) and scanning all S
+// children of every node.  Here one thread owns one (row, v) pair and keeps the walk in
+// registers: a binary search among the node's children per order (children are sorted by id,
+// invariant 3 at :628), the back-off chain of the row's context is walked alongside.  The only
+// HBM traffic that scales is the dense (rows, V) float32 result -- the kernel is bound by that
+// store stream; the trie tables (a few MB) stay in L2 / MALL.
+//
+// Arithmetic is the reference's, in the reference's order (float32,
+// (last_logp + cur_backoff) + last_backoff, :504-506), so results are bit-identical.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pdt_amd.h"
+
+namespace pdt {
+
+struct LmArgs {
+  const int64_t *hist;  // (S, B) through element strides
+  int64_t h_ss, h_sb;
+  const int64_t *idx;   // per-row position through idx_stride (0: one value), or null: full mode
+  int64_t idx_stride;
+  int S, B;
+  int64_t rows;         // B, or (S + 1) * B in full mode (row = t * B + b, idx = t)
+  const float *logps, *logbs;
+  const int *child_start;  // [O] absolute index of a node's first child; end = child_start[i + 1]
+  const int *ids;          // labels of nodes >= U, indexed node - U
+  int V, N, U, shift;
+  int64_t sos;
+  float *out;           // (rows, V)
+  int *status;          // bit 0: a position outside [0, S]
+};
+
+// child of `node` labelled `tok`, or -1
+__device__ __forceinline__ int find_child(const LmArgs &a, int node, int tok) {
+  int lo = a.child_start[node];
+  const int end = a.child_start[node + 1];
+  int hi = end;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a.ids[mid - a.U] < tok) lo = mid + 1; else hi = mid;
+  }
+  return (lo < end && a.ids[lo - a.U] == tok) ? lo : -1;
+}
+
+constexpr int kMaxOrder = 16;
+
+__global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= a.rows * a.V) return;
+  const int64_t r = gid / a.V;
+  const int v = (int)(gid - r * a.V);
+  int64_t pos;
+  int b;
+  if (a.idx) {
+    b = (int)r;
+    pos = a.idx[r * a.idx_stride];
+    if (pos < 0 || pos > a.S) {
+      if (v == 0) atomicOr(a.status, 1);
+      pos = pos < 0 ? 0 : a.S;
+    }
+  } else {
+    const int64_t t = r / a.B;
+    b = (int)(r - t * a.B);
+    pos = t;
+  }
+  // context token at distance n >= 1 behind the queried position; sos beyond the start (:452-461)
+  auto ctx = [&](int n) -> int {
+    const int64_t p = pos - n;
+    int64_t tok = p >= 0 ? a.hist[p * a.h_ss + (int64_t)b * a.h_sb] : a.sos;
+    if (a.shift && tok == a.sos) tok = a.V;  // :471-472
+    return (tok >= 0 && tok < a.U - 1) ? (int)tok : -1;
+  };
+  const int N = a.N;
+  // back-off chain of the context: bo[n] = log-backoff of the length-n context, 0 once the
+  // context is no longer in the trie (:491-497)
+  float bo[kMaxOrder];
+  {
+    int node = ctx(1);
+    bo[1] = node >= 0 ? a.logbs[node] : 0.0f;
+    for (int n = 2; n <= N - 1; ++n) {
+      if (node >= 0) {
+        const int tok = ctx(n);
+        node = tok >= 0 ? find_child(a, node, tok) : -1;
+      }
+      bo[n] = node >= 0 ? a.logbs[node] : 0.0f;
+    }
+  }
+  float lp = a.logps[v];
+  float last_b = bo[1];
+  int node = v;
+  for (int n = 1; n <= N - 1; ++n) {
+    if (node >= 0) {
+      const int tok = ctx(n);
+      node = tok >= 0 ? find_child(a, node, tok) : -1;
+    }
+    const float cur_b = n == N - 1 ? 0.0f : bo[n + 1];
+    const float lpd = node >= 0 ? a.logps[node] : 0.0f;
+    // an infinite entry marks a node that only exists for its children (:499-503)
+    const bool clobber = node >= 0 && isfinite(lpd);
+    lp = clobber ? lpd : (lp + cur_b) + last_b;
+    last_b = clobber ? cur_b : 0.0f;
+  }
+  a.out[gid] = lp;
+}
+
+}  // namespace pdt
+
+extern "C" {
+
+int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h_ss, int64_t h_sb,
+                            const int64_t *idx, int64_t idx_stride, int64_t rows,
+                            const float *logps, const float *logbs, const int32_t *child_start,
+                            const int32_t *ids, int64_t V, int64_t N, int64_t U, int64_t sos,
+                            float *out, int32_t *status, void *stream) {
+  using namespace pdt;
+  if (S < 0 || B < 0 || rows < 0 || V < 1 || N < 2 || U < V + 1 || U > V + 2) return PDT_E_ARG;
+  if (rows == 0) return PDT_OK;
+  if (N > kMaxOrder) return PDT_E_TOO_LONG;
+  if (rows * V >= (1ll << 31) * 256 || S >= (1ll << 31) || B >= (1ll << 31)) return PDT_E_TOO_LONG;
+  if ((S > 0 && !hist) || !logps || !logbs || !child_start || !ids || !out || !status)
+    return PDT_E_ARG;
+  if (!idx && rows != (S + 1) * B) return PDT_E_ARG;
+  if (idx && rows != B) return PDT_E_ARG;
+  LmArgs a{};
+  a.hist = hist; a.h_ss = h_ss; a.h_sb = h_sb; a.idx = idx; a.idx_stride = idx_stride;
+  a.S = (int)S; a.B = (int)B; a.rows = rows;
+  a.logps = logps; a.logbs = logbs; a.child_start = child_start; a.ids = ids;
+  a.V = (int)V; a.N = (int)N; a.U = (int)U; a.shift = (int)(U - V - 1); a.sos = sos;
+  a.out = out; a.status = status;
+  const int64_t total = rows * V;
+  hipLaunchKernelGGL(lm_lookup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -90,6 +90,10 @@ SIGNATURES = {
         _INT,
         [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _P],
     ),
+    "pdt_lookup_lm_log_probs": (
+        _INT,
+        [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
+    ),
     "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_ctc_prefix_search": (
         _INT,

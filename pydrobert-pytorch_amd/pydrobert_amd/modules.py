@@ -6,8 +6,12 @@ from ._img import DenseImageWarp, PolyharmonicSpline, SparseImageWarp, SpecAugme
 from ._decoding import CTCGreedySearch, RandomWalk, SequenceLogProbabilities
 from ._lm import (
     ExtractableSequentialLanguageModel,
+    ExtractableShallowFusionLanguageModel,
+    LookupLanguageModel,
     MixableSequentialLanguageModel,
+    MixableShallowFusionLanguageModel,
     SequentialLanguageModel,
+    ShallowFusionLanguageModel,
 )
 from ._string import (
     HardOptimalCompletionDistillationLoss,
@@ -29,6 +33,10 @@ __all__ = [
     "BeamSearch",
     "CTCPrefixSearch",
     "ExtractableSequentialLanguageModel",
+    "ExtractableShallowFusionLanguageModel",
+    "LookupLanguageModel",
+    "MixableShallowFusionLanguageModel",
+    "ShallowFusionLanguageModel",
     "MixableSequentialLanguageModel",
     "SequentialLanguageModel",
     "EditDistance",

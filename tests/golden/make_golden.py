@@ -316,3 +316,77 @@ def loss_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "losses"):
     loss_goldens()
+
+
+def lm_goldens():
+    """LookupLanguageModel tries and scores from the live reference.  The tables are large
+    enough for int16 offsets: with uint8 offsets the reference's builder fails under NumPy 2
+    (defect 1)."""
+    rng = np.random.default_rng(0x5EED0006)
+    d = {}
+
+    def make(V, sos, N, counts, p_uni=0.9):
+        toks = list(range(V)) + ([sos] if not (0 <= sos < V) else [])
+        dicts = []
+        for n in range(N):
+            dd = {}
+            if n == 0:
+                for v in toks:
+                    if rng.random() < p_uni:
+                        dd[v] = (float(rng.normal()), float(rng.normal())) if N > 1 else float(rng.normal())
+            else:
+                keys = set()
+                while len(keys) < counts[n]:
+                    keys.add(tuple(int(toks[i]) for i in rng.integers(0, len(toks), n + 1)))
+                for k in keys:
+                    dd[k] = float(rng.normal()) if n == N - 1 else (float(rng.normal()), float(rng.normal()))
+            dicts.append(dd)
+        return dicts
+
+    cases = {
+        "A": (20, -1, 2, [0, 300]),
+        "B": (20, 3, 3, [0, 200, 400]),
+        "C": (30, 30, 4, [0, 150, 300, 300]),
+        "U": (12, -5, 1, [0]),
+    }
+    lms = {}
+    for tag, (V, sos, N, counts) in cases.items():
+        dicts = make(V, sos, N, counts)
+        for n, dd in enumerate(dicts):
+            keys = np.array([[k] if n == 0 else list(k) for k in dd.keys()], dtype=np.int64).reshape(len(dd), n + 1)
+            vals = np.array([[v] if n == N - 1 else list(v) for v in dd.values()], dtype=np.float64)
+            d["{}_keys{}".format(tag, n)], d["{}_vals{}".format(tag, n)] = keys, vals
+        lm = M.LookupLanguageModel(V, sos, [x.copy() for x in dicts])
+        lms[tag] = lm
+        d[tag + "_cfg"] = np.array([V, sos, N, lm.max_ngram_nodes, lm.max_direct_descendants])
+        for name in ("logps", "logbs", "ids", "offsets"):
+            d[tag + "_" + name] = getattr(lm, name)
+        S, B = 9, 6
+        toks = list(range(V)) + ([sos] if not (0 <= sos < V) else [])
+        hist = torch.from_numpy(np.asarray(toks)[rng.integers(0, len(toks), (S, B))])
+        idx = torch.from_numpy(rng.integers(0, S + 1, B))
+        d[tag + "_hist"], d[tag + "_idx"] = hist, idx
+        d[tag + "_full"] = lm(hist)
+        d[tag + "_at_idx"] = lm(hist, None, idx)[0]
+        d[tag + "_at_4"] = lm(hist, None, 4)[0]
+        d[tag + "_at_0"] = lm(hist[:0], None, 0)[0]
+    # uniform default model
+    d["D_full"] = M.LookupLanguageModel(7, 2)(torch.zeros((3, 2), dtype=torch.long))
+    # CTC prefix search with the trigram model in shallow fusion
+    V, K, T, N = 20, 5, 18, 4
+    lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+    peak = rng.integers(0, V + 1, (T, N))
+    np.put_along_axis(lg, peak[..., None], np.take_along_axis(lg, peak[..., None], 2) + 5.0, 2)
+    lens = rng.integers(8, T + 1, N)
+    y, yl, yp = M.CTCPrefixSearch(K, 0.4, lms["B"])(torch.from_numpy(lg), torch.from_numpy(lens))
+    mask = torch.arange(y.shape[0]).view(-1, 1, 1) < yl.unsqueeze(0)
+    d.update(ctc_logits=lg, ctc_lens=lens, ctc_width=np.array(K), ctc_beta=np.array(0.4),
+             ctc_y=torch.where(mask, y, torch.zeros_like(y)), ctc_y_lens=yl, ctc_y_probs=yp)  # fmt: skip
+    # BeamSearch driven by the 4-gram model
+    y, yl, lp = M.BeamSearch(lms["C"], 4, eos=0)(dict(), batch_size=3, max_iters=10)
+    d.update(beam_y=y, beam_lens=yl, beam_lp=lp)
+    save("lm", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "lm"):
+    lm_goldens()

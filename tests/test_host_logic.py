@@ -1,5 +1,6 @@
 """CPU: host-side behaviour of the drop-in boundary -- constructor validation, shape errors,
 the LM interface, and the absence of any CPU compute path."""
+import numpy as np
 import pytest
 import torch
 
@@ -160,3 +161,138 @@ def test_spec_augment_draw_parameters_on_cpu_ranges():
     assert (f <= 4).all() and (f_0 >= 0).all() and (f_0 + f <= Fq).all()
     out = F.spec_augment_draw_parameters(feats, 0.0, 0.0, 0, 0, 0.1, 3, 0.03, 0)
     assert all(p.numel() == 0 for p in out)
+
+
+# ---- language model host logic ---------------------------------------
+def test_trie_builder_matches_reference_buffers():
+    """The array-based builder reproduces the reference's flattened trie bit for bit, dtypes
+    included (buffers captured from the live reference in tests/golden/lm.npz)."""
+    import torch
+    from _lm_fixtures import dicts_from_golden, golden
+    from pydrobert_amd.modules import LookupLanguageModel
+
+    g = golden()
+    for tag in ("A", "B", "C", "U"):
+        V, sos, N, dicts = dicts_from_golden(g, tag)
+        lm = LookupLanguageModel(V, sos, dicts)
+        assert lm.max_ngram == N
+        assert lm.max_ngram_nodes == int(g[tag + "_cfg"][3])
+        assert lm.max_direct_descendants == int(g[tag + "_cfg"][4])
+        for name in ("logps", "logbs", "ids", "offsets"):
+            exp, act = g[tag + "_" + name], getattr(lm, name).numpy()
+            assert exp.dtype == act.dtype and exp.shape == act.shape, (tag, name, exp.dtype, act.dtype)
+            assert np.array_equal(exp, act, equal_nan=exp.dtype.kind == "f"), (tag, name)
+        # destructive=False left the caller's tables alone
+        assert dicts_from_golden(g, tag)[3] == dicts
+    uniform = LookupLanguageModel(7, 2)
+    assert torch.allclose(uniform.logps, torch.full((7,), -np.log(7.0)).float())
+    assert uniform.offsets.numel() == uniform.ids.numel() == uniform.logbs.numel() == 0
+
+
+@pytest.mark.parametrize("which", ["unigram", "bigram", "trigram"])
+def test_trie_known_answers(which):
+    """The reference's hand-written tables (facts from tests/test_lm.py:117-139): walking the
+    built trie from the last token backwards finds every entry with its values."""
+    from pydrobert_amd.modules import LookupLanguageModel
+
+    prob_dicts = {
+        "unigram": [{0: 0.0, 1: 1.0, 4: 4.0}],
+        "bigram": [
+            {1: (1.0, -1.0), 2: (2.0, -2.0), 3: (3.0, -3)},
+            {(1, 0): 1.1, (1, 1): 11.1, (3, 2): 23.1},
+        ],
+        "trigram": [
+            {1: (1.0, -1.0), 2: (2.0, -2.0), 3: (3.0, -3.0), 4: (4.0, -4.0)},
+            {(1, 1): (11.1, -11.1), (2, 3): (32.1, -32.1), (2, 4): (42.1, -42.1), (4, 1): (14.1, -14.1)},
+            {(0, 0, 1): 1.2, (0, 0, 2): 2.2, (4, 1, 4): 414.2, (3, 4, 1): 143.2},
+        ],
+    }[which]
+    V, N = 5, len(prob_dicts)
+    lm = LookupLanguageModel(V, 0, prob_dicts)
+    off, ids = lm.offsets.long().numpy(), lm.ids.long().numpy()
+    logps, logbs = lm.logps.numpy(), lm.logbs.numpy()
+    U = V + 1
+    S = 0
+    for n, d in enumerate(prob_dicts):
+        for key, exp in d.items():
+            key = (key,) if n == 0 else key
+            node = key[-1]
+            for tok in key[-2::-1]:
+                lo, hi = node + off[node], node + 1 + off[node + 1]
+                S = max(S, hi - lo)
+                hits = [c for c in range(lo, hi) if ids[c - U] == tok]
+                assert len(hits) == 1, (key, tok)
+                node = hits[0]
+            if n == N - 1:
+                assert np.isclose(logps[node], exp), key
+            else:
+                assert np.isclose(logps[node], exp[0]) and np.isclose(logbs[node], exp[1]), key
+    assert lm.max_direct_descendants >= S
+    if N > 1:  # (0, 0) is only a suffix of (0, 0, x): added with probability 0, no penalty
+        assert lm.max_ngram_nodes == len(prob_dicts[-1])
+
+
+def test_trie_builder_rejects_bad_tables():
+    from pydrobert_amd.modules import LookupLanguageModel
+
+    with pytest.raises(ValueError, match="at least unigrams"):
+        LookupLanguageModel(3, 0, [])
+    with pytest.raises(ValueError, match="Unexpected unigrams"):
+        LookupLanguageModel(3, 0, [{7: 0.0}])
+    with pytest.raises(ValueError, match="must not be empty"):
+        LookupLanguageModel(3, 0, [{0: (0.0, 0.0)}, {}])
+    with pytest.raises(ValueError, match="not a sequence of length"):
+        LookupLanguageModel(3, 0, [{0: (0.0, 0.0)}, {(0, 1, 2): 0.0}])
+    with pytest.raises(ValueError, match="Unexpected tokens"):
+        LookupLanguageModel(3, 0, [{0: (0.0, 0.0)}, {(0, 5): 0.0}])
+
+
+def test_lookup_lm_state_dict_resizes():
+    """load_state_dict accepts tables of another size and re-derives the order (reference
+    tests/test_lm.py:422-489)."""
+    from _lm_fixtures import dicts_from_golden, golden
+    from pydrobert_amd.modules import LookupLanguageModel
+
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, "B")
+    full = LookupLanguageModel(V, sos, dicts)
+    blank = LookupLanguageModel(V, sos)
+    assert blank.max_ngram == 1
+    blank.load_state_dict(full.state_dict())
+    assert blank.max_ngram == N and blank.max_ngram_nodes == full.max_ngram_nodes
+    assert blank.max_direct_descendants == full.max_direct_descendants
+    for name in ("logps", "logbs", "ids", "offsets"):
+        assert np.array_equal(getattr(blank, name).numpy(), getattr(full, name).numpy(), equal_nan=True)
+    # back down to a unigram table
+    uni = LookupLanguageModel(V, sos, [{k: v[0] for k, v in dicts[0].items()}])
+    blank.load_state_dict(uni.state_dict())
+    assert blank.max_ngram == 1 and blank.max_ngram_nodes == V + blank.shift
+    # wrong vocabulary size is detected
+    wrong = LookupLanguageModel(V + 4, sos)
+    with pytest.raises(RuntimeError):
+        wrong.load_state_dict(full.state_dict())
+    sd = full.state_dict()
+    del sd["ids"]
+    with pytest.raises(RuntimeError, match="Missing key"):
+        blank.load_state_dict(sd)
+
+
+def test_shallow_fusion_dict_plumbing():
+    from pydrobert_amd.modules import LookupLanguageModel, MixableShallowFusionLanguageModel, ShallowFusionLanguageModel
+
+    a, b = LookupLanguageModel(4, 0), LookupLanguageModel(4, 0)
+    with pytest.raises(ValueError, match="vocab_size"):
+        ShallowFusionLanguageModel(a, LookupLanguageModel(5, 0))
+    with pytest.raises(ValueError, match="matches second_prefix"):
+        ShallowFusionLanguageModel(a, b, 0.1, "x.", "x.")
+    with pytest.raises(ValueError, match="cannot be empty"):
+        ShallowFusionLanguageModel(a, b, 0.1, "", "y.")
+    lm = MixableShallowFusionLanguageModel(a, b, 0.5, "one.", "two.")
+    import torch
+
+    prev = {"one.h": torch.zeros(2), "two.c": torch.ones(3)}
+    first, second = lm.split_dicts(prev)
+    assert list(first) == ["h"] and list(second) == ["c"]
+    assert set(lm.merge_dicts(first, second)) == set(prev)
+    with pytest.raises(RuntimeError, match="does not start with"):
+        lm.split_dicts({"three.x": torch.zeros(1)})

@@ -35,6 +35,9 @@ def _modules():
         M.SparseImageWarp(),
         M.SparseImageWarp(include_flow=False, pinned_boundary_points=2),
         M.SpecAugment(max_freq_warp=3.0),
+        M.LookupLanguageModel(5, 0),
+        M.LookupLanguageModel(5, -1, [{0: (0.0, 0.0), 1: (-1.0, -0.5)}, {(1, 0): -0.3}]),
+        M.CTCPrefixSearch(3, 0.5, M.LookupLanguageModel(5, -1, [{0: (0.0, 0.0)}, {(0, 0): -0.3}])),
     ]
 
 
@@ -50,6 +53,7 @@ def test_kernels_are_registered_operators():
         "ctc_greedy_search", "sequence_log_probs", "sequence_log_probs_backward",
         "polyharmonic_spline", "warp_1d_grid", "dense_image_warp", "dense_image_warp_backward",
         "sparse_image_warp", "spec_augment_apply", "spec_augment_apply_backward",
+        "sparse_image_warp_backward", "lookup_lm_log_probs",
     ]  # fmt: skip
     for name in names:
         assert hasattr(torch.ops.pydrobert_amd, name), name

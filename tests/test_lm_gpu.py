@@ -1,0 +1,189 @@
+"""LookupLanguageModel on the GPU: the lookup kernel against the
+live reference's scores (tests/golden/lm.npz, bit-exact), against the oracle's two CPU
+restatements on tables of every size class, and inside the searches."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from pydrobert_amd import modules as M
+
+from _lm_fixtures import dicts_from_golden, golden, random_dicts
+from _toy_lm import BigramLM
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("tag", ["A", "B", "C", "U"])
+def test_scores_match_reference_bit_for_bit(tag):
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, tag)
+    lm = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    hist, idx = _t(g[tag + "_hist"]), _t(g[tag + "_idx"])
+    assert np.array_equal(g[tag + "_full"], lm(hist).cpu().numpy(), equal_nan=True)
+    assert np.array_equal(g[tag + "_at_idx"], lm(hist, None, idx)[0].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(g[tag + "_at_4"], lm(hist, None, 4)[0].cpu().numpy(), equal_nan=True)
+    assert np.array_equal(g[tag + "_at_0"], lm(hist[:0], None, 0)[0].cpu().numpy(), equal_nan=True)
+    # negative positions count from the end; chunked form is the same computation
+    assert torch.equal(lm(hist, None, -1)[0], lm(hist, None, hist.shape[0])[0])
+    assert torch.equal(lm.calc_full_log_probs_chunked(hist, dict(), 3), lm(hist))
+    # a transposed (strided) history
+    ht = hist.t().contiguous().t()
+    assert torch.equal(lm(ht), lm(hist))
+
+
+def test_default_model_is_uniform():
+    g = golden()
+    lm = M.LookupLanguageModel(7, 2).to(DEV)
+    act = lm(torch.zeros((3, 2), dtype=torch.long, device=DEV))
+    assert np.allclose(g["D_full"], act.cpu().numpy())
+
+
+@pytest.mark.parametrize("N", [1, 2, 3, 5])
+@pytest.mark.parametrize("sos", [-1, 0])
+def test_scores_match_oracle_small_tables(N, sos):
+    """Dense random tables in the uint8-offset regime (where the reference's own builder fails
+    under NumPy 2): every possible history of every length, as tests/test_lm.py:218-306."""
+    rng = np.random.default_rng(100 + N)
+    V = 5
+    dicts = random_dicts(rng, V, N, 0.5, sos if sos < 0 else None)
+    lm = M.LookupLanguageModel(V, sos, [d.copy() for d in dicts]).to(DEV)
+    assert N not in (2, 3) or lm.offsets.dtype == torch.uint8
+    for n in range(0, N + 1):
+        hist = np.array(np.meshgrid(*[np.arange(V)] * n, indexing="ij")).reshape(n, -1) if n else np.zeros((0, 1), int)
+        act = lm(_t(hist.astype(np.int64)), None, -1)[0].cpu().numpy()
+        brute = oracle.backoff_log_probs(dicts, V, sos, hist, n)
+        assert np.allclose(brute, act, atol=1e-5, equal_nan=True), (N, n)
+        walk = oracle.trie_log_probs(
+            lm.logps.cpu().numpy(), lm.logbs.cpu().numpy(), lm.ids.cpu().numpy(),
+            lm.offsets.cpu().numpy(), V, sos, N, hist, n,
+        )  # fmt: skip
+        assert np.array_equal(walk, act, equal_nan=True), (N, n)
+
+
+def test_sos_context_known_answer():
+    """Facts from the reference's tests/test_lm.py:348-364 (0 = sos)."""
+    prob_dicts = [
+        {0: (-99, 0.0), 1: (0.1, -0.1), 2: (0.2, -0.2), 3: (0.3, -0.3)},
+        {(0, 1): (0.01, -0.01), (0, 2): (0.02, -0.02)},
+        {(0, 0, 1): 0.001},
+    ]
+    lm = M.LookupLanguageModel(4, 0, prob_dicts, destructive=True).to(DEV)
+    act = lm(torch.empty((0, 1), device=DEV, dtype=torch.long))
+    exp = torch.tensor([[[-99.0, 0.001, 0.02, 0.3]]], device=DEV)
+    assert torch.allclose(exp, act, atol=1e-5)
+
+
+def test_nonuniform_idx_matches_full():
+    """tests/test_lm.py:309-345: per-row positions select rows of the full table."""
+    rng = np.random.default_rng(7)
+    S, N, B, V, sos = 20, 5, 4, 10, -1
+    dicts = random_dicts(rng, V, N, 0.02 if N > 3 else 0.5, sos)
+    lm = M.LookupLanguageModel(V, sos, dicts, destructive=True).to(DEV)
+    hist = torch.randint(0, V, (S, B), device=DEV)
+    full = lm(hist)
+    assert not torch.isnan(full).any()
+    idx = torch.randint(0, S + 1, (B,), device=DEV)
+    exp = full.gather(0, idx.view(1, B, 1).expand(1, B, V)).squeeze(0)
+    assert torch.equal(exp, lm(hist, idx=idx)[0])
+    with pytest.raises(RuntimeError):
+        lm(hist, idx=torch.tensor([S + 1] * B, device=DEV))
+
+
+def test_large_vocabulary_and_wide_types():
+    """int32 offsets / int16 ids: a sparse trigram table over 3000 tokens."""
+    rng = np.random.default_rng(8)
+    V, sos = 3000, 3000
+    uni = {v: (float(rng.normal()), float(rng.normal())) for v in range(V)}
+    bi = {tuple(int(x) for x in rng.integers(0, V, 2)): (float(rng.normal()), float(rng.normal())) for _ in range(70000)}
+    tri = {tuple(int(x) for x in rng.integers(0, V, 3)): float(rng.normal()) for _ in range(5000)}
+    for k in list(bi)[:3000]:  # trigrams that extend real bigrams
+        tri[(int(rng.integers(0, V)),) + k] = float(rng.normal())
+    dicts = [uni, bi, tri]
+    lm = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    assert lm.ids.dtype == torch.int16 and lm.offsets.dtype in (torch.int32, torch.int64)
+    keys = list(tri)[-40:] + list(bi)[:40]
+    hist = np.array([list(k[:2]) if len(k) == 3 else [k[0], k[0]] for k in keys]).T
+    act = lm(_t(hist.astype(np.int64)), None, -1)[0].cpu().numpy()
+    brute = oracle.backoff_log_probs(dicts, V, sos, hist, 2)
+    assert np.allclose(brute, act, atol=1e-4, equal_nan=True)
+
+
+def test_state_dict_round_trip_on_device():
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, "C")
+    full = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    hist = _t(g["C_hist"])
+    exp = full(hist)
+    blank = M.LookupLanguageModel(V, sos).to(DEV)
+    assert blank(hist).shape == exp.shape  # uniform before loading
+    blank.load_state_dict(full.state_dict())
+    assert torch.equal(exp, blank(hist))
+
+
+def test_ctc_prefix_search_with_lookup_lm_fusion():
+    """CTCPrefixSearch(width, beta, lm=LookupLanguageModel) against the live reference."""
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, "B")
+    lm = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    search = M.CTCPrefixSearch(int(g["ctc_width"]), float(g["ctc_beta"]), lm)
+    y, yl, yp = search(_t(g["ctc_logits"]), _t(g["ctc_lens"]))
+    assert torch.equal(yl.cpu(), torch.from_numpy(g["ctc_y_lens"]))
+    mask = torch.arange(y.shape[0], device=DEV).view(-1, 1, 1) < yl.unsqueeze(0)
+    assert torch.equal(torch.where(mask, y, torch.zeros_like(y)).cpu(), torch.from_numpy(g["ctc_y"]))
+    assert np.allclose(g["ctc_y_probs"], yp.cpu().numpy(), rtol=1e-5, atol=1e-30)
+
+
+def test_beam_search_with_lookup_lm():
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, "C")
+    lm = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    y, yl, lp = M.BeamSearch(lm, 4, eos=0).to(DEV)(dict(), batch_size=3, max_iters=10)
+    assert torch.equal(yl.cpu(), torch.from_numpy(g["beam_lens"]))
+    assert np.allclose(g["beam_lp"], lp.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    S = y.shape[0]
+    mask = torch.arange(S, device=DEV).view(-1, 1, 1) < yl.unsqueeze(0)
+    exp = torch.from_numpy(g["beam_y"]).to(DEV)[:S]
+    assert torch.equal(torch.where(mask, y, exp), exp)
+
+
+def test_shallow_fusion_of_two_models():
+    """tests/test_lm.py:512-560: fused scores = first + beta * second, states kept apart."""
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, "B")
+    first = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    table = torch.randn((V + 1, V), device=DEV, generator=torch.Generator(DEV).manual_seed(3)).log_softmax(-1)
+    second = BigramLM(table)
+    beta = 0.7
+    lm = M.MixableShallowFusionLanguageModel(first, second, beta)
+    hist = _t(g["B_hist"]).clamp(0, V - 1)
+    exp = first(hist) + beta * second(hist)
+    assert torch.allclose(exp, lm(hist))
+    idx = torch.tensor(5, device=DEV)
+    lp, state = lm(hist, None, idx)
+    assert torch.allclose(exp[5], lp)
+    assert lm.extract_by_src(state, torch.arange(hist.shape[1], device=DEV)) == state
+    # drives a search like any other LM
+    y, yl, yp = M.CTCPrefixSearch(3, 0.2, lm)(torch.randn((6, 2, V + 1), device=DEV))
+    assert y.shape == (6, 2, 3) and torch.isfinite(yp).all()
+
+
+def test_scripted_lookup_lm():
+    """"JIT scripting is possible with this module, but not tracing" (reference _lm.py:568)."""
+    g = golden()
+    V, sos, N, dicts = dicts_from_golden(g, "C")
+    lm = M.LookupLanguageModel(V, sos, dicts).to(DEV)
+    scripted = torch.jit.script(lm)
+    hist, idx = _t(g["C_hist"]), _t(g["C_idx"])
+    assert torch.equal(lm(hist), scripted(hist))
+    assert torch.equal(lm(hist, None, idx)[0], scripted(hist, None, idx)[0])
+    search = M.CTCPrefixSearch(4, 0.3, lm)
+    logits = torch.randn((7, 3, V + 1), device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+    exp, act = search(logits), torch.jit.script(search)(logits)
+    for a, b in zip(exp, act):
+        assert torch.equal(a, b)
