@@ -291,6 +291,26 @@ int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h
                             const int32_t *ids, int64_t V, int64_t N, int64_t U, int64_t sos,
                             float *out, int32_t *status, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Variable-length padding (reference _pad.py:108-149), the data movement of RandomShift
+ * (_img.py:883-908).  x (N, T, F) contiguous, elements of elem_bytes in {1, 2, 4, 8} moved as
+ * opaque words; lens (N,), pad (2, N) int64; out (N, Tp, F) with Tp >= max(lens + pad sums):
+ *   out[n, :pad[0,n]]                          left padding
+ *   out[n, pad[0,n] : pad[0,n] + lens[n]]      x[n, :lens[n]]
+ *   ... + pad[1,n]                             right padding;  the rest: *fill
+ * mode 0 constant (*fill), 1 reflect (x[n, pad0 - t], x[n, lens - 2 - j]; the caller checks
+ * pad < lens), 2 replicate (x[n, 0], x[n, lens - 1]; the caller checks lens >= 1).
+ * pdt_pad_variable_backward: float32 adjoint with respect to x, written as a gather
+ * (deterministic); grad_out (N, Tp, F), grad_x (N, T, F).
+ * ------------------------------------------------------------------------------------- */
+int pdt_pad_variable(const void *x, int64_t N, int64_t T, int64_t F, int64_t elem_bytes,
+                     const int64_t *lens, const int64_t *pad, int mode, const void *fill,
+                     int64_t Tp, void *out, void *stream);
+
+int pdt_pad_variable_backward(const float *grad_out, int64_t N, int64_t T, int64_t F,
+                              const int64_t *lens, const int64_t *pad, int mode, int64_t Tp,
+                              float *grad_x, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

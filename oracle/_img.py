@@ -16,6 +16,7 @@ import numpy as np
 __all__ = [
     "dense_image_warp",
     "grid_sample",
+    "pad_variable",
     "polyharmonic_spline",
     "sparse_image_warp",
     "spec_augment_apply_parameters",
@@ -228,3 +229,34 @@ def spec_augment_apply_parameters(feats, params, interpolation_order, lengths=No
         ar = np.arange(F)[None, :, None]
         mask |= ((ar >= f_0[:, None, :]) & (ar < (f_0 + f)[:, None, :])).any(2)[:, None, :]
     return np.where(mask, np.zeros((), feats.dtype), out).astype(feats.dtype)
+
+
+def pad_variable(x, lens, pad, mode="constant", value=0.0):
+    """Loop restatement of the reference's ``pad_variable`` (_pad.py:108-149): per sequence,
+    left padding, the sequence, right padding, then ``value`` up to the longest new length."""
+    x = np.asarray(x)
+    lens, pad = np.asarray(lens), np.asarray(pad)
+    N = x.shape[0]
+    new_lens = lens + pad.sum(0)
+    Tp = int(new_lens.max()) if N else 0
+    out = np.full((N, Tp) + x.shape[2:], value, dtype=x.dtype)
+    for n in range(N):
+        L, (a, b) = int(lens[n]), (int(pad[0, n]), int(pad[1, n]))
+        seq = x[n, :L]
+        if mode == "constant":
+            left = np.full((a,) + x.shape[2:], value, dtype=x.dtype)
+            right = np.full((b,) + x.shape[2:], value, dtype=x.dtype)
+        elif mode == "reflect":
+            if a >= L or b >= L:
+                raise NotImplementedError("reflect padding must be shorter than the sequence")
+            left = seq[1 : a + 1][::-1]
+            right = seq[L - 1 - b : L - 1][::-1]
+        elif mode == "replicate":
+            if L < 1:
+                raise RuntimeError("replicate padding needs non-empty sequences")
+            left = np.repeat(seq[:1], a, 0)
+            right = np.repeat(seq[-1:], b, 0)
+        else:
+            raise ValueError(mode)
+        out[n, : a + L + b] = np.concatenate([left, seq, right], 0)
+    return out

@@ -13,15 +13,18 @@ import torch
 from torch.library import custom_op, register_autograd
 
 from . import _cabi, argcheck
+from ._pad import pad_variable
 
 __all__ = [
     "DenseImageWarp",
     "PolyharmonicSpline",
+    "RandomShift",
     "SparseImageWarp",
     "SpecAugment",
     "Warp1DGrid",
     "dense_image_warp",
     "polyharmonic_spline",
+    "random_shift",
     "sparse_image_warp",
     "spec_augment",
     "spec_augment_apply_parameters",
@@ -822,3 +825,65 @@ class SpecAugment(torch.nn.Module):
             return feats
         params = self.draw_parameters(feats, lengths)
         return self.apply_parameters(feats, params, lengths)
+
+
+def random_shift(
+    input: torch.Tensor,
+    in_lens: torch.Tensor,
+    prop: Tuple[float, float],
+    mode: str,
+    value: float,
+    training: bool = True,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Functional version of :class:`RandomShift` (reference _img.py:883-908): the draws use
+    torch's generator on ``in_lens``' device, the movement is one ``pad_variable`` pass."""
+    if input.dim() < 2:
+        raise RuntimeError("input must be at least 2 dimensional")
+    if in_lens.dim() != 1 or in_lens.size(0) != input.size(0):
+        raise RuntimeError(
+            "For input of shape {}, expected in_lens to be of shape ({}), got {}".format(
+                input.shape, input.size(0), in_lens.shape
+            )
+        )
+    if training:
+        in_lens_ = in_lens.float()
+        pad = torch.stack([prop[0] * in_lens_, prop[1] * in_lens_])
+        pad *= torch.rand_like(pad)
+        pad = pad.long()
+        out_lens = in_lens + pad.sum(0)
+        return pad_variable(input, in_lens, pad, mode, value), out_lens
+    else:
+        return input, in_lens
+
+
+class RandomShift(torch.nn.Module):
+    """Pad to the left and right of each sequence by a random amount (reference
+    _img.py:911-1017).  Identity in eval mode."""
+
+    __constants__ = ("prop", "mode", "value")
+
+    def __init__(self, prop, mode: str = "reflect", value: float = 0.0):
+        try:
+            prop = (argcheck.is_float(prop, "prop"), float(prop))
+        except (TypeError, ValueError):
+            prop = tuple(prop)
+        if len(prop) != 2:
+            raise ValueError("prop must be a single or pair of floating points, got '{}'".format(prop))
+        prop = (float(prop[0]), float(prop[1]))
+        if prop[0] < 0.0 or prop[1] < 0.0:
+            raise ValueError("prop values must be non-negative")
+        mode = argcheck.is_in(mode, ("reflect", "constant", "replicate"), "mode")
+        if mode == "reflect" and (prop[0] > 1.0 or prop[1] > 1.0):
+            raise NotImplementedError("if 'mode' is 'reflect', values in 'prop' must be <= 1")
+        value = argcheck.is_float(value, "value")
+        super().__init__()
+        self.mode, self.prop, self.value = mode, prop, value
+
+    def extra_repr(self) -> str:
+        return "prop={}, mode={}, value={}".format(self.prop, self.mode, self.value)
+
+    def reset_parameters(self) -> None:
+        pass
+
+    def forward(self, input: torch.Tensor, in_lens: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        return random_shift(input, in_lens, self.prop, self.mode, self.value, self.training)

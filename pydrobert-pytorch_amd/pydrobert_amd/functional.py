@@ -10,12 +10,14 @@ from ._decoding import ctc_greedy_search, random_walk_advance, sequence_log_prob
 from ._img import (
     dense_image_warp,
     polyharmonic_spline,
+    random_shift,
     sparse_image_warp,
     spec_augment,
     spec_augment_apply_parameters,
     spec_augment_draw_parameters,
     warp_1d_grid,
 )
+from ._pad import pad_variable
 from ._string import (
     hard_optimal_completion_distillation_loss,
     minimum_error_rate_loss,
@@ -28,6 +30,8 @@ from ._string import (
 )
 
 __all__ = [
+    "pad_variable",
+    "random_shift",
     "ctc_greedy_search",
     "random_walk_advance",
     "sequence_log_probs",

@@ -2,7 +2,15 @@
 operators on the MI355X hot path."""
 
 from ._decoding import BeamSearch, CTCPrefixSearch
-from ._img import DenseImageWarp, PolyharmonicSpline, SparseImageWarp, SpecAugment, Warp1DGrid
+from ._img import (
+    DenseImageWarp,
+    PolyharmonicSpline,
+    RandomShift,
+    SparseImageWarp,
+    SpecAugment,
+    Warp1DGrid,
+)
+from ._pad import PadVariable
 from ._decoding import CTCGreedySearch, RandomWalk, SequenceLogProbabilities
 from ._lm import (
     ExtractableSequentialLanguageModel,
@@ -25,6 +33,13 @@ from ._string import (
 )
 
 __all__ = [
+    "PadVariable",
+    "RandomShift",
+    "DenseImageWarp",
+    "PolyharmonicSpline",
+    "SparseImageWarp",
+    "SpecAugment",
+    "Warp1DGrid",
     "CTCGreedySearch",
     "RandomWalk",
     "SequenceLogProbabilities",

@@ -390,3 +390,21 @@ def lm_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "lm"):
     lm_goldens()
+
+
+def pad_goldens():
+    rng = np.random.default_rng(0x5EED0007)
+    N, T, F = 6, 9, 3
+    x = rng.normal(size=(N, T, F)).astype(np.float32)
+    lens = np.array([9, 4, 1, 7, 5, 9])
+    pad = np.array([[0, 3, 0, 6, 2, 1], [4, 2, 0, 1, 4, 0]])
+    d = dict(x=x, lens=lens, pad=pad, xi=rng.integers(-5, 5, (N, T)))
+    for mode in ("constant", "reflect", "replicate"):
+        d["out_" + mode] = F_.pad_variable(torch.from_numpy(x), torch.from_numpy(lens), torch.from_numpy(pad), mode, -1.5)
+        d["outi_" + mode] = F_.pad_variable(torch.from_numpy(d["xi"]), torch.from_numpy(lens), torch.from_numpy(pad), mode, 7)
+    save("pad", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "pad"):
+    F_ = F
+    pad_goldens()
