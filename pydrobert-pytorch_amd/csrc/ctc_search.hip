@@ -184,7 +184,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     L.pos = slot_pos(sl);
     const float s = slot_hdr(sl)[0];
     int ns, nt, nk;
+#ifndef PDT_SKIP_CONSUMER
     ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+#else
+    ns = nt = nk = 0; (void)s;
+#endif
     int *tmp = L.nxt_old;
     L.nxt_old = L.nxt_new;
     L.nxt_new = tmp;
