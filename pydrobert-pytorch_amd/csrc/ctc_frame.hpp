@@ -62,6 +62,11 @@ struct DenseCtx {
   int S;
 };
 
+// ints per next-token table: W * W, but at least 128 so that the table not in use (nxt_new
+// before the is-prefix update writes it) can double as the 64 x u64 scratch of the candidate
+// selection
+__host__ __device__ inline int nxt_stride(int W) { return W * W < 128 ? 128 : W * W; }
+
 // Per-wave LDS scratch of one frame.
 struct FrameLds {
   u64 *surv;           // [PDT_SURV_CAP] survivors of the top-M selection
@@ -70,7 +75,7 @@ struct FrameLds {
   unsigned char *pos;  // [V] list index of a token or 0xFF (shared list only)
   unsigned *chm;       // [max(W, Kp)] new beam entries that descend from old entry j
   int *info;           // [2 * W] packed description of every new beam entry
-  int *nxt_old, *nxt_new;  // [W * W] token of prefix b right after prefix a (trie form only)
+  int *nxt_old, *nxt_new;  // [nxt_stride(W)] token of prefix b right after prefix a (trie form only)
   static __host__ __device__ size_t bytes(int V, int W, int Kp, bool dense) {
     const int RS = W > Kp ? W : Kp;
     size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)(dense ? Kp : 1) * PDT_WAVE * 8;
@@ -277,6 +282,51 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
 
   new_src = 0, new_tok = 0, new_kind = -1;
   float new_mass = -PDT_INF;
+  // Fast path: the K winners all at once.  A lane holding a winner has a local maximum >= the
+  // K-th best candidate, and at most K lanes do, so tau = K-th largest local maximum bounds
+  // the winners from below; the (>= K, usually ~K) resident candidates >= tau are compacted
+  // and sorted once.  Ties resolve as in the serial rounds below (lowest lane, then slot).
+  // The serial rounds remain for the frames where the result could depend on entries that are
+  // not resident: more than 64 survivors, or a winner that is the last resident stream-0
+  // entry of its prefix (the rounds would refill that prefix's slots).
+  bool selected = false;
+  {
+    u64 *sel = DENSE ? L.surv : reinterpret_cast<u64 *>(L.nxt_new);
+    const unsigned lk = max(max(key0, key1), key2);
+    const unsigned slk = wave_sort_desc<unsigned>(lk);
+    const unsigned tau = max((unsigned)__builtin_amdgcn_readlane((int)slk, K - 1), 1u);
+    const bool p0 = key0 >= tau, p1 = key1 >= tau, p2 = key2 >= tau;
+    const u64 b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2);
+    const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2);
+    const int count = c0 + c1 + c2;
+    if (count <= PDT_WAVE) {
+      auto below = [&](u64 b) {
+        return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      };
+      if (p0) sel[below(b0)] = pack_key(key0, (unsigned)(lane * 4 + 0));
+      if (p1) sel[c0 + below(b1)] = pack_key(key1, (unsigned)(lane * 4 + 1));
+      if (p2) sel[c0 + c1 + below(b2)] = pack_key(key2, (unsigned)(lane * 4 + 2));
+      wave_sync();
+      const u64 s = wave_sort_desc<u64>(lane < count ? sel[lane] : 0ull);
+      wave_sync();  // sel is nxt_new: the is-prefix update below writes it
+      const unsigned wkey = key_of(s);
+      const bool isw = lane < K && wkey != 0u;
+      const int id = isw ? (int)idx_of(s) : 0;
+      const int wl = id >> 2, sw = id & 3;
+      const int e = (wl / G) + R * sw;
+      if (__ballot(isw && e == n_main - 1) == 0ull) {
+        const int t0 = __shfl(tk0, wl), t1 = __shfl(tk1, wl), t2 = __shfl(tk2, wl);
+        if (isw) {
+          new_src = wl & (G - 1);
+          new_tok = sw == 0 ? t0 : (sw == 1 ? t1 : t2);
+          new_kind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
+          new_mass = fkey_inv(wkey);
+        }
+        selected = true;
+      }
+    }
+  }
+  if (!selected)
   for (int i = 0; i < K; ++i) {
     const unsigned lk = max(max(key0, key1), key2);
     const unsigned mx = wave_max_u32(lk);

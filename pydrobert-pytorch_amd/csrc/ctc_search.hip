@@ -39,7 +39,7 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
   r.pos_bytes = (V + 15) & ~15;
   r.slot_bytes = r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
   r.nstage = nstage;
-  const int consumer = (W > 0 ? W : 1) * 4 * 3 + 2 * W * W * 4;  // chm + info + nxt tables
+  const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
   r.utt_bytes = (r.slot_bytes * nstage + consumer + PDT_SURV_CAP * 8 + 16 + 15) & ~15;
   r.utt_per_wg = utt_per_wg;
   return r;
@@ -63,7 +63,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
   unsigned char *cs = ub + (size_t)rl.slot_bytes * rl.nstage;      // consumer scratch
-  u64 *surv = reinterpret_cast<u64 *>(cs + (W * 4 * 3 + 2 * W * W * 4));
+  u64 *surv = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
   int *flags = reinterpret_cast<int *>(surv + PDT_SURV_CAP);        // [0] produced, [1] consumed
   auto slot_row = [&](int sl) { return reinterpret_cast<float *>(ring + (size_t)sl * rl.slot_bytes); };
   auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(slot_row(sl) + rl.row_floats); };
@@ -158,10 +158,10 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   // ---- consumer: the sequential beam update ----------------------------------------------
   FrameLds L;
   L.surv = surv;  // unused by the shared-list form
-  L.chm = reinterpret_cast<unsigned *>(cs);
+  L.nxt_old = reinterpret_cast<int *>(cs);  // 8-byte aligned: nxt_new doubles as u64 scratch
+  L.nxt_new = L.nxt_old + nxt_stride(W);
+  L.chm = reinterpret_cast<unsigned *>(L.nxt_new + nxt_stride(W));
   L.info = reinterpret_cast<int *>(L.chm + W);
-  L.nxt_old = L.info + 2 * W;
-  L.nxt_new = L.nxt_old + W * W;
   Beam bm;  // :1097-1105: one empty prefix with all the mass on "ends in blank"
   bm.nb = lane == 0 ? 0.0f : -PDT_INF;
   bm.b = lane == 0 ? 1.0f : -PDT_INF;
