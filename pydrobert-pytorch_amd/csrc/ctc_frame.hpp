@@ -303,11 +303,25 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       auto below = [&](u64 b) {
         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
       };
+      sel[lane] = 0ull;
+      wave_sync();
       if (p0) sel[below(b0)] = pack_key(key0, (unsigned)(lane * 4 + 0));
       if (p1) sel[c0 + below(b1)] = pack_key(key1, (unsigned)(lane * 4 + 1));
       if (p2) sel[c0 + c1 + below(b2)] = pack_key(key2, (unsigned)(lane * 4 + 2));
       wave_sync();
-      const u64 s = wave_sort_desc<u64>(lane < count ? sel[lane] : 0ull);
+      // rank by counting: the packed keys are distinct, so the number of larger survivors is
+      // a survivor's position in the sorted order (2 VALU per survivor instead of a 21-stage
+      // bitonic network; the LDS reads are same-address broadcasts)
+      const u64 mine = sel[lane];
+      int rank = 0;
+      for (int j = 0; j < count; j += 4) {
+        const u64 o0 = sel[j], o1 = sel[j + 1], o2 = sel[j + 2], o3 = sel[j + 3];
+        rank += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
+      }
+      wave_sync();
+      if (lane < count && rank < K) sel[rank] = mine;
+      wave_sync();
+      const u64 s = (lane < K && lane < count) ? sel[lane] : 0ull;
       wave_sync();  // sel is nxt_new: the is-prefix update below writes it
       const unsigned wkey = key_of(s);
       const bool isw = lane < K && wkey != 0u;
