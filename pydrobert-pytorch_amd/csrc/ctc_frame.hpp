@@ -103,22 +103,24 @@ __device__ __forceinline__ int ctc_list_len(int V, int W, int Kp) {
   return min(V, K + Kp);
 }
 
-// Shared sorted token list of one frame from the unnormalised row p[0..V) (sum = normaliser):
+// Shared sorted token list of one frame from the unnormalised row p[0..V) (inv = 1 / normaliser):
 // tl_tok / tl_p (normalised) / pos (inverse index; entries of the previous list must be 0xFF).
-__device__ __forceinline__ void build_shared_list(const float *p, float sum, int V, int M, u64 *surv,
+__device__ __forceinline__ void build_shared_list(const float *p, float inv, int V, int M, u64 *surv,
                                                   int *tl_tok, float *tl_p, unsigned char *pos) {
   const int lane = lane_id();
   const u64 tk = wave_top_sorted(p, V, M, surv);
   if (lane < M) {
     const int tok = (int)idx_of(tk);
     tl_tok[lane] = tok;
-    tl_p[lane] = __fdiv_rn(p[tok], sum);
+    tl_p[lane] = p[tok] * inv;
     pos[tok] = (unsigned char)lane;
   }
 }
 
 // One frame of the search.  `p` holds the (unnormalised) non-extension probabilities of
-// v in [0, V] (index V = blank) and `sum` their normaliser (1 when already normalised).
+// v in [0, V] (index V = blank) and `inv` the reciprocal of their normaliser (1 when already
+// normalised): probabilities are p * inv, one correctly rounded reciprocal per frame instead
+// of a division per use (<= 1 ulp from the quotient, far inside the 1e-5 parity tolerance).
 // Kp = number of live lanes (1 at t = 0, then W).
 // On return new_src / new_tok / new_kind describe where lane i's new prefix came from
 // (kind: 0/1 extension, 2 non-extension, -1 invalid).
@@ -131,7 +133,7 @@ __device__ __forceinline__ void build_shared_list(const float *p, float sum, int
 #endif
 
 template <bool DENSE>
-__device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float sum, const int V,
+__device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float inv, const int V,
                                           const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
                                           const FrameLds &L, int &new_src, int &new_tok,
@@ -160,9 +162,9 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   const int *mt = L.tl_tok + (DENSE ? me : 0) * PDT_WAVE;
 
   // ---- candidate masses that do not depend on the token (:777-794) ----------------------
-  const float p_blank = __fdiv_rn(p[V], sum);
+  const float p_blank = p[V] * inv;
   const int lastc = min(max(bm.last, 0), V - 1);
-  const float pl = __fdiv_rn(p[lastc], sum);  // non-extension probability of my last token
+  const float pl = p[lastc] * inv;  // non-extension probability of my last token
   const float e_last = DENSE ? dc.ext[me * dc.ext_sk + lastc * dc.ext_sv] : pl;
   const float tot = bm.nb + bm.b;
   const float B = tot * p_blank;

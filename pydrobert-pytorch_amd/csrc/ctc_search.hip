@@ -23,6 +23,16 @@
 
 namespace pdt {
 
+// exp(x) for x <= 0 (softmax numerators): OCML's expf without its overflow / underflow guards --
+// the same hi/lo range reduction around v_exp_f32; v_ldexp_f32 flushes what underflows.
+__device__ __forceinline__ float exp_nonpos(float x) {
+  const float t = x * 0x1.715476p+0f;                       // x * log2(e), rounded
+  const float lo = __builtin_fmaf(x, 0x1.715476p+0f, -t);   // its rounding error
+  const float n = __builtin_rintf(t);
+  const float f = (t - n) + __builtin_fmaf(x, 0x1.4ae0bep-26f, lo);  // + x * (log2(e) - fl(log2(e)))
+  return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
 // LDS ring slot shared by the producer and consumer waves of one utterance.
 struct RingLayout {
   int row_floats;   // V + 1 padded to 4
@@ -137,16 +147,17 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       mx = wave_max_f(mx);
       float s = 0.0f;
       for (int v = lane; v <= V; v += PDT_WAVE) {
-        const float e = expf(p[v] - mx);
+        const float e = exp_nonpos(p[v] - mx);
         p[v] = e;
         s += e;
       }
       s = wave_sum_f(s);
       wave_sync();
       const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
-      build_shared_list(p, s, V, M, surv, tl_tok, slot_p(sl), pos);
+      const float inv = __fdiv_rn(1.0f, s);  // the only division of the frame
+      build_shared_list(p, inv, V, M, surv, tl_tok, slot_p(sl), pos);
       if (lane == 0) {
-        hdr[0] = s;
+        hdr[0] = inv;
         hdr[2] = __int_as_float(M);
       }
       wave_sync();
@@ -182,7 +193,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     L.tl_tok = slot_tok(sl);
     L.tl_p = slot_p(sl);
     L.pos = slot_pos(sl);
-    const float s = slot_hdr(sl)[0];
+    const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
 #ifndef PDT_SKIP_CONSUMER
     ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
