@@ -51,10 +51,10 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   bm.last = lane < Kp ? (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)-1), (int64_t)V) : 0;
   bm.len = lane < Kp ? (int)a.lens[n * a.le_sn + lane * a.le_sk] : 0;
   bm.node = -1;
-  u64 m = 0ull;
+  unsigned m = 0u;
   if (lane < Kp)
     for (int b = 0; b < Kp; ++b)
-      if (a.isp[n * a.ip_sn + lane * a.ip_sa + b * a.ip_sb]) m |= 1ull << b;
+      if (a.isp[n * a.ip_sn + lane * a.ip_sa + b * a.ip_sb]) m |= 1u << b;
   bm.isp = m;
   wave_sync();
 
@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
     a.b_next[n * W + lane] = bm.b;
     a.next_src[n * W + lane] = valid ? new_src : 0;
     a.next_nonext[n * W + lane] = (uint8_t)(new_kind == 2);
-    for (int b = 0; b < W; ++b) a.next_isp[(n * W + lane) * W + b] = (uint8_t)((bm.isp >> b) & 1ull);
+    for (int b = 0; b < W; ++b) a.next_isp[(n * W + lane) * W + b] = (uint8_t)((bm.isp >> b) & 1u);
     srcs[lane] = valid ? new_src : -1;
     // the new token sits right after the source prefix (:862-864)
     if (valid && new_kind != 2) a.y_next[((int64_t)(bm.len - 1) * a.N + n) * W + lane] = new_tok;

@@ -39,7 +39,7 @@ struct CtcArgs {
 struct Beam {
   float nb, b;
   int last, len, node;
-  u64 isp;  // bit k' set <=> this prefix is a prefix of beam entry k'
+  unsigned isp;  // bit k' set <=> this prefix is a prefix of beam entry k' (beam width <= 32)
 };
 
 __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
@@ -188,13 +188,13 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // ---- merge: an extension of kk that equals an existing prefix feeds that prefix --------
   // (:804-837); only prefixes that have descendants in the beam are visited
   float add = 0.0f;
-  u64 par = __ballot(live && (bm.isp & ~(1ull << lane)) != 0ull);
+  u64 par = __ballot(live && (bm.isp & ~(1u << lane)) != 0u);
   while (par) {
     const int kk = (int)__builtin_ctzll(par);
     par &= par - 1ull;
-    const u64 isp_kk = readlane_u64(bm.isp, kk);
+    const unsigned isp_kk = (unsigned)__builtin_amdgcn_readlane((int)bm.isp, kk);
     const int len_kk = __builtin_amdgcn_readlane(bm.len, kk);
-    const bool child = live && ((isp_kk >> lane) & 1ull) && (len_kk + 1 == bm.len);
+    const bool child = live && ((isp_kk >> lane) & 1u) && (len_kk + 1 == bm.len);
     u64 cm = __ballot(child);
     if (cm == 0ull) continue;
     const float nb_kk = readlane_f(bm.nb, kk), b_kk = readlane_f(bm.b, kk);
@@ -251,9 +251,31 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // fills the stream-0 slots of every lane whose prefix is in `mask_k` from that prefix's
   // current `avail`
   auto fill_main = [&](bool mine) {
-    u64 av = shfl_u64(avail, ksrc);
     const int *lt = L.tl_tok + (DENSE ? ksrc : 0) * PDT_WAVE;
     const float *lp = L.tl_p + (DENSE ? ksrc : 0) * PDT_WAVE;
+    if (M <= 32) {  // the usual case (K + K' <= 32): half the work per bit operation
+      unsigned av = (unsigned)__shfl((int)(unsigned)avail, ksrc);
+      for (int i = 0; i < rr; ++i) av &= av - 1u;
+#pragma unroll
+      for (int sl = 0; sl < 3; ++sl) {
+        const int e = rr + R * sl;
+        unsigned key = 0u;
+        int tok = 0;
+        if (e < n_main && av != 0u && kvalid) {
+          const int j = __builtin_ctz(av);
+          tok = lt[j];
+          key = fkey(tot_k * lp[j]);
+        }
+        if (mine && e < n_main) {
+          if (sl == 0) { key0 = key; tk0 = tok; }
+          if (sl == 1) { key1 = key; tk1 = tok; }
+          if (sl == 2) { key2 = key; tk2 = tok; }
+        }
+        for (int i = 0; i < R; ++i) av &= av - 1u;
+      }
+      return;
+    }
+    u64 av = shfl_u64(avail, ksrc);
     for (int i = 0; i < rr; ++i) av &= av - 1ull;  // skip to entry rr
 #pragma unroll
     for (int sl = 0; sl < 3; ++sl) {
@@ -377,7 +399,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   const int srcl = new_kind >= 0 ? new_src : lane;
   const float NB_s = shfl_f(NB, srcl), B_s = shfl_f(B, srcl);
   const int last_s = __shfl(lastc, srcl), len_s = __shfl(bm.len, srcl), node_s = __shfl(bm.node, srcl);
-  const u64 isp_s = shfl_u64(bm.isp, srcl);
+  const unsigned isp_s = (unsigned)__shfl((int)bm.isp, srcl);
   const bool is_ext = new_kind == 0 || new_kind == 1;
   const bool is_valid = new_kind >= 0;
   Beam nw;
@@ -403,11 +425,11 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     L.info[2 * lane + 1] = len_s | (new_src << 20) | ((is_ext ? 1 : 0) << 28);
   }
   wave_sync();
-  u64 isp_new = 0ull;
+  unsigned isp_new = 0u;
   bool need_walk = false;
   if (is_valid) {
     unsigned cand = 0u;
-    for (u64 m = isp_s; m; m &= m - 1ull) cand |= L.chm[__builtin_ctzll(m)];
+    for (unsigned m = isp_s; m; m &= m - 1u) cand |= L.chm[__builtin_ctz(m)];
     while (cand) {
       const int b = __builtin_ctz(cand);
       cand &= cand - 1u;
@@ -423,7 +445,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       else
         tok_at = ext_b ? tok_b : -1;  // lenB == len_s
       if (is_ext && tok_at != new_tok) continue;
-      isp_new |= 1ull << b;
+      isp_new |= 1u << b;
       if (!DENSE && nw.len < len_b) {  // strict prefix: the token that follows me inside b
         int nx;
         if (!is_ext) {
@@ -445,7 +467,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     for (int b = 0; b < K; ++b) {
       const int node_b = __builtin_amdgcn_readlane(node_s, b);
       const int lenB = __builtin_amdgcn_readlane(len_s, b);
-      if (need_walk && ((isp_new >> b) & 1ull) && L.nxt_new[lane * W + b] == -(2 + b)) {
+      if (need_walk && ((isp_new >> b) & 1u) && L.nxt_new[lane * W + b] == -(2 + b)) {
         int node = node_b, depth = lenB, tok = -1;
         while (node >= 0) {
           const int tt = node / W, ii = node - tt * W;

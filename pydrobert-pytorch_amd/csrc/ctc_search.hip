@@ -179,7 +179,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   bm.last = 0;
   bm.len = 0;
   bm.node = -1;
-  bm.isp = lane == 0 ? 1ull : 0ull;
+  bm.isp = lane == 0 ? 1u : 0u;
   int Kp = 1;
 #ifdef PDT_STAMPS
   unsigned long long pdt_stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
