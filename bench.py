@@ -191,11 +191,21 @@ def main():
     }
     # HBM bytes per launch from rocprofv3 PMC passes (profiles/), only for the profiled config
     traffic = None
+    valu = None
     tpath = os.path.join(ROOT, "profiles", "r01_ctc_traffic.json")
     if dom == "ctc_prefix_search" and os.path.exists(tpath):
         rec = json.load(open(tpath))
         if rec["config"] == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
             traffic = rec["hbm_bytes_per_launch"]
+            if "sq" in rec:
+                # what actually bounds this kernel: VALU issue.  A wave64 VALU instruction holds
+                # its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
+                insts = rec["sq"]["SQ_INSTS_VALU_per_launch"]
+                valu = {
+                    "wave_insts_per_launch": insts,
+                    "pipe_busy_frac": insts * 4 / (1024 * 2.4e9 * op_ms[dom] * 1e-3),
+                    "source": "profiles/r01_ctc_sq_counters.csv (rocprofv3 --pmc SQ_INSTS_VALU)",
+                }
 
     if rank == 0:
         out = {
@@ -228,6 +238,7 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "valu": valu,
             },
         }
         if world == 1 and not args.no_cpu_baseline:
