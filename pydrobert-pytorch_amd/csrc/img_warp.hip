@@ -400,6 +400,108 @@ spec_augment_backward_kernel(const SpecAugArgs a, const float *__restrict__ grad
   }
 }
 
+// Adjoint of spec_augment_rows_kernel written as a GATHER (no atomics, no zero fill,
+// deterministic): a workgroup owns 256 source rows of one utterance; a source row y collects
+// w0(t) * g[t] from the output rows t sampled at y0(t) = y and w1(t) * g[t] from those at
+// y0(t) = y - 1.  Warp grids are non-decreasing (warp_1d_grid pins both ends), so those rows
+// form one contiguous range found by binary search over the per-row table in LDS; for any
+// other grid the range degrades to all rows (still exact, just slower).
+__global__ void __launch_bounds__(256)
+spec_augment_rows_backward_kernel(const SpecAugArgs a, const float *__restrict__ grad_out,
+                                  float *__restrict__ grad_feats, int tiles) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int T = a.T, F4 = a.F >> 2;
+  int *sy0 = reinterpret_cast<int *>(smem);             // [T] source row of output row t
+  float *sw0 = reinterpret_cast<float *>(sy0 + T);      // [T] weight of row y0 (0 if masked)
+  float *sw1 = sw0 + T;                                 // [T] weight of row y0 + 1
+  int *lb = reinterpret_cast<int *>(sw1 + T);           // [258] first t with y0(t) >= y_b - 1 + i
+  unsigned *col_keep = reinterpret_cast<unsigned *>(lb + 260);  // [64]
+  const int64_t n = blockIdx.x / tiles;
+  const int tile = (int)(blockIdx.x % tiles);
+  const int y_b = tile * kRowsPerTile, y_e = min(T, y_b + kRowsPerTile);
+  const int tid = (int)threadIdx.x;
+  bool bad = false;
+  for (int t = tid; t < T; t += 256) {
+    bool masked = false;
+    for (int m = 0; m < a.MT; ++m) {
+      const int64_t s = a.t0[n * a.MT + m];
+      masked = masked || (t >= s && t < s + a.tl[n * a.MT + m]);
+    }
+    int y0 = t;
+    float w0 = 1.0f, w1 = 0.0f;
+    if (a.tgrid) {
+      const float iy = clip_coord(unnormalize(a.tgrid[n * T + t], T), T);
+      const float y0f = floorf(iy);
+      y0 = (int)y0f;
+      w1 = iy - y0f;
+      w0 = ((float)y0 + 1.0f) - ((float)y0 + w1);  // as the forward kernel
+      if (y0 + 1 >= T) w1 = 0.0f;                  // tap outside the image
+      if (t > 0) {
+        const float ip = clip_coord(unnormalize(a.tgrid[n * T + t - 1], T), T);
+        bad = bad || ((int)floorf(ip) > y0);
+      }
+    }
+    sy0[t] = y0;
+    sw0[t] = masked ? 0.0f : w0;
+    sw1[t] = masked ? 0.0f : w1;
+  }
+  for (int c = tid; c < F4; c += 256) {
+    unsigned keep = 0u;
+    for (int j = 0; j < 4; ++j) {
+      const int f = 4 * c + j;
+      bool fm = false;
+      for (int m = 0; m < a.MF; ++m) {
+        const int64_t s = a.f0[n * a.MF + m];
+        fm = fm || (f >= s && f < s + a.fl[n * a.MF + m]);
+      }
+      keep |= fm ? 0u : (1u << j);
+    }
+    col_keep[c] = keep;
+  }
+  const bool monotone = !__syncthreads_or(bad);
+  for (int i = tid; i < kRowsPerTile + 2; i += 256) {
+    int lo = 0, hi = T;
+    if (monotone) {
+      const int target = y_b - 1 + i;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sy0[mid] < target) lo = mid + 1; else hi = mid;
+      }
+    } else {
+      lo = i == 0 ? 0 : T;  // every range becomes [0, T)
+    }
+    lb[i] = lo;
+  }
+  __syncthreads();
+  const float *gn = grad_out + n * (int64_t)T * a.F;
+  float *on = grad_feats + n * (int64_t)T * a.F;
+  const float inv = 1.0f / (float)F4;
+  const int total = (y_e - y_b) * F4;
+  for (int idx = tid; idx < total; idx += 256) {
+    int r = (int)(((float)idx + 0.5f) * inv);
+    int f4 = idx - r * F4;
+    if (f4 < 0) { --r; f4 += F4; }
+    if (f4 >= F4) { ++r; f4 -= F4; }
+    const int y = y_b + r;
+    const int t_lo = monotone ? lb[r] : 0, t_hi = monotone ? lb[r + 2] : T;
+    float4 acc = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int t = t_lo; t < t_hi; ++t) {
+      const int y0 = sy0[t];
+      const float w = y0 == y ? sw0[t] : (y0 + 1 == y ? sw1[t] : 0.0f);
+      if (w != 0.0f) {
+        const float4 g = *reinterpret_cast<const float4 *>(gn + (int64_t)t * a.F + 4 * f4);
+        acc.x += g.x * w; acc.y += g.y * w; acc.z += g.z * w; acc.w += g.w * w;
+      }
+    }
+    const unsigned keep = col_keep[f4];
+    acc.x = (keep & 1u) ? acc.x : 0.0f;
+    acc.y = (keep & 2u) ? acc.y : 0.0f;
+    acc.z = (keep & 4u) ? acc.z : 0.0f;
+    acc.w = (keep & 8u) ? acc.w : 0.0f;
+    *reinterpret_cast<float4 *>(on + (int64_t)y * a.F + 4 * f4) = acc;
+  }
+}
+
 struct WarpArgs {
   const float *image;  // (N,C,H,W) contiguous
   float *out;          // (N,C,H,W)
@@ -614,6 +716,14 @@ int pdt_spec_augment_apply_backward(const float *grad_out, int64_t N, int64_t T,
   a.tgrid = time_grid; a.fgrid = freq_grid;
   a.t0 = t_0; a.tl = t_len; a.f0 = f_0; a.fl = f_len;
   a.N = (int)N; a.T = (int)T; a.F = (int)F; a.MT = (int)MT; a.MF = (int)MF;
+  const size_t rows_smem = (size_t)T * 12 + 260 * 4 + 64 * 4;
+  if (!freq_grid && F % 4 == 0 && F <= 256 && rows_smem <= 64 * 1024 &&
+      ((uintptr_t)grad_out % 16 == 0) && ((uintptr_t)grad_feats % 16 == 0)) {
+    const int rtiles = (int)((T + kRowsPerTile - 1) / kRowsPerTile);
+    hipLaunchKernelGGL(spec_augment_rows_backward_kernel, dim3((unsigned)(N * rtiles)), dim3(256),
+                       rows_smem, (hipStream_t)stream, a, grad_out, grad_feats, rtiles);
+    return (int)hipGetLastError();
+  }
   hipError_t e = hipMemsetAsync(grad_feats, 0, (size_t)(N * T * F) * sizeof(float), (hipStream_t)stream);
   if (e != hipSuccess) return (int)e;
   int tiles = (int)((T * F + 16383) / 16384);
