@@ -212,16 +212,21 @@ int pdt_oracle_ctc_prefix_search_advance(
   return 0;
 }
 
-/* softmax over the last axis in float32 (logits.softmax(2), _decoding.py:1093) */
+/* softmax over the last axis in float32 (logits.softmax(2), _decoding.py:1093).  The
+ * normaliser is accumulated in double and rounded once: ATen sums float32 lanes pairwise
+ * (error ~ sqrt(n / lanes) ulp), a sequential float32 sum would drift ~ sqrt(n) ulp away from
+ * it for vocabularies in the thousands -- more than the 1e-5 parity tolerance after a few
+ * dozen frames.  For n <= a few hundred the two are indistinguishable (goldens: n = 13). */
 static void softmax_f32(const float *x, int64_t n, float *y) {
   float mx = -INFINITY;
   for (int64_t i = 0; i < n; ++i)
     if (x[i] > mx) mx = x[i];
-  float s = 0.0f;
+  double acc = 0.0;
   for (int64_t i = 0; i < n; ++i) {
     y[i] = expf(x[i] - mx);
-    s += y[i];
+    acc += (double)y[i];
   }
+  const float s = (float)acc;
   for (int64_t i = 0; i < n; ++i) y[i] = y[i] / s;
 }
 

@@ -41,40 +41,51 @@ struct RingLayout {
   int nstage;
   int utt_bytes;    // ring + consumer scratch + producer scratch + flags
   int utt_per_wg;
+  int producers;    // producer waves per utterance
 };
 
-__host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int utt_per_wg) {
+__host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int utt_per_wg,
+                                                  int producers) {
   RingLayout r;
   r.row_floats = (V + 1 + 3) & ~3;
   r.pos_bytes = (V + 15) & ~15;
   r.slot_bytes = r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
   r.nstage = nstage;
   const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
-  r.utt_bytes = (r.slot_bytes * nstage + consumer + PDT_SURV_CAP * 8 + 16 + 15) & ~15;
+  r.utt_bytes = (r.slot_bytes * nstage + consumer + producers * PDT_SURV_CAP * 8 + 32 + 15) & ~15;
   r.utt_per_wg = utt_per_wg;
+  r.producers = producers;
   return r;
 }
 
-// Workgroup = utt_per_wg x (producer wave, consumer wave).  The producer streams the logits:
-// softmax statistics + sorted top-M token list of frame t go into ring slot t % nstage while
-// the consumer runs the (sequential) beam update of earlier frames -- the two dependency
-// chains overlap instead of adding up.  Hand-off through two LDS counters per utterance
-// (workgroup-scope release / acquire; both waves run exactly Tn iterations).
-__global__ void __launch_bounds__(256, 8) __attribute__((amdgpu_num_sgpr(80)))
+// Workgroup = utt_per_wg x (P producer waves + one consumer wave).  A producer streams the
+// logits: softmax statistics + sorted top-M token list of frame t go into ring slot t % nstage
+// while the consumer runs the (sequential) beam update of earlier frames -- the dependency
+// chains overlap instead of adding up.  The producer side has no dependence between frames,
+// so for long rows (large V, where one wave per frame is the bottleneck) P > 1 producers take
+// frames t = p, p + P, ... in turn.  Hand-off through LDS words per utterance
+// (workgroup-scope release / acquire): ready[slot] = t + 1 once frame t is in its slot,
+// consumed = number of frames the consumer has finished.
+template <int P>
+__global__ void __launch_bounds__(256, P == 1 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
-  const int u = wave >> 1;
-  const bool producer = (wave & 1) == 0;
+  const int u = wave / (P + 1);
+  const int role = wave - u * (P + 1);  // 0 .. P-1: producer, P: consumer
+  const bool producer = role < P;
   const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
   if (u >= rl.utt_per_wg || n >= a.N) return;
   const int V = a.V, W = a.W;
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
   unsigned char *cs = ub + (size_t)rl.slot_bytes * rl.nstage;      // consumer scratch
-  u64 *surv = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
-  int *flags = reinterpret_cast<int *>(surv + PDT_SURV_CAP);        // [0] produced, [1] consumed
+  u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
+  const int pr = (P == 1 || !producer) ? 0 : role;                   // producer index
+  u64 *surv = surv0 + pr * PDT_SURV_CAP;                             // one scratch per producer
+  int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
+  int *ready = consumed + 1;                                          // [nstage] frame + 1 held by a slot
   auto slot_row = [&](int sl) { return reinterpret_cast<float *>(ring + (size_t)sl * rl.slot_bytes); };
   auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(slot_row(sl) + rl.row_floats); };
   auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
@@ -84,30 +95,28 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   const int NS = rl.nstage;
 
   if (producer) {
-    for (int sl = 0; sl < NS; ++sl)
+    for (int sl = pr; sl < NS; sl += P)
       for (int v = lane; v < rl.pos_bytes; v += PDT_WAVE) slot_pos(sl)[v] = 0xFF;
-    if (lane == 0) {
-      __hip_atomic_store(&flags[1], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      __hip_atomic_store(&flags[0], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+    if (pr == 0 && lane <= NS)  // consumed and ready[0 .. NS)
+      __hip_atomic_store(&consumed[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();  // flags / pos tables initialised (the only workgroup barrier)
 
   if (producer) {
     constexpr int kPrefetch = 8;
     float pre[kPrefetch];
-    if (Tn > 0) {
-      const float *row0 = a.logits + n * a.lg_sn;
+    if (pr < Tn) {
+      const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn;
 #pragma unroll
       for (int i = 0; i < kPrefetch; ++i) {
         const int v = lane + i * PDT_WAVE;
         pre[i] = v <= V ? row0[(int64_t)v * a.lg_sv] : 0.0f;
       }
     }
-    for (int t = 0; t < Tn; ++t) {
+    for (int t = pr; t < Tn; t += P) {
       const int sl = t % NS;
       // wait for the slot to be free: at most NS frames in flight
-      while (t - __hip_atomic_load(&flags[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
+      while (t - __hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
         __builtin_amdgcn_s_sleep(2);
       float *p = slot_row(sl);
       int *tl_tok = slot_tok(sl);
@@ -136,8 +145,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
           mx = fmaxf(mx, x);
         }
       }
-      if (t + 1 < Tn) {
-        const float *nrow = a.logits + (int64_t)(t + 1) * a.lg_st + n * a.lg_sn;
+      if (t + P < Tn) {
+        const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn;
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i) {
           const int v = lane + i * PDT_WAVE;
@@ -161,7 +170,9 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         hdr[2] = __int_as_float(M);
       }
       wave_sync();
-      if (lane == 0) __hip_atomic_store(&flags[0], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      // one producer: frames arrive in order and ready[0] is a plain frame counter
+      if (lane == 0)
+        __hip_atomic_store(&ready[P == 1 ? 0 : sl], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     return;
   }
@@ -187,7 +198,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   for (int t = 0; t < Tn; ++t) {
     PDT_STAMP_BEGIN;
     const int sl = t % NS;
-    while (__hip_atomic_load(&flags[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t)
+    while (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t)
       __builtin_amdgcn_s_sleep(2);
     PDT_STAMP(0);
     L.tl_tok = slot_tok(sl);
@@ -204,7 +215,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     L.nxt_old = L.nxt_new;
     L.nxt_new = tmp;
     Kp = W;
-    if (lane == 0) __hip_atomic_store(&flags[1], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
 
 #ifdef PDT_STAMPS
@@ -235,26 +246,41 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #endif
 }
 
-int launch_ctc_search(CtcArgs a, hipStream_t stream) {
-  if (a.W < 1 || a.W > kMaxWidth) return PDT_E_TOO_LONG;
-  // ring depth and utterances per workgroup from the LDS budget
-  int nstage = 4, upw = 2;
-  RingLayout rl = ring_layout(a.V, a.W, nstage, upw);
-  const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
-  while ((size_t)rl.utt_bytes * upw > soft_cap && (upw > 1 || nstage > 2)) {
-    if (upw > 1) upw = 1; else nstage = 2;
-    rl = ring_layout(a.V, a.W, nstage, upw);
-  }
-  const size_t smem = (size_t)rl.utt_bytes * upw;
-  if (smem > hard_cap) return PDT_E_TOO_LONG;
-  if (smem > soft_cap) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel),
+template <int P>
+static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream_t stream) {
+  const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  const unsigned grid = (unsigned)((a.N + upw - 1) / upw);
-  hipLaunchKernelGGL(ctc_search_kernel, dim3(grid), dim3(128 * upw), smem, stream, a, rl);
+  const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
+  hipLaunchKernelGGL(ctc_search_kernel<P>, dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
+                     stream, a, rl);
   return (int)hipGetLastError();
+}
+
+int launch_ctc_search(CtcArgs a, hipStream_t stream) {
+  if (a.W < 1 || a.W > kMaxWidth) return PDT_E_TOO_LONG;
+  const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
+  // Long rows: one producer wave per frame is the bottleneck and LDS (not registers) bounds
+  // the occupancy, so three producers share the frames of an utterance (one utterance per
+  // workgroup); fall back to two, then one, when the ring does not fit.
+  if (a.V + 1 > 8 * PDT_WAVE) {
+    RingLayout rl = ring_layout(a.V, a.W, 4, 1, 3);
+    if ((size_t)rl.utt_bytes * 2 <= hard_cap) return launch_ctc_search_p<3>(a, rl, stream);
+    rl = ring_layout(a.V, a.W, 3, 1, 2);
+    if ((size_t)rl.utt_bytes <= hard_cap) return launch_ctc_search_p<2>(a, rl, stream);
+  }
+  // ring depth and utterances per workgroup from the LDS budget
+  int nstage = 4, upw = 2;
+  RingLayout rl = ring_layout(a.V, a.W, nstage, upw, 1);
+  while ((size_t)rl.utt_bytes * upw > soft_cap && (upw > 1 || nstage > 2)) {
+    if (upw > 1) upw = 1; else nstage = 2;
+    rl = ring_layout(a.V, a.W, nstage, upw, 1);
+  }
+  if ((size_t)rl.utt_bytes * upw > hard_cap) return PDT_E_TOO_LONG;
+  return launch_ctc_search_p<1>(a, rl, stream);
 }
 
 }  // namespace pdt

@@ -50,6 +50,21 @@ def test_ctc_prefix_search_random(device, V, K):
         _check_search(act, exp, (V, K, T, N))
 
 
+@pytest.mark.parametrize("V,K", [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4)])
+def test_ctc_prefix_search_long_rows(device, V, K):
+    """Vocabularies beyond 512: several producer waves share an utterance's frames (three for
+    V = 513..~3700, two beyond, one when even that ring does not fit); ragged lens shorter than
+    the number of producers included."""
+    rng = np.random.default_rng(7000 + V)
+    for it, (T, N) in enumerate([(2, 3), (25, 5), (61, 2)]):
+        lg = _peaky_logits(rng, T, N, V, scale=11.0)
+        lens = None if it == 1 else rng.integers(0, T + 1, N)
+        exp = oracle.ctc_prefix_search(lg, K, lens)
+        act = F.ctc_prefix_search(torch.from_numpy(lg).to(device), K,
+                                  None if lens is None else torch.from_numpy(lens).to(device))  # fmt: skip
+        _check_search(act, exp, (V, K, T, N))
+
+
 def test_ctc_prefix_search_golden_shape(device):
     """SURVEY G-D2 shape: T=30, N=8, V=12, K=4, peaky logits, ragged lens."""
     rng = np.random.default_rng(0x5EED0003)
