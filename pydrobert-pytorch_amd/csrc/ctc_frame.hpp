@@ -105,10 +105,11 @@ __device__ __forceinline__ int ctc_list_len(int V, int W, int Kp) {
 
 // Shared sorted token list of one frame from the unnormalised row p[0..V) (inv = 1 / normaliser):
 // tl_tok / tl_p (normalised) / pos (inverse index; entries of the previous list must be 0xFF).
+template <bool LONG = false>
 __device__ __forceinline__ void build_shared_list(const float *p, float inv, int V, int M, u64 *surv,
                                                   int *tl_tok, float *tl_p, unsigned char *pos) {
   const int lane = lane_id();
-  const u64 tk = wave_top_sorted(p, V, M, surv);
+  const u64 tk = wave_top_sorted<LONG>(p, V, M, surv);
   if (lane < M) {
     const int tok = (int)idx_of(tk);
     tl_tok[lane] = tok;

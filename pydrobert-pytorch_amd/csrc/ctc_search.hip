@@ -103,7 +103,9 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   __syncthreads();  // flags / pos tables initialised (the only workgroup barrier)
 
   if (producer) {
+    // elements of the NEXT row of this wave held in registers while the current one is processed
     constexpr int kPrefetch = 8;
+    constexpr int kBatch = 8;  // long rows: loads in flight beyond the prefetched part
     float pre[kPrefetch];
     if (pr < Tn) {
       const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn;
@@ -139,7 +141,20 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       }
       {
         const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
-        for (int v = lane + kPrefetch * PDT_WAVE; v <= V; v += PDT_WAVE) {
+        int v = lane + kPrefetch * PDT_WAVE;
+        if constexpr (P > 1) {  // long rows: kBatch loads in flight
+          for (; v + (kBatch - 1) * PDT_WAVE <= V; v += kBatch * PDT_WAVE) {
+            float x[kBatch];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) x[i] = row[(int64_t)(v + i * PDT_WAVE) * a.lg_sv];
+#pragma unroll
+            for (int i = 0; i < kBatch; ++i) {
+              p[v + i * PDT_WAVE] = x[i];
+              mx = fmaxf(mx, x[i]);
+            }
+          }
+        }
+        for (; v <= V; v += PDT_WAVE) {
           const float x = row[(int64_t)v * a.lg_sv];
           p[v] = x;
           mx = fmaxf(mx, x);
@@ -155,16 +170,32 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       }
       mx = wave_max_f(mx);
       float s = 0.0f;
-      for (int v = lane; v <= V; v += PDT_WAVE) {
-        const float e = exp_nonpos(p[v] - mx);
-        p[v] = e;
-        s += e;
+      {
+        int v = lane;
+        if constexpr (P > 1) {
+          for (; v + 7 * PDT_WAVE <= V; v += 8 * PDT_WAVE) {
+            float x[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[i] = p[v + i * PDT_WAVE];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+              const float e = exp_nonpos(x[i] - mx);
+              p[v + i * PDT_WAVE] = e;
+              s += e;
+            }
+          }
+        }
+        for (; v <= V; v += PDT_WAVE) {
+          const float e = exp_nonpos(p[v] - mx);
+          p[v] = e;
+          s += e;
+        }
       }
       s = wave_sum_f(s);
       wave_sync();
       const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
       const float inv = __fdiv_rn(1.0f, s);  // the only division of the frame
-      build_shared_list(p, inv, V, M, surv, tl_tok, slot_p(sl), pos);
+      build_shared_list<(P > 1)>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos);
       if (lane == 0) {
         hdr[0] = inv;
         hdr[2] = __int_as_float(M);

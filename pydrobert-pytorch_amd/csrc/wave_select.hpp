@@ -146,6 +146,10 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 //   3. <= 64 survivors: one bitonic sort.  Otherwise (heavy ties / clustered values) a
 //      chunked top-64 merge over the whole vector.
 #define PDT_SURV_CAP 64
+// LONG: rows of thousands of elements read by a wave that has its SIMD almost to itself --
+// eight loads are put in flight before any is used, so the passes run at LDS / L2 throughput
+// instead of one round trip per 64 elements (needs the registers of a low-occupancy kernel).
+template <bool LONG = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
                                                        int M, u64 *surv) {
   const int lane = lane_id();
@@ -154,20 +158,41 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
     const u64 k = lane < V ? pack_key(fkey(X(lane)), (unsigned)lane) : 0ull;
     return wave_sort_desc<u64>(k);
   }
+  constexpr int B = LONG ? 8 : 1;  // 64-element chunks per batch of loads
   unsigned lmax = 0u;
-  for (int v = lane; v < V; v += PDT_WAVE) lmax = max(lmax, fkey(X(v)));
+  {
+    int v = lane;
+    if constexpr (LONG) {
+      for (; v + (B - 1) * PDT_WAVE < V; v += B * PDT_WAVE) {
+        float x[B];
+#pragma unroll
+        for (int i = 0; i < B; ++i) x[i] = X(v + i * PDT_WAVE);
+#pragma unroll
+        for (int i = 0; i < B; ++i) lmax = max(lmax, fkey(x[i]));
+      }
+    }
+    for (; v < V; v += PDT_WAVE) lmax = max(lmax, fkey(X(v)));
+  }
   const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
   const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
   int count = 0;
-  for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
-    const int v = v0 + lane;
-    const unsigned key = v < V ? fkey(X(v)) : 0u;
-    const bool pred = v < V && key >= tau;
-    const u64 b = __ballot(pred);
-    if (b) {
-      const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
-      if (pred && pos < PDT_SURV_CAP) surv[pos] = pack_key(key, (unsigned)v);
-      count += __popcll(b);
+  for (int v0 = 0; v0 < V; v0 += B * PDT_WAVE) {
+    unsigned keys[B];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int v = v0 + i * PDT_WAVE + lane;
+      keys[i] = v < V ? fkey(X(v)) : 0u;  // 0 < tau: never a survivor
+    }
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+      const int v = v0 + i * PDT_WAVE + lane;
+      const bool pred = keys[i] >= tau;
+      const u64 b = __ballot(pred);
+      if (b) {
+        const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+        if (pred && pos < PDT_SURV_CAP) surv[pos] = pack_key(keys[i], (unsigned)v);
+        count += __popcll(b);
+      }
     }
   }
   wave_sync();
@@ -182,8 +207,9 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
   }
   return cur;
 }
+template <bool LONG = false>
 __device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv) {
-  return wave_top_sorted_strided(x, 1, V, M, surv);
+  return wave_top_sorted_strided<LONG>(x, 1, V, M, surv);
 }
 
 }  // namespace pdt
