@@ -263,3 +263,28 @@ def test_full_size_properties(device):
     got = oc[:, :4].cpu().numpy()
     C = exp.shape[2]
     assert np.array_equal(exp, got[:, :, :C]) and (got[:, :, C:] == -100).all()
+
+
+def test_optimal_completion_long_reference(device):
+    """R > 512: the row-synchronous kernel's BIG instantiation (more than 8 columns per lane),
+    and the documented size limit (R <= 2048) raising instead of computing garbage."""
+    rng = np.random.default_rng(13)
+    N, R, H, V = 3, 700, 90, 9
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    ref[650, 1] = V
+    hyp[40, 2] = V
+    for kw in (dict(eos=V), dict(eos=V, include_eos=False, exclude_last=True), dict()):
+        exp = oracle.optimal_completion(ref, hyp, faithful=False, **kw)
+        act = F.optimal_completion(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device),
+                                   warn=False, **kw).cpu().numpy()  # fmt: skip
+        assert exp.shape == act.shape and np.array_equal(exp, act), kw
+    # R = 2048 is the largest supported reference for the row-synchronous kernels
+    ref = torch.from_numpy(rng.integers(0, V, (2048, 2))).to(device)
+    hyp2 = torch.from_numpy(rng.integers(0, V, (5, 2))).to(device)
+    oc = F.optimal_completion(ref, hyp2, warn=False)
+    exp = oracle.optimal_completion(ref.cpu().numpy(), hyp2.cpu().numpy(), faithful=False)
+    assert np.array_equal(exp, oc.cpu().numpy())
+    too_long = torch.zeros((2049, 2), dtype=torch.long, device=device)
+    with pytest.raises(RuntimeError, match="too long|limit|supported"):
+        F.optimal_completion(too_long, hyp2, warn=False)
