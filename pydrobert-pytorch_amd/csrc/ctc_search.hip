@@ -237,7 +237,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     L.pos = slot_pos(sl);
     const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
-#ifndef PDT_SKIP_CONSUMER
+#ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
     ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
 #else
     ns = nt = nk = 0; (void)s;
