@@ -247,3 +247,23 @@ def test_opcheck_registrations():
         (img, flow, "hw", "bilinear", "border"),
         test_utils=tests,
     )
+
+
+def test_torch_compile_sees_opaque_operators():
+    """torch.compile (eager backend: graph capture + fake-tensor propagation, no code
+    generation) traces through the operators via their fake kernels and autograd formulas."""
+    T, N, V = 16, 5, 7
+    ref, hyp = _tokens(T, N, V, 30), _tokens(T, N, V, 31)
+    logits = torch.randn((T, N, V), device=DEV)
+
+    def fn(ref, hyp, logits):
+        er = F.error_rate(ref, hyp, eos=1, warn=False)
+        slp = F.sequence_log_probs(logits, hyp, 0, None)
+        return er, slp
+
+    compiled = torch.compile(fn, backend="eager", fullgraph=True)
+    _same(fn(ref, hyp, logits), compiled(ref, hyp, logits))
+    l1, l2 = logits.clone().requires_grad_(True), logits.clone().requires_grad_(True)
+    g1 = torch.autograd.grad(fn(ref, hyp, l1)[1].sum(), l1)
+    g2 = torch.autograd.grad(compiled(ref, hyp, l2)[1].sum(), l2)
+    _same(g1, g2)
