@@ -23,7 +23,10 @@ namespace pdt {
 
 constexpr int kMaxCPL = 8;
 
-template <int CPL, bool COUNT, bool FROM_LDS>
+// UNIT (cost mode with ins = del = sub = 1, what every uniform-cost call becomes after the host's
+// rescaling): D[h][c] = D[h-1][c-1] when the tokens match, else 1 + min of the three
+// neighbours -- four VALU per cell instead of six, same values (all small integers).
+template <int CPL, bool COUNT, bool FROM_LDS, bool UNIT = false>
 __device__ __forceinline__ void skew_sweep(const int *ref_l, const int *hyp_l, float *bnd_c,
                                            float *bnd_m, const int c_first, const int Heff,
                                            const float ins, const float del, const float sub) {
@@ -73,7 +76,11 @@ __device__ __forceinline__ void skew_sweep(const int *ref_l, const int *hyp_l, f
         const bool neq = rtok[j] != tok;  // _string.py:291
         const float up_c = pc[j], up_m = pm[j];
         float c_, m_ = 0.0f;
-        if (COUNT) {
+        if (UNIT) {
+          // columns < 1 are virtual (+inf, or D[h][0] = h in column 0): never a "match"
+          const float m3 = fminf(fminf(dc, up_c), left_c) + 1.0f;
+          c_ = (neq || cbase + j < 1) ? m3 : dc;
+        } else if (COUNT) {
           c_ = up_c + ins;  // :292
           m_ = up_m + 1.0f; // :299
           const float sc = dc + (neq ? sub : 0.0f);  // :293
@@ -111,7 +118,10 @@ template <int CPL, bool COUNT>
 __device__ __forceinline__ void skew_first(const int *ref_l, const int *hyp_l, float *bnd_c,
                                            float *bnd_m, int c_first, int Heff, float ins,
                                            float del, float sub) {
-  skew_sweep<CPL, COUNT, false>(ref_l, hyp_l, bnd_c, bnd_m, c_first, Heff, ins, del, sub);
+  if (!COUNT && ins == 1.0f && del == 1.0f && sub == 1.0f)
+    skew_sweep<CPL, false, false, true>(ref_l, hyp_l, bnd_c, bnd_m, c_first, Heff, ins, del, sub);
+  else
+    skew_sweep<CPL, COUNT, false>(ref_l, hyp_l, bnd_c, bnd_m, c_first, Heff, ins, del, sub);
 }
 
 template <bool COUNT>
