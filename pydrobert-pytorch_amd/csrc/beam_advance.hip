@@ -87,6 +87,8 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
     a.next_nonext[n * W + lane] = (uint8_t)(new_kind == 2);
     for (int b = 0; b < W; ++b) a.next_isp[(n * W + lane) * W + b] = (uint8_t)((bm.isp >> b) & 1u);
     srcs[lane] = valid ? new_src : -1;
+    L.info[lane] = bm.len;        // the frame's scratch is free again: per-entry length and
+    L.info[W + lane] = new_kind;  // kind for the copy loop (its tail runs with part of the wave)
     // the new token sits right after the source prefix (:862-864)
     if (valid && new_kind != 2) a.y_next[((int64_t)(bm.len - 1) * a.N + n) * W + lane] = new_tok;
   }
@@ -95,8 +97,8 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   for (int idx = lane; idx < (S + 1) * W; idx += PDT_WAVE) {
     const int s = idx / W, i = idx - s * W;
     const int src = srcs[i];
-    const int len_i = __shfl(bm.len, i);
-    const bool ext_i = __shfl(new_kind, i) == 0 || __shfl(new_kind, i) == 1;
+    const int len_i = L.info[i], kind_i = L.info[W + i];
+    const bool ext_i = kind_i == 0 || kind_i == 1;
     const int plen = len_i - (ext_i ? 1 : 0);
     if (src < 0)
       a.y_next[((int64_t)s * a.N + n) * W + i] = 0;
@@ -152,6 +154,7 @@ __global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) 
   int *tl = reinterpret_cast<int *>(surv + PDT_SURV_CAP);
   int *srcs = tl + Kp * PDT_WAVE;
   int *toks = srcs + W;
+  int *plens = toks + W;
 
   // per-prefix sorted lists of the best tokens
   for (int k = 0; k < Kp; ++k) {
@@ -193,12 +196,13 @@ __global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) 
     a.y_next_lens[n * W + lane] = valid ? plen + 1 : 0;
     srcs[lane] = valid ? new_src : -1;
     toks[lane] = new_tok;
+    plens[lane] = plen;
   }
   wave_sync();
   for (int idx = lane; idx < a.S_out * W; idx += PDT_WAVE) {
     const int s = idx / W, i = idx - s * W;
     const int src = srcs[i];
-    const int pl = __shfl(plen, i);
+    const int pl = plens[i];  // (not a shuffle: the tail iteration runs with part of the wave)
     int64_t v;
     if (src < 0)
       v = 0;
@@ -212,7 +216,7 @@ __global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) 
 
 int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.W > PDT_WAVE || a.Kp < 1 || a.Kp > PDT_WAVE) return PDT_E_TOO_LONG;
-  size_t per_wave = (size_t)PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 4 + (size_t)a.W * 8;
+  size_t per_wave = (size_t)PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 4 + (size_t)a.W * 12;
   per_wave = (per_wave + 15) & ~(size_t)15;
   int wpw = (int)((64 * 1024) / per_wave);
   wpw = wpw > 4 ? 4 : (wpw < 1 ? 1 : wpw);

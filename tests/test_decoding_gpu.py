@@ -163,12 +163,15 @@ def _cmp_ctc_step(act, exp, what):
             assert np.array_equal(y[: elens[n, k], n, k], ey[: elens[n, k], n, k]), (what, n, k)
 
 
-@pytest.mark.parametrize("V,W", [(3, 2), (4, 5), (9, 4), (30, 8), (100, 16), (300, 32)])
+@pytest.mark.parametrize(
+    "V,W", [(3, 2), (4, 5), (9, 4), (30, 8), (100, 16), (300, 32), (12, 7), (40, 13), (60, 27), (33, 31)]
+)
 def test_ctc_prefix_search_advance_teacher_forced(device, V, W):
     """Run the oracle's search with per-prefix (LM-like) extension probabilities and, at every
-    frame, feed the oracle's state to the kernel and compare all seven outputs."""
+    frame, feed the oracle's state to the kernel and compare all seven outputs.  Widths that do
+    not divide 64 over 20+ frames make the history copy end on every possible partial wave."""
     rng = np.random.default_rng(V * 100 + W)
-    N, T = 3, 12
+    N, T = 3, 12 if W in (2, 4, 8, 16, 32) else 22
     nb, b = np.zeros((N, 1), np.float32), np.ones((N, 1), np.float32)
     y = np.zeros((0, N, 1), np.int64)
     last = lens = np.zeros((N, 1), np.int64)
@@ -229,6 +232,28 @@ def test_beam_search_advance_random(device, with_lens):
         assert np.array_equal(act[1], exp[1]) and np.array_equal(act[3], exp[3]), it
         assert np.array_equal(act[2], exp[2]), it  # float adds are the same single operation
         assert np.array_equal(act[0][..., :K], exp[0][..., :K]), it
+
+
+def test_beam_search_advance_without_growth(device):
+    """All paths shorter than the history (y keeps its S rows, reference :133-137) with widths
+    that leave a partial wave in the copy loop: the appended token must land at row lens."""
+    rng = np.random.default_rng(41)
+    for it in range(60):
+        N, Kp, V = int(rng.integers(1, 4)), int(rng.integers(1, 12)), int(rng.integers(20, 70))
+        W, S = int(rng.integers(9, 40)), int(rng.integers(2, 10))
+        lpt = np.log(rng.dirichlet(np.ones(V), (N, Kp))).astype(np.float32)
+        lpp = rng.normal(size=(N, Kp)).astype(np.float32)
+        yp = rng.integers(0, V, (S, N, Kp))
+        ypl = rng.integers(0, S, (N, Kp))  # strictly shorter than S
+        exp = oracle.beam_search_advance(lpt, W, lpp, yp, ypl)
+        tt = lambda a: torch.from_numpy(a).to(device)  # noqa: E731
+        act = [x.cpu().numpy() for x in F.beam_search_advance(tt(lpt), W, tt(lpp), tt(yp), tt(ypl))]
+        K = min(W, Kp * V)
+        assert act[0].shape == exp[0].shape == (S, N, W), (it, act[0].shape, exp[0].shape)
+        assert np.array_equal(act[1], exp[1]) and np.array_equal(act[3], exp[3]), it
+        valid = np.arange(S)[:, None, None] < exp[1][None]
+        valid[..., K:] = False
+        assert np.array_equal(np.where(valid, act[0], 0), np.where(valid, exp[0], 0)), it
 
 
 def test_beam_search_advance_errors(device):
