@@ -1,0 +1,99 @@
+"""Randomised differential run of the HIP path against the oracle (not a test: a bug hunt)."""
+import sys, time
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "pydrobert-pytorch_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import numpy as np, torch, warnings
+import oracle
+from pydrobert_amd import functional as F
+warnings.simplefilter("ignore")
+dev = "cuda"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
+t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() + 60
+bad = 0
+ONLY_CTC = len(sys.argv) > 3
+n_cases = 0
+def T(a): return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+while time.time() < t_end:
+    n_cases += 1
+    kind = 1 if ONLY_CTC else rng.integers(0, 4)
+    if kind == 0:  # string ops
+        N, R, H, V = int(rng.integers(1, 9)), int(rng.integers(0, 140)), int(rng.integers(0, 140)), int(rng.integers(1, 12))
+        if rng.random() < 0.1: R = int(rng.integers(500, 700))
+        ref, hyp = rng.integers(0, V, (R, N)), rng.integers(0, V, (H, N))
+        eos = None if rng.random() < 0.3 else int(rng.integers(0, V))
+        costs = [(1., 1., 1.), (2., 2., 2.), (3., 3., 4.), (2., .5, 1.), (1., 2., 1.5)][rng.integers(0, 5)]
+        name = ["error_rate", "edit_distance", "prefix_error_rates", "prefix_edit_distances", "optimal_completion"][rng.integers(0, 5)]
+        kw = dict(eos=eos, include_eos=bool(rng.integers(0, 2)), ins_cost=costs[0], del_cost=costs[1], sub_cost=costs[2])
+        if name.startswith("prefix") or name == "optimal_completion":
+            kw["exclude_last"] = bool(rng.integers(0, 2))
+        if name != "optimal_completion":
+            kw["norm"] = bool(rng.integers(0, 2))
+        bf = bool(rng.integers(0, 2))
+        if (H == 0 and kw.get("exclude_last")):
+            continue
+        try:
+            exp = getattr(oracle, name)(ref, hyp, **kw)
+        except Exception as e:
+            continue
+        r_, h_ = (T(ref.T), T(hyp.T)) if bf else (T(ref), T(hyp))
+        act = getattr(F, name)(r_, h_, batch_first=bf, warn=False, **kw).cpu().numpy()
+        if bf and act.ndim >= 2:
+            act = np.swapaxes(act, 0, 1)
+        ok = exp.shape == act.shape and np.array_equal(exp, act, equal_nan=True)
+        if not ok:
+            bad += 1; print("MISMATCH", name, N, R, H, V, kw, bf, exp.shape, act.shape)
+    elif kind == 1:  # ctc search
+        V = int(rng.integers(1, 80)); K = int(rng.integers(1, min(V + 1, 32) + 1))
+        Tn, N = int(rng.integers(0, 70)), int(rng.integers(1, 7))
+        lg = rng.normal(size=(Tn, N, V + 1)).astype(np.float32)
+        if Tn:
+            pk = rng.integers(0, V + 1, (Tn, N))
+            np.put_along_axis(lg, pk[..., None], np.take_along_axis(lg, pk[..., None], 2) + rng.uniform(2, 9), 2)
+        lens = None if rng.random() < 0.5 else rng.integers(0, Tn + 1, N)
+        ey, eyl, eyp = oracle.ctc_prefix_search(lg, K, lens)
+        y, yl, yp = (x.cpu().numpy() for x in F.ctc_prefix_search(T(lg), K, None if lens is None else T(lens)))
+        fin = np.isfinite(eyp) & (eyp > 1e-30)
+        ok = y.shape == ey.shape and np.array_equal(yl[fin], eyl[fin]) and np.allclose(yp[fin], eyp[fin], rtol=2e-5)
+        if ok:
+            m = (np.arange(y.shape[0])[:, None, None] < yl[None]) & fin[None]
+            ok = np.array_equal(np.where(m, y, 0), np.where(m, ey, 0))
+        if not ok:
+            bad += 1; print("MISMATCH ctc", V, K, Tn, N, lens)
+            lens_ok = np.array_equal(yl[fin], eyl[fin])
+            rel = np.abs(yp[fin] - eyp[fin]) / np.abs(eyp[fin])
+            print("   lens_ok", lens_ok, "max rel", rel.max() if rel.size else None, "min eyp", eyp[fin].min() if fin.any() else None)
+            import os
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez("gpurun_out/fuzz_ctc_%d.npz" % bad, lg=lg, K=K, lens=np.array([-1]) if lens is None else lens, y=y, yl=yl, yp=yp)
+    elif kind == 2:  # pad_variable
+        N, Tn = int(rng.integers(1, 9)), int(rng.integers(1, 40))
+        shape = (N, Tn) + tuple(int(x) for x in rng.integers(1, 5, rng.integers(0, 3)))
+        x = rng.normal(size=shape).astype(np.float32)
+        lens = rng.integers(1, Tn + 1, N)
+        mode = ["constant", "reflect", "replicate"][rng.integers(0, 3)]
+        hi = np.maximum(lens - 1, 0) if mode == "reflect" else np.full(N, 9)
+        pad = np.stack([rng.integers(0, hi + 1), rng.integers(0, hi + 1)])
+        exp = oracle.pad_variable(x, lens, pad, mode, 1.5)
+        act = F.pad_variable(T(x), T(lens), T(pad), mode, 1.5).cpu().numpy()
+        if not np.array_equal(exp, act):
+            bad += 1; print("MISMATCH pad", shape, mode)
+    else:  # greedy ctc + sequence log probs
+        Tn, N, V = int(rng.integers(1, 50)), int(rng.integers(1, 7)), int(rng.integers(2, 40))
+        lg = rng.normal(size=(Tn, N, V)).astype(np.float32)
+        lens = rng.integers(0, Tn + 1, N)
+        blank = int(rng.integers(-V, V))
+        em, ep, el = oracle.ctc_greedy_search(lg, lens, blank)
+        am, ap, al = (x.cpu().numpy() for x in F.ctc_greedy_search(T(lg), T(lens), blank))
+        ok = np.array_equal(el, al) and np.allclose(em, am, rtol=1e-5, atol=1e-6)
+        if ok:
+            m = np.arange(Tn)[:, None] < al[None]
+            ok = np.array_equal(np.where(m, ep, 0), np.where(m, ap, 0))
+        hyp = rng.integers(-1, V, (Tn, N))
+        es = oracle.sequence_log_probs(lg, hyp, 0, None)
+        as_ = F.sequence_log_probs(T(lg), T(hyp), 0, None).cpu().numpy()
+        ok = ok and np.allclose(es, as_, rtol=1e-5, atol=1e-5)
+        if not ok:
+            bad += 1; print("MISMATCH seqops", Tn, N, V, blank)
+print("cases", n_cases, "mismatches", bad)
