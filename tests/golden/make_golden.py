@@ -408,3 +408,59 @@ def pad_goldens():
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "pad"):
     F_ = F
     pad_goldens()
+
+
+def search_sweep_goldens():
+    """Many small searches with a language model in the loop (CTCPrefixSearch with shallow
+    fusion / valid mixture, BeamSearch with every option) from the live reference: pins the
+    host-side frame loops, which the oracle does not restate."""
+    rng = np.random.default_rng(0x5EED0008)
+    d = {}
+    n_ctc = n_beam = 0
+    while n_ctc < 24:
+        V, K = int(rng.integers(2, 15)), int(rng.integers(1, 9))
+        if K > V + 1:
+            continue
+        T, N = int(rng.integers(1, 25)), int(rng.integers(1, 5))
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        peak = rng.integers(0, V + 1, (T, N))
+        np.put_along_axis(lg, peak[..., None], np.take_along_axis(lg, peak[..., None], 2) + 4.0, 2)
+        lens = None if rng.random() < 0.3 else rng.integers(0, T + 1, N)
+        table = torch.from_numpy((rng.normal(size=(V + 1, V)) * 1.5).astype(np.float32)).log_softmax(-1)
+        beta = float(rng.uniform(0.05, 0.9))
+        vm = bool(rng.integers(0, 2))
+        y, yl, yp = M.CTCPrefixSearch(K, beta, BigramLM(table), valid_mixture=vm)(
+            torch.from_numpy(lg), None if lens is None else torch.from_numpy(lens)
+        )
+        srt = yp.sort(1, descending=True).values
+        if not torch.isfinite(yp).all() or (K > 1 and ((srt[:, :-1] - srt[:, 1:]) < 1e-6 * srt[:, :-1]).any()):
+            continue  # padded beams / near ties: outcome unspecified
+        mask = torch.arange(y.shape[0]).view(-1, 1, 1) < yl.unsqueeze(0)
+        tag = "ctc%d_" % n_ctc
+        d[tag + "logits"], d[tag + "table"] = lg, table
+        d[tag + "lens"] = np.array([-1]) if lens is None else lens
+        d[tag + "cfg"] = np.array([K, beta, float(vm)])
+        d[tag + "y"], d[tag + "y_lens"], d[tag + "y_probs"] = torch.where(mask, y, torch.zeros_like(y)), yl, yp
+        n_ctc += 1
+    while n_beam < 24:
+        V, K = int(rng.integers(2, 12)), int(rng.integers(1, 8))
+        table = torch.from_numpy((rng.normal(size=(V + 1, V)) * 2).astype(np.float32)).log_softmax(-1)
+        eos = None if rng.random() < 0.3 else int(rng.integers(-V, V))
+        fin = bool(rng.integers(0, 2))
+        N = None if rng.random() < 0.2 else int(rng.integers(1, 5))
+        iters = int(rng.integers(0, 12))
+        y, yl, lp = M.BeamSearch(BigramLM(table), K, eos, fin, -7)(dict(), N, iters)
+        fl = lp.reshape(-1, K)
+        srt = fl.sort(1, descending=True).values
+        if K > 1 and torch.isfinite(srt).all() and (srt[:, :-1] - srt[:, 1:]).min() < 1e-6:
+            continue
+        tag = "beam%d_" % n_beam
+        d[tag + "table"] = table
+        d[tag + "cfg"] = np.array([K, -1000 if eos is None else eos, int(fin), -1 if N is None else N, iters])
+        d[tag + "y"], d[tag + "y_lens"], d[tag + "lp"] = y, yl, lp
+        n_beam += 1
+    save("search_sweep", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "sweep"):
+    search_sweep_goldens()

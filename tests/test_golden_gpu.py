@@ -161,3 +161,39 @@ def test_tensorflow_addons_arrays(device):
             T(ld("sparse_img"), device), T(ld("sparse_src"), device), T(ld("sparse_dst"), device))  # fmt: skip
         assert np.allclose(w.cpu().numpy(), ld("sparse_warped_{}".format(pinned)), atol=1e-3)
         assert np.allclose(f.cpu().numpy(), ld("sparse_flow_{}".format(pinned)), atol=1e-3)
+
+
+def test_search_sweep_with_language_model(device):
+    """48 small searches with a bigram LM in the loop, outputs captured from the live reference
+    (tests/golden/search_sweep.npz): CTCPrefixSearch with shallow fusion / valid mixture over
+    random widths, betas and ragged lens; BeamSearch over eos / finish_all_paths / batch_size /
+    max_iters.  Pins the host-side frame loops around the step kernels."""
+    from _toy_lm import BigramLM
+
+    g = np.load(os.path.join(G, "search_sweep.npz"))
+    for i in range(24):
+        tag = "ctc%d_" % i
+        K, beta, vm = g[tag + "cfg"]
+        lens = g[tag + "lens"]
+        lm = BigramLM(torch.from_numpy(g[tag + "table"]).to(device))
+        mod = M.CTCPrefixSearch(int(K), float(beta), lm, valid_mixture=bool(vm))
+        y, yl, yp = mod(
+            torch.from_numpy(g[tag + "logits"]).to(device),
+            None if lens[0] == -1 else torch.from_numpy(lens).to(device),
+        )
+        assert torch.equal(yl.cpu(), torch.from_numpy(g[tag + "y_lens"])), tag
+        assert np.allclose(g[tag + "y_probs"], yp.cpu().numpy(), rtol=2e-5, atol=1e-30), tag
+        mask = torch.arange(y.shape[0], device=device).view(-1, 1, 1) < yl.unsqueeze(0)
+        assert torch.equal(torch.where(mask, y, torch.zeros_like(y)).cpu(), torch.from_numpy(g[tag + "y"])), tag
+    for i in range(24):
+        tag = "beam%d_" % i
+        K, eos, fin, N, iters = (int(x) for x in g[tag + "cfg"])
+        lm = BigramLM(torch.from_numpy(g[tag + "table"]).to(device))
+        mod = M.BeamSearch(lm, K, None if eos == -1000 else eos, bool(fin), -7).to(device)
+        y, yl, lp = mod(dict(), None if N == -1 else N, iters)
+        ey, eyl, elp = (torch.from_numpy(g[tag + k]) for k in ("y", "y_lens", "lp"))
+        assert y.shape == ey.shape and torch.equal(yl.cpu(), eyl), (tag, y.shape, ey.shape)
+        assert np.allclose(elp.numpy(), lp.cpu().numpy(), rtol=1e-5, atol=1e-6, equal_nan=True), tag
+        S = y.shape[0]
+        mask = torch.arange(S).view([S] + [1] * (y.dim() - 1)) < eyl.unsqueeze(0)
+        assert torch.equal(torch.where(mask, y.cpu(), ey), ey), tag
