@@ -22,6 +22,32 @@ lg.scatter_add_(2, torch.randint(0, V + 1, (T, N, 1), device=dev, generator=g), 
 ms = timeit(lambda: F.ctc_prefix_search(lg, K), reps=3, warm=1)
 res["C3 ctc_prefix_search N=1024 T=1000 V=1000 K=16"] = dict(ms=ms, utt_per_s=N / ms * 1e3, GBs=lg.numel() * 4 / ms / 1e6)
 del lg
+# C3, the bare step functions at S=100 (the state comes from 100 real frames of the search itself)
+N, V, K, S = 1024, 1000, 16, 100
+g = torch.Generator(device=dev).manual_seed(4)
+nb, b = torch.zeros((N, 1), device=dev), torch.ones((N, 1), device=dev)
+y = torch.zeros((0, N, 1), dtype=torch.long, device=dev)
+last = lens = torch.zeros((N, 1), dtype=torch.long, device=dev)
+isp = torch.ones((N, 1, 1), dtype=torch.bool, device=dev)
+for t in range(S + 1):
+    lgt = torch.randn((N, V + 1), device=dev, generator=g)
+    lgt.scatter_add_(1, torch.randint(0, V + 1, (N, 1), device=dev, generator=g), torch.full((N, 1), 12.0, device=dev))
+    p = lgt.softmax(1)
+    nonext, blank = p[:, :V].contiguous(), p[:, V].contiguous()
+    ext = nonext.unsqueeze(1).expand(N, nb.shape[1], V)
+    args = ((ext, nonext, blank), K, (nb, b), y, last, lens, isp)
+    if t == S:
+        break
+    y, last, lens, (nb, b), isp, _, _ = F.ctc_prefix_search_advance(*args)
+ms = timeit(lambda: F.ctc_prefix_search_advance(*args))
+res["C3 bare ctc_prefix_search_advance N=1024 K=16 V=1000 S=100"] = dict(ms=ms, steps_per_s=1e3 / ms)
+lpt = torch.randn((N, K, V), device=dev, generator=g).log_softmax(-1)
+lpp = torch.randn((N, K), device=dev, generator=g)
+yb = torch.randint(0, V, (S, N, K), device=dev, generator=g)
+ybl = torch.full((N, K), S, device=dev)
+ms = timeit(lambda: F.beam_search_advance(lpt, K, lpp, yb, ybl))
+res["C3-like bare beam_search_advance N=1024 K=16 V=1000 S=100"] = dict(ms=ms, steps_per_s=1e3 / ms)
+del lpt, yb
 # C4: SpecAugment N=2048 x 1000 x 80
 N, T, Fq = 2048, 1000, 80
 feats = torch.randn((N, T, Fq), device=dev)
