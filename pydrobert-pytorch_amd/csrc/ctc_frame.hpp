@@ -109,7 +109,7 @@ template <bool LONG = false>
 __device__ __forceinline__ void build_shared_list(const float *p, float inv, int V, int M, u64 *surv,
                                                   int *tl_tok, float *tl_p, unsigned char *pos) {
   const int lane = lane_id();
-  const u64 tk = wave_top_sorted<LONG>(p, V, M, surv);
+  const u64 tk = wave_top_sorted<LONG, true>(p, V, M, surv);  // p = exp(...) >= 0
   if (lane < M) {
     const int tok = (int)idx_of(tk);
     tl_tok[lane] = tok;
@@ -228,6 +228,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   NB = NB + add;
   PDT_STAMP(2);
 
+  // (candidate masses are probabilities >= +0: one-instruction keys, see fkey_nonneg)
   // ---- K-way merge of the per-prefix candidate streams ----------------------------------
   // stream 0: available list entries in order, mass (nb + b) * ext[v]
   // stream 1: my last token, mass b * ext[last]                (:784-789)
@@ -265,7 +266,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
         if (e < n_main && av != 0u && kvalid) {
           const int j = __builtin_ctz(av);
           tok = lt[j];
-          key = fkey(tot_k * lp[j]);
+          key = fkey_nonneg(tot_k * lp[j]);
         }
         if (mine && e < n_main) {
           if (sl == 0) { key0 = key; tk0 = tok; }
@@ -286,7 +287,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       if (e < n_main && av != 0ull && kvalid) {
         const int j = (int)__builtin_ctzll(av);
         tok = lt[j];
-        key = fkey(tot_k * lp[j]);
+        key = fkey_nonneg(tot_k * lp[j]);
       }
       if (mine && e < n_main) {
         if (sl == 0) { key0 = key; tk0 = tok; }
@@ -301,8 +302,8 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     // stream 1 / stream 2 live in slot 2 of rows R-2 / R-1
     const float m1_k = shfl_f(m1, ksrc), m2_k = shfl_f(m2, ksrc);
     const bool o1 = __shfl((int)s1_open, ksrc) != 0, o2 = __shfl((int)s2_open, ksrc) != 0;
-    if (rr == R - 2) { key2 = (kvalid && o1) ? fkey(m1_k) : 0u; tk2 = lastc_k; }
-    if (rr == R - 1) { key2 = (kvalid && o2) ? fkey(m2_k) : 0u; tk2 = lastc_k; }
+    if (rr == R - 2) { key2 = (kvalid && o1) ? fkey_nonneg(m1_k) : 0u; tk2 = lastc_k; }
+    if (rr == R - 1) { key2 = (kvalid && o2) ? fkey_nonneg(m2_k) : 0u; tk2 = lastc_k; }
   }
 
   new_src = 0, new_tok = 0, new_kind = -1;
@@ -359,7 +360,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
           new_src = wl & (G - 1);
           new_tok = sw == 0 ? t0 : (sw == 1 ? t1 : t2);
           new_kind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
-          new_mass = fkey_inv(wkey);
+          new_mass = fkey_nonneg_inv(wkey);
         }
         selected = true;
       }
@@ -382,7 +383,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     new_src = rec ? wbeam : new_src;
     new_tok = rec ? wtok : new_tok;
     new_kind = rec ? wkind : new_kind;
-    new_mass = rec ? fkey_inv(mx) : new_mass;
+    new_mass = rec ? fkey_nonneg_inv(mx) : new_mass;
     const bool me_win = lane == win;
     key0 = (me_win & (sw == 0)) ? 0u : key0;
     key1 = (me_win & (sw == 1)) ? 0u : key1;

@@ -17,6 +17,10 @@ __device__ __forceinline__ unsigned fkey(float f) {
 __device__ __forceinline__ float fkey_inv(unsigned k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
+// the same for values known to be >= +0 (probabilities): the IEEE bit pattern is already
+// monotone there; +1 keeps 0 free as "no candidate".  One instruction instead of three.
+__device__ __forceinline__ unsigned fkey_nonneg(float f) { return __float_as_uint(f) + 1u; }
+__device__ __forceinline__ float fkey_nonneg_inv(unsigned k) { return __uint_as_float(k - 1u); }
 // (value key, index) -> one u64 whose max is "largest value, then lowest index"
 __device__ __forceinline__ u64 pack_key(unsigned key, unsigned idx) {
   return ((u64)key << 32) | (u64)(0xffffffffu - idx);
@@ -149,11 +153,14 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // LONG: rows of thousands of elements read by a wave that has its SIMD almost to itself --
 // eight loads are put in flight before any is used, so the passes run at LDS / L2 throughput
 // instead of one round trip per 64 elements (needs the registers of a low-occupancy kernel).
-template <bool LONG = false>
+// NONNEG: every x[v] >= +0 (the keys inside the result are then fkey_nonneg keys; callers that
+// only read the indices do not care).
+template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
                                                        int M, u64 *surv) {
   const int lane = lane_id();
   auto X = [&](int v) { return xb[(int64_t)v * sx]; };
+  auto fkey = [](float f) { return NONNEG ? fkey_nonneg(f) : pdt::fkey(f); };
   if (V <= PDT_WAVE) {
     const u64 k = lane < V ? pack_key(fkey(X(lane)), (unsigned)lane) : 0ull;
     return wave_sort_desc<u64>(k);
@@ -207,9 +214,9 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
   }
   return cur;
 }
-template <bool LONG = false>
+template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv) {
-  return wave_top_sorted_strided<LONG>(x, 1, V, M, surv);
+  return wave_top_sorted_strided<LONG, NONNEG>(x, 1, V, M, surv);
 }
 
 }  // namespace pdt
