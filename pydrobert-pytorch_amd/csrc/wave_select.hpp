@@ -1,6 +1,6 @@
 // Wave-level (64-lane) ordering primitives used by the beam-search kernels:
 // order-preserving float keys, bitonic sort of one key per lane, top-64 merge, and
-// "sorted top-M of a V-vector" selection.  No LDS traffic except the small survivor list.
+// "sorted top-M of a V-vector" selection.  No LDS memory traffic except the small survivor list.
 #pragma once
 #include "pdt_common.hpp"
 
@@ -34,29 +34,23 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 
-// value of lane (lane ^ J), J a power of two, WITHOUT touching the LDS crossbar:
-// DPP quad_perm (J = 1, 2), two bank-masked row shifts (J = 4), row_ror:8 (J = 8), and the
-// gfx950 v_permlane16_swap / v_permlane32_swap for J = 16 / 32.
+// value of lane (lane ^ J), J a power of two.  One DPP move where one exists (quad_perm for
+// J = 1, 2; row_ror:8 for J = 8).  J = 4 would take two bank-masked row shifts and J = 16 / 32
+// a v_permlane*_swap plus a select: the kernels that sort are VALU-issue-bound while their LDS
+// pipe is nearly idle, so those three go through the LDS crossbar (ds_bpermute: no LDS memory
+// is touched) -- measured 3.88 -> 3.80 ms on the CTC search; routing EVERY stage through the
+// crossbar instead lengthens the dependency chain too much (4.23 ms).
 template <int J>
 __device__ __forceinline__ unsigned xor_shfl(unsigned v) {
   if constexpr (J == 1) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
   } else if constexpr (J == 2) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
-  } else if constexpr (J == 4) {
-    const int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);  // row_shl:4
-    return (unsigned)__builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xa, false);    // row_shr:4
   } else if constexpr (J == 8) {
     return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
-  } else if constexpr (J == 16) {
-    const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    // r[0] = rows (0,0,2,2), r[1] = rows (1,1,3,3) of v
-    return __builtin_amdgcn_inverse_ballot_w64(0x0000FFFF0000FFFFull) ? r[1] : r[0];
   } else {
-    static_assert(J == 32, "xor_shfl: J must be a power of two <= 32");
-    const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    // r[0] = (low half, low half), r[1] = (high half, high half) of v
-    return __builtin_amdgcn_inverse_ballot_w64(0x00000000FFFFFFFFull) ? r[1] : r[0];
+    static_assert(J == 4 || J == 16 || J == 32, "xor_shfl: J must be a power of two <= 32");
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ J) << 2), (int)v);
   }
 }
 template <int J>
@@ -88,7 +82,7 @@ __device__ __forceinline__ T bitonic_merge(T key) {
 }
 
 // bitonic sort of one key per lane, DESCENDING (lane 0 ends with the maximum); 21
-// compare-exchange stages of ~6 (u64) / ~4 (u32) VALU instructions, no LDS
+// compare-exchange stages of ~5 (u64) / ~3 (u32) VALU instructions
 template <typename T>
 __device__ __forceinline__ T wave_sort_desc(T key) {
   key = bitonic_merge<2, 1>(key);
