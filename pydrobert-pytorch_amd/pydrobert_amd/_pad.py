@@ -4,7 +4,7 @@ the reference's masks + masked_scatter chain."""
 import torch
 from torch.library import custom_op, register_autograd
 
-from . import _cabi, argcheck, config
+from . import _cabi, argcheck
 
 __all__ = ["PadVariable", "pad_variable"]
 
