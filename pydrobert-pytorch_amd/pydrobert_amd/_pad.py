@@ -4,12 +4,11 @@ the reference's masks + masked_scatter chain."""
 import torch
 from torch.library import custom_op, register_autograd
 
-from . import _cabi, argcheck
+from . import _cabi, argcheck, config
 
 __all__ = ["PadVariable", "pad_variable"]
 
 _PAD_MODES = {"constant": 0, "reflect": 1, "replicate": 2}
-DEFT_PAD_VALUE = 0.0  # reference config.DEFT_PAD_VALUE
 
 
 @custom_op("pydrobert_amd::pad_variable", mutates_args=())
@@ -117,7 +116,7 @@ def pad_variable(
     lens: torch.Tensor,
     pad: torch.Tensor,
     mode: str = "constant",
-    value: float = DEFT_PAD_VALUE,
+    value: float = config.DEFT_PAD_VALUE,
 ) -> torch.Tensor:
     """Functional version of :class:`PadVariable` (reference _pad.py:108-149)."""
     return torch.ops.pydrobert_amd.pad_variable(x, lens, pad, mode, value)
@@ -128,7 +127,7 @@ class PadVariable(torch.nn.Module):
 
     __constants__ = ("mode", "value")
 
-    def __init__(self, mode: str = "constant", value: float = DEFT_PAD_VALUE):
+    def __init__(self, mode: str = "constant", value: float = config.DEFT_PAD_VALUE):
         mode = argcheck.is_in(mode, tuple(_PAD_MODES), "mode")
         value = argcheck.is_float(value, "value")
         super().__init__()
