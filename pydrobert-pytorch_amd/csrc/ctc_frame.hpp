@@ -235,6 +235,62 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // stream 2: not extending, mass NB + B                        (:842-845)
   const float m1 = bm.b * e_last;
   const float m2 = NB + B;
+  new_src = 0, new_tok = 0, new_kind = -1;
+  float new_mass = -PDT_INF;
+  bool selected = false;
+  {  // scope of the lean tier's per-lane layout values
+  // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
+  // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
+  // available list entries of stream 0 in order, entry 3R-2 is stream 1, entry 3R-1 stream 2.
+  // A prefix's resident entries are consumed in order (they are sorted), so a round is just
+  // a wave max + clearing the winning slot; only when a prefix uses up ALL its resident
+  // stream-0 entries are its slots refilled with the next 3R-2.
+  const int G = Kp <= 16 ? 16 : 32;
+  const int kb = lane & (G - 1), rr = lane / G;
+  const int ksrc = kb < Kp ? kb : 0;
+  const bool kvalid = kb < Kp && (__shfl((int)valid_beam, ksrc) != 0);
+  const float tot_k = shfl_f(tot, ksrc);
+  const int lastc_k = __shfl(lastc, ksrc);
+
+  // Lean tier (K' <= 16, K + K' <= 32): in 94 % of the frames of the bench input every winner
+  // is a prefix's BEST available token, its last-token stream or its non-extension, so the four
+  // rows hold just those -- main entries 0 and 1, stream 1, stream 2: one candidate per lane --
+  // and ONE 64-key sort ranks them all.  If a winner is a main entry 1, the prefix's entry 2
+  // (not resident here) could matter: the full tiers below decide the frame instead (5.6 %).
+  if (G == 16 && M <= 32) {
+    // this row's candidate of prefix kb: rows 0 / 1 read the list, rows 2 / 3 a stream mass
+    const unsigned avk = (unsigned)__shfl((int)(unsigned)avail, ksrc);
+    const unsigned av = rr == 1 ? (avk & (avk - 1u)) : avk;
+    // (a shuffle moves the SOURCE lane's operand: fetch both streams, then pick by row)
+    const float ms1 = shfl_f(m1, ksrc), ms2 = shfl_f(m2, ksrc);
+    const int open12 = __shfl((int)s1_open | ((int)s2_open << 1), ksrc);
+    const float ms = rr == 2 ? ms1 : ms2;
+    const bool os = ((open12 >> (rr == 2 ? 0 : 1)) & 1) != 0;
+    const int j = av ? __builtin_ctz(av) : 0;
+    const int tokj = L.tl_tok[(DENSE ? ksrc : 0) * PDT_WAVE + j];
+    const float pj = L.tl_p[(DENSE ? ksrc : 0) * PDT_WAVE + j];
+    const bool has = kvalid && (rr < 2 ? av != 0u : os);
+    const unsigned keyL = has ? fkey_nonneg(rr < 2 ? tot_k * pj : ms) : 0u;
+    const int tokL = rr < 2 ? tokj : lastc_k;
+    const u64 s = wave_sort_desc<u64>(pack_key(keyL, (unsigned)lane));
+    const unsigned wkey = key_of(s);
+    const bool isw = lane < K && wkey != 0u;
+    const int wl = isw ? (int)idx_of(s) : 0;
+    const int rw = wl >> 4;
+    if (__ballot(isw && rw == 1) == 0ull) {
+      const int wtok = __shfl(tokL, wl);
+      if (isw) {
+        new_src = wl & 15;
+        new_tok = wtok;
+        new_kind = rw == 2 ? 1 : (rw == 3 ? 2 : 0);
+        new_mass = fkey_nonneg_inv(wkey);
+      }
+      selected = true;
+    }
+  }
+
+  }
+  if (!selected) {  // the full tiers own their layout values: nothing of them is live above
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
   // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
   // available list entries of stream 0 in order, entry 3R-2 is stream 1, entry 3R-1 stream 2.
@@ -297,17 +353,14 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       for (int i = 0; i < R; ++i) av &= av - 1ull;  // next entry of this lane: e + R
     }
   };
-  fill_main(true);
   {
+    fill_main(true);
     // stream 1 / stream 2 live in slot 2 of rows R-2 / R-1
     const float m1_k = shfl_f(m1, ksrc), m2_k = shfl_f(m2, ksrc);
     const bool o1 = __shfl((int)s1_open, ksrc) != 0, o2 = __shfl((int)s2_open, ksrc) != 0;
     if (rr == R - 2) { key2 = (kvalid && o1) ? fkey_nonneg(m1_k) : 0u; tk2 = lastc_k; }
     if (rr == R - 1) { key2 = (kvalid && o2) ? fkey_nonneg(m2_k) : 0u; tk2 = lastc_k; }
   }
-
-  new_src = 0, new_tok = 0, new_kind = -1;
-  float new_mass = -PDT_INF;
   // Fast path: the K winners all at once.  A lane holding a winner has a local maximum >= the
   // K-th best candidate, and at most K lanes do, so tau = K-th largest local maximum bounds
   // the winners from below; the (>= K, usually ~K) resident candidates >= tau are compacted
@@ -315,8 +368,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // The serial rounds remain for the frames where the result could depend on entries that are
   // not resident: more than 64 survivors, or a winner that is the last resident stream-0
   // entry of its prefix (the rounds would refill that prefix's slots).
-  bool selected = false;
-  {
+  if (!selected) {
     u64 *sel = DENSE ? L.surv : reinterpret_cast<u64 *>(L.nxt_new);
     const unsigned lk = max(max(key0, key1), key2);
     const unsigned slk = wave_sort_desc<unsigned>(lk);
@@ -395,6 +447,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
         for (int q = 0; q < n_main; ++q) avail &= avail - 1ull;
       fill_main(kb == wbeam);
     }
+  }
   }
   PDT_STAMP(3);
   // ---- new beam state of lane i (:868-880) ---------------------------------------------
