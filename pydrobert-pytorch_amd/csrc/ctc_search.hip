@@ -1,24 +1,30 @@
-// CTC prefix beam search for gfx950 -- one wave per utterance, one LANE per beam entry.
+// CTC prefix beam search for gfx950 -- producer / consumer waves per utterance, one LANE per
+// beam entry.
 //
 // Replaces CTCPrefixSearch.forward without a language model (reference
 // _decoding.py:1064-1202) and its step function ctc_prefix_search_advance (:636-934),
 // which the reference evaluates as ~45 dense tensor ops per frame (a (N,K,K,V) one-hot and a
 // gather over the whole (t,N,K) history among them).  Here the whole T-frame search of one
-// utterance runs inside one wave:
-//   * beam state (nb, b, last token, length, trie node, is-prefix row as a 64-bit mask) lives
-//     in the registers of lane k;
-//   * a frame's logits are staged once into LDS, softmax statistics by DPP reductions;
-//   * candidates are never materialised: the mass of extending prefix k with token v is
-//     w_k(v) * p[v], monotone in p[v] for fixed k, so a K-way merge over per-prefix streams
-//     that walk ONE shared list of the top (K + K') tokens (wave_top_sorted) yields the exact
-//     global top-K in K rounds of a 32-bit DPP max-reduce;
+// utterance runs inside one workgroup slice:
+//   * producer wave(s): stage a frame's logits in an LDS ring slot, softmax statistics by DPP
+//     reductions, and the sorted list of the top (K + K') tokens (wave_top_sorted);
+//   * consumer wave: beam state (nb, b, last token, length, trie node, is-prefix row as a
+//     32-bit mask) lives in the registers of lane k; candidates are never materialised: the
+//     mass of extending prefix k with token v is w_k(v) * p[v], monotone in p[v] for fixed k,
+//     so every prefix walks the ONE shared sorted list, and the exact global top-K comes from
+//     the tiers in ctc_frame.hpp (lean 64-key sort / threshold + counting rank / serial
+//     wave-max rounds with refills);
 //   * prefixes are a trie in HBM ((parent, token) per created node) instead of dense
 //     (t, N, K) histories, so a frame writes K records instead of gathering t*K tokens; the
 //     only history look-ups the algorithm needs (token of prefix b at the position where
 //     prefix a ends) are served from a K x K table in LDS maintained incrementally.
 //
-// Tie policy: equal-mass candidates are taken lowest beam index first (the reference's
-// torch.topk leaves ties unspecified); parity is defined on tie-free inputs.
+// K + K' list entries suffice: a prefix can take at most K winners, lose at most K' - 1 list
+// entries to extensions that merge into existing beam prefixes, and its own last token is a
+// separate stream.
+//
+// Tie policy: equal-mass candidates are taken lowest lane first (the reference's torch.topk
+// leaves ties unspecified); parity is defined on tie-free inputs.
 #include "ctc_frame.hpp"
 
 namespace pdt {
