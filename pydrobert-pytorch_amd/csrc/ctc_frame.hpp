@@ -107,9 +107,10 @@ __device__ __forceinline__ int ctc_list_len(int V, int W, int Kp) {
 // tl_tok / tl_p (normalised) / pos (inverse index; entries of the previous list must be 0xFF).
 template <bool LONG = false>
 __device__ __forceinline__ void build_shared_list(const float *p, float inv, int V, int M, u64 *surv,
-                                                  int *tl_tok, float *tl_p, unsigned char *pos) {
+                                                  int *tl_tok, float *tl_p, unsigned char *pos,
+                                                  const unsigned *lmax_in = nullptr) {
   const int lane = lane_id();
-  const u64 tk = wave_top_sorted<LONG, true>(p, V, M, surv);  // p = exp(...) >= 0
+  const u64 tk = wave_top_sorted<LONG, true>(p, V, M, surv, lmax_in);  // p = exp(...) >= 0
   if (lane < M) {
     const int tok = (int)idx_of(tk);
     tl_tok[lane] = tok;

@@ -136,72 +136,102 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         if (lane < Mprev) pos[tl_tok[lane]] = 0xFF;
       }
       // softmax statistics of frame t (:1093): p[v] = exp(x[v] - max), sum over v in [0, V]
-      float mx = -PDT_INF;
+      float s = 0.0f;
+      unsigned lmax = 0u;  // per-lane maximum ordering key over the tokens (not the blank)
+      if constexpr (P == 1) {
+        // the whole row (V + 1 <= 512) sits in the prefetch registers: maximum, exponentials
+        // and ordering keys come straight from them -- one LDS store per element instead of
+        // store + load + store + load
+        float mx = -PDT_INF;
 #pragma unroll
-      for (int i = 0; i < kPrefetch; ++i) {
-        const int v = lane + i * PDT_WAVE;
-        if (v <= V) {
-          p[v] = pre[i];
-          mx = fmaxf(mx, pre[i]);
-        }
-      }
-      {
-        const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
-        int v = lane + kPrefetch * PDT_WAVE;
-        if constexpr (P > 1) {  // long rows: kBatch loads in flight
-          for (; v + (kBatch - 1) * PDT_WAVE <= V; v += kBatch * PDT_WAVE) {
-            float x[kBatch];
-#pragma unroll
-            for (int i = 0; i < kBatch; ++i) x[i] = row[(int64_t)(v + i * PDT_WAVE) * a.lg_sv];
-#pragma unroll
-            for (int i = 0; i < kBatch; ++i) {
-              p[v + i * PDT_WAVE] = x[i];
-              mx = fmaxf(mx, x[i]);
-            }
-          }
-        }
-        for (; v <= V; v += PDT_WAVE) {
-          const float x = row[(int64_t)v * a.lg_sv];
-          p[v] = x;
-          mx = fmaxf(mx, x);
-        }
-      }
-      if (t + P < Tn) {
-        const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn;
+        for (int i = 0; i < kPrefetch; ++i)
+          if (lane + i * PDT_WAVE <= V) mx = fmaxf(mx, pre[i]);
+        mx = wave_max_f(mx);
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i) {
           const int v = lane + i * PDT_WAVE;
-          if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
-        }
-      }
-      mx = wave_max_f(mx);
-      float s = 0.0f;
-      {
-        int v = lane;
-        if constexpr (P > 1) {
-          for (; v + 7 * PDT_WAVE <= V; v += 8 * PDT_WAVE) {
-            float x[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) x[i] = p[v + i * PDT_WAVE];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-              const float e = exp_nonpos(x[i] - mx);
-              p[v + i * PDT_WAVE] = e;
-              s += e;
-            }
+          if (v <= V) {
+            const float e = exp_nonpos(pre[i] - mx);
+            p[v] = e;
+            s += e;
+            if (v < V) lmax = max(lmax, fkey_nonneg(e));
           }
         }
-        for (; v <= V; v += PDT_WAVE) {
-          const float e = exp_nonpos(p[v] - mx);
-          p[v] = e;
-          s += e;
+        if (t + P < Tn) {
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn;
+#pragma unroll
+          for (int i = 0; i < kPrefetch; ++i) {
+            const int v = lane + i * PDT_WAVE;
+            if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
+          }
+        }
+      } else {
+        float mx = -PDT_INF;
+#pragma unroll
+        for (int i = 0; i < kPrefetch; ++i) {
+          const int v = lane + i * PDT_WAVE;
+          if (v <= V) {
+            p[v] = pre[i];
+            mx = fmaxf(mx, pre[i]);
+          }
+        }
+        {
+          const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+          int v = lane + kPrefetch * PDT_WAVE;
+          if constexpr (P > 1) {  // long rows: kBatch loads in flight
+            for (; v + (kBatch - 1) * PDT_WAVE <= V; v += kBatch * PDT_WAVE) {
+              float x[kBatch];
+#pragma unroll
+              for (int i = 0; i < kBatch; ++i) x[i] = row[(int64_t)(v + i * PDT_WAVE) * a.lg_sv];
+#pragma unroll
+              for (int i = 0; i < kBatch; ++i) {
+                p[v + i * PDT_WAVE] = x[i];
+                mx = fmaxf(mx, x[i]);
+              }
+            }
+          }
+          for (; v <= V; v += PDT_WAVE) {
+            const float x = row[(int64_t)v * a.lg_sv];
+            p[v] = x;
+            mx = fmaxf(mx, x);
+          }
+        }
+        if (t + P < Tn) {
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn;
+#pragma unroll
+          for (int i = 0; i < kPrefetch; ++i) {
+            const int v = lane + i * PDT_WAVE;
+            if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
+          }
+        }
+        mx = wave_max_f(mx);
+        {
+          int v = lane;
+          if constexpr (P > 1) {
+            for (; v + 7 * PDT_WAVE <= V; v += 8 * PDT_WAVE) {
+              float x[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) x[i] = p[v + i * PDT_WAVE];
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                const float e = exp_nonpos(x[i] - mx);
+                p[v + i * PDT_WAVE] = e;
+                s += e;
+              }
+            }
+          }
+          for (; v <= V; v += PDT_WAVE) {
+            const float e = exp_nonpos(p[v] - mx);
+            p[v] = e;
+            s += e;
+          }
         }
       }
       s = wave_sum_f(s);
       wave_sync();
       const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
       const float inv = __fdiv_rn(1.0f, s);  // the only division of the frame
-      build_shared_list<(P > 1)>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos);
+      build_shared_list<(P > 1)>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos, P == 1 ? &lmax : nullptr);
       if (lane == 0) {
         hdr[0] = inv;
         hdr[2] = __int_as_float(M);

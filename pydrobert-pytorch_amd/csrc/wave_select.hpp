@@ -149,9 +149,12 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // instead of one round trip per 64 elements (needs the registers of a low-occupancy kernel).
 // NONNEG: every x[v] >= +0 (the keys inside the result are then fkey_nonneg keys; callers that
 // only read the indices do not care).
+// lmax_in: the caller already holds max over its lane's slice of the ordering keys (it had
+// the values in registers), so the first pass over x is skipped.
 template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
-                                                       int M, u64 *surv) {
+                                                       int M, u64 *surv,
+                                                       const unsigned *lmax_in = nullptr) {
   const int lane = lane_id();
   auto X = [&](int v) { return xb[(int64_t)v * sx]; };
   auto fkey = [](float f) { return NONNEG ? fkey_nonneg(f) : pdt::fkey(f); };
@@ -161,7 +164,9 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
   }
   constexpr int B = LONG ? 8 : 1;  // 64-element chunks per batch of loads
   unsigned lmax = 0u;
-  {
+  if (lmax_in) {
+    lmax = *lmax_in;
+  } else {
     int v = lane;
     if constexpr (LONG) {
       for (; v + (B - 1) * PDT_WAVE < V; v += B * PDT_WAVE) {
@@ -209,8 +214,9 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
   return cur;
 }
 template <bool LONG = false, bool NONNEG = false>
-__device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv) {
-  return wave_top_sorted_strided<LONG, NONNEG>(x, 1, V, M, surv);
+__device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv,
+                                               const unsigned *lmax_in = nullptr) {
+  return wave_top_sorted_strided<LONG, NONNEG>(x, 1, V, M, surv, lmax_in);
 }
 
 }  // namespace pdt
