@@ -13,6 +13,8 @@
 // torch.nn.functional.grid_sample(align_corners=False) arithmetic in float32.
 #include <cfloat>
 
+#include <type_traits>
+
 #include "pdt_common.hpp"
 
 namespace pdt {
@@ -31,6 +33,23 @@ __device__ __forceinline__ float phi_f(float r, int order) {
   for (int i = 0; i < order; ++i) rk *= r;
   if (order & 1) return rk;
   return rk * logf(fmaxf(r, FLT_EPSILON));
+}
+
+// phi(r) from the SQUARED distance, float32, for the per-pixel spline evaluation of the sparse
+// warp (7-100 centres per pixel: this is where its time goes).  Even orders need no square
+// root (r^k log r = d2^(k/2) * log(d2) / 2) and the logarithm is the hardware v_log_f32
+// (1 ulp) instead of OCML's logf; order 2 -- the default -- costs ~8 VALU per centre
+// instead of ~35.
+// ORDER = 1, 2, 3: that order, compiled without branches; ORDER = 0: any order (runtime).
+template <int ORDER>
+__device__ __forceinline__ float phi_from_d2(float d2, int order) {
+  if (ORDER == 2) return d2 * (0.5f * __logf(fmaxf(d2, FLT_EPSILON * FLT_EPSILON)));
+  if (ORDER == 1) return sqrtf(d2);
+  if (ORDER == 3) return d2 * sqrtf(d2);
+  float pw = 1.0f;  // d2^(order / 2)
+  for (int i = 0; i < (order >> 1); ++i) pw *= d2;
+  if (order & 1) return pw * sqrtf(d2);
+  return pw * (0.5f * __logf(fmaxf(d2, FLT_EPSILON * FLT_EPSILON)));
 }
 
 // Solve the bordered system [[A + reg*I, B], [B^T, 0]] [w; v] = [f; 0] (_img.py:79-130) for one
@@ -520,6 +539,7 @@ struct WarpArgs {
 
 // BACKWARD = adjoint with respect to the image: the same sampling positions, each pixel scatters
 // its gradient to its taps with the hardware float atomic.
+constexpr int kPixPerWG = 2048;
 template <bool BACKWARD>
 __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -532,79 +552,103 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
     for (int i = (int)threadIdx.x; i < 2 * (a.M + 3); i += 256) lw[i] = a.wv[n * 2 * (a.M + 3) + i];
     __syncthreads();
   }
-  const int pix = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (pix >= H * W) return;
-  const int h = pix / W, w = pix - h * W;
-  float gx, gy;
-  if (a.knots) {
-    const float x = (float)w, y = (float)h;
-    float sx = lw[2 * a.M + 0] * x + lw[2 * (a.M + 1) + 0] * y + lw[2 * (a.M + 2) + 0];
-    float sy = lw[2 * a.M + 1] * x + lw[2 * (a.M + 1) + 1] * y + lw[2 * (a.M + 2) + 1];
-    for (int m = 0; m < a.M; ++m) {
-      const float dx = x - lk[2 * m], dy = y - lk[2 * m + 1];
-      const float p = phi_f(sqrtf(dx * dx + dy * dy), a.order);
-      sx += p * lw[2 * m];
-      sy += p * lw[2 * m + 1];
-    }
-    if (a.as_grid) {
-      gx = sx;
-      gy = sy;
+  const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;  // wave-uniform: two divisions per wave
+  // a workgroup covers kPixPerWG pixels: the LDS staging + barrier above is paid once per
+  // 2048 pixels instead of once per 256 (it dominated at one pixel per thread)
+  for (int pix = (int)(blockIdx.x * kPixPerWG + threadIdx.x);
+       pix < min(H * W, (int)((blockIdx.x + 1) * kPixPerWG)); pix += 256) {
+    // (h, w) of the pixel without an integer division where a float holds pix exactly:
+    // reciprocal estimate + one-step fix-up
+    int h, w;
+    if (H * W < (1 << 23)) {
+      h = (int)(((float)pix + 0.5f) * inv_w);
+      w = pix - h * W;
+      if (w < 0) { --h; w += W; }
+      if (w >= W) { ++h; w -= W; }
     } else {
-      if (!BACKWARD && a.flow_out) {
-        float *fo = a.flow_out + ((n * H + h) * (int64_t)W + w) * 2;
-        fo[0] = a.flow_out_flip ? sy : sx;
-        fo[1] = a.flow_out_flip ? sx : sy;
+      h = pix / W;
+      w = pix - h * W;
+    }
+    float gx, gy;
+    if (a.knots) {
+      const float x = (float)w, y = (float)h;
+      float sx = lw[2 * a.M + 0] * x + lw[2 * (a.M + 1) + 0] * y + lw[2 * (a.M + 2) + 0];
+      float sy = lw[2 * a.M + 1] * x + lw[2 * (a.M + 1) + 1] * y + lw[2 * (a.M + 2) + 1];
+      // the order is wave-uniform: pick the specialised loop once, outside the centre loop
+      auto centres = [&](auto tag) {
+        constexpr int ORDER = decltype(tag)::value;
+#pragma unroll 4
+        for (int m = 0; m < a.M; ++m) {
+          const float dx = x - lk[2 * m], dy = y - lk[2 * m + 1];
+          const float p = phi_from_d2<ORDER>(dx * dx + dy * dy, a.order);
+          sx += p * lw[2 * m];
+          sy += p * lw[2 * m + 1];
+        }
+      };
+      if (a.order == 2) centres(std::integral_constant<int, 2>{});
+      else if (a.order == 1) centres(std::integral_constant<int, 1>{});
+      else if (a.order == 3) centres(std::integral_constant<int, 3>{});
+      else centres(std::integral_constant<int, 0>{});
+      if (a.as_grid) {
+        gx = sx;
+        gy = sy;
+      } else {
+        if (!BACKWARD && a.flow_out) {
+          float *fo = a.flow_out + ((n * H + h) * (int64_t)W + w) * 2;
+          fo[0] = a.flow_out_flip ? sy : sx;
+          fo[1] = a.flow_out_flip ? sx : sy;
+        }
+        gx = (2.0f * x - 2.0f * sx + 1.0f) * inv_w - 1.0f;  // _img.py:432
+        gy = (2.0f * y - 2.0f * sy + 1.0f) * inv_h - 1.0f;
       }
-      gx = (2.0f * x - 2.0f * sx + 1.0f) / (float)W - 1.0f;  // _img.py:432
-      gy = (2.0f * y - 2.0f * sy + 1.0f) / (float)H - 1.0f;
+    } else {
+      const float *fl = a.flow + ((n * H + h) * (int64_t)W + w) * 2;
+      const float fx = a.flip ? fl[1] : fl[0], fy = a.flip ? fl[0] : fl[1];
+      gx = (2.0f * (float)w - 2.0f * fx + 1.0f) * inv_w - 1.0f;
+      gy = (2.0f * (float)h - 2.0f * fy + 1.0f) * inv_h - 1.0f;
     }
-  } else {
-    const float *fl = a.flow + ((n * H + h) * (int64_t)W + w) * 2;
-    const float fx = a.flip ? fl[1] : fl[0], fy = a.flip ? fl[0] : fl[1];
-    gx = (2.0f * (float)w - 2.0f * fx + 1.0f) / (float)W - 1.0f;
-    gy = (2.0f * (float)h - 2.0f * fy + 1.0f) / (float)H - 1.0f;
-  }
-  const float ix = source_index(gx, W, a.padding), iy = source_index(gy, H, a.padding);
-  const int64_t plane = (int64_t)H * W;
-  const float *img = a.image + n * a.C * plane;
-  float *o = a.out + n * a.C * plane + pix;
-  float *gi = a.grad_image + n * a.C * plane;
-  if (a.mode == INTERP_NEAREST) {
-    const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
-    const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
+    const float ix = source_index(gx, W, a.padding), iy = source_index(gy, H, a.padding);
+    const int64_t plane = (int64_t)H * W;
+    const float *img = a.image + n * a.C * plane;
+    float *o = a.out + n * a.C * plane + pix;
+    float *gi = a.grad_image + n * a.C * plane;
+    if (a.mode == INTERP_NEAREST) {
+      const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+      const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
+      if (BACKWARD) {
+        if (ok)
+          for (int c = 0; c < a.C; ++c) unsafeAtomicAdd(gi + c * plane + (int64_t)yn * W + xn, o[c * plane]);
+        continue;
+      }
+      for (int c = 0; c < a.C; ++c) o[c * plane] = ok ? img[c * plane + (int64_t)yn * W + xn] : 0.0f;
+      continue;
+    }
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
+    const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
+    const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     if (BACKWARD) {
-      if (ok)
-        for (int c = 0; c < a.C; ++c) unsafeAtomicAdd(gi + c * plane + (int64_t)yn * W + xn, o[c * plane]);
-      return;
+      for (int c = 0; c < a.C; ++c) {
+        float *pl = gi + c * plane;
+        const float g = o[c * plane];
+        if (vx0 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x0, g * (wx0 * wy0));
+        if (vx1 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x1, g * (wx1 * wy0));
+        if (vx0 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x0, g * (wx0 * wy1));
+        if (vx1 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x1, g * (wx1 * wy1));
+      }
+      continue;
     }
-    for (int c = 0; c < a.C; ++c) o[c * plane] = ok ? img[c * plane + (int64_t)yn * W + xn] : 0.0f;
-    return;
-  }
-  const float x0f = floorf(ix), y0f = floorf(iy);
-  const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-  const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
-  const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
-  const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
-  if (BACKWARD) {
     for (int c = 0; c < a.C; ++c) {
-      float *pl = gi + c * plane;
-      const float g = o[c * plane];
-      if (vx0 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x0, g * (wx0 * wy0));
-      if (vx1 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x1, g * (wx1 * wy0));
-      if (vx0 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x0, g * (wx0 * wy1));
-      if (vx1 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x1, g * (wx1 * wy1));
+      const float *pl = img + c * plane;
+      float v = 0.0f;
+      if (vx0 && vy0) v += pl[(int64_t)y0 * W + x0] * (wx0 * wy0);
+      if (vx1 && vy0) v += pl[(int64_t)y0 * W + x1] * (wx1 * wy0);
+      if (vx0 && vy1) v += pl[(int64_t)y1 * W + x0] * (wx0 * wy1);
+      if (vx1 && vy1) v += pl[(int64_t)y1 * W + x1] * (wx1 * wy1);
+      o[c * plane] = v;
     }
-    return;
-  }
-  for (int c = 0; c < a.C; ++c) {
-    const float *pl = img + c * plane;
-    float v = 0.0f;
-    if (vx0 && vy0) v += pl[(int64_t)y0 * W + x0] * (wx0 * wy0);
-    if (vx1 && vy0) v += pl[(int64_t)y0 * W + x1] * (wx1 * wy0);
-    if (vx0 && vy1) v += pl[(int64_t)y1 * W + x0] * (wx0 * wy1);
-    if (vx1 && vy1) v += pl[(int64_t)y1 * W + x1] * (wx1 * wy1);
-    o[c * plane] = v;
-  }
+}
 }
 
 // copy the double solution into float (w, v) laid out (N, M+3, 2) for image_warp_kernel
@@ -746,7 +790,7 @@ static int dense_warp_launch(const float *image, const float *flow, int64_t N, i
   a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
   a.mode = mode; a.padding = padding; a.flow = flow; a.flip = flow_is_hw;
   a.grad_image = grad_image;
-  const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)N);
+  const dim3 grid((unsigned)((H * W + kPixPerWG - 1) / kPixPerWG), (unsigned)N);
   if (grad_image) {
     hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(float),
                                   (hipStream_t)stream);
@@ -800,7 +844,7 @@ static int sparse_warp_launch(const float *image, const float *train_points,
   a.flow_out = flow_out; a.flow_out_flip = flow_out_is_hw;
   a.grad_image = grad_image;
   const size_t smem = (size_t)(2 * M + 2 * (M + 3)) * sizeof(float);
-  const dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)N);
+  const dim3 grid((unsigned)((H * W + kPixPerWG - 1) / kPixPerWG), (unsigned)N);
   if (grad_image) {
     hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(float),
                                   (hipStream_t)stream);
