@@ -100,7 +100,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        # RCCL is the data path.  PDT_BENCH_BACKEND=gloo is a rehearsal switch for boxes with fewer
+        # GPUs than ranks (RCCL refuses two ranks on one device); the gather is then host-staged.
+        backend = os.environ.get("PDT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     from pydrobert_amd import functional as F
 
@@ -143,7 +149,12 @@ def main():
             F.ctc_prefix_search(logits, args.beam)
             mark()
         if world > 1:
-            dist.all_gather_into_tensor(gathered, er)
+            if dist.get_backend() == "nccl":
+                dist.all_gather_into_tensor(gathered, er)
+            else:
+                parts = [torch.empty(N) for _ in range(world)]
+                dist.all_gather(parts, er.cpu())
+                gathered.copy_(torch.cat(parts))
             mark()
         return er
 
@@ -165,7 +176,9 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        tmax = torch.tensor(
+            [dt], device=device if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64
+        )
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
