@@ -22,6 +22,14 @@ __device__ unsigned long long *g_stamp_lds_dummy;
 #define PDT_STAMP_BEGIN do {} while (0)
 #endif
 
+// Diagnostic build only (-DPDT_STATS): event counters (lane 0 of every wave)
+#ifdef PDT_STATS
+__device__ unsigned long long g_stats[16];
+#define PDT_STAT(i) do { if (lane_id() == 0) atomicAdd(&g_stats[i], 1ull); } while (0)
+#else
+#define PDT_STAT(i) do {} while (0)
+#endif
+
 constexpr int kMaxWidth = 32;  // K + K' <= 64 tokens fit one per lane
 
 struct CtcArgs {
@@ -51,6 +59,13 @@ __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 __device__ __forceinline__ float shfl_f(float v, int l) { return __shfl(v, l); }
+// a zero the compiler cannot hoist out of the frame loop (it kept hoisted zero registers live
+// across the whole loop, spilled them, and reloaded them from scratch before every LDS clear)
+__device__ __forceinline__ unsigned fresh_zero() {
+  unsigned z;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+  return z;
+}
 
 // Extra inputs of the step-function form (ctc_prefix_search_advance): per-prefix extension
 // probabilities (language-model fusion) and a dense (S, N, K') history instead of the trie.
@@ -76,6 +91,10 @@ struct FrameLds {
   unsigned *chm;       // [max(W, Kp)] new beam entries that descend from old entry j
   int *info;           // [2 * W] packed description of every new beam entry
   int *nxt_old, *nxt_new;  // [nxt_stride(W)] token of prefix b right after prefix a (trie form only)
+  // shared list only: entries the list holds (a producer may hand over a SHORT exact top-c list,
+  // c < K + K'; ctc_frame completes it when a frame needs more) and the slot header to record that
+  int list_len;
+  float *hdr;
   static __host__ __device__ size_t bytes(int V, int W, int Kp, bool dense) {
     const int RS = W > Kp ? W : Kp;
     size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)(dense ? Kp : 1) * PDT_WAVE * 8;
@@ -108,9 +127,10 @@ __device__ __forceinline__ int ctc_list_len(int V, int W, int Kp) {
 template <bool LONG = false>
 __device__ __forceinline__ void build_shared_list(const float *p, float inv, int V, int M, u64 *surv,
                                                   int *tl_tok, float *tl_p, unsigned char *pos,
-                                                  const unsigned *lmax_in = nullptr) {
+                                                  const unsigned *lmax_in = nullptr,
+                                                  unsigned *probe = nullptr, int probe_rank = 1) {
   const int lane = lane_id();
-  const u64 tk = wave_top_sorted<LONG, true>(p, V, M, surv, lmax_in);  // p = exp(...) >= 0
+  const u64 tk = wave_top_sorted<LONG, true>(p, V, M, surv, lmax_in, probe, probe_rank);  // p >= 0
   if (lane < M) {
     const int tok = (int)idx_of(tk);
     tl_tok[lane] = tok;
@@ -140,7 +160,11 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
                                           const FrameLds &L, int &new_src, int &new_tok,
                                           int &new_kind PDT_STAMP_PARAM) {
-  const int lane = lane_id();
+  // (laundered: inside a frame loop nothing derived from the lane index is loop-invariant to the
+  // compiler, so it is recomputed where used instead of hoisted, kept live across the whole
+  // loop and spilled -- scratch reloads sat on the critical path of every frame)
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));
   const bool live = lane < Kp;
   const int K = min(W, Kp * (V + 1));  // _decoding.py:775
   const int M = min(V, K + Kp);
@@ -174,58 +198,68 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   const bool valid_beam = live && tot > -PDT_INF;
   wave_sync();
 
-  // index of my last token in my list (-1: not among the top M)
-  int jl = -1;
-  if (!DENSE) {
-    const int q = L.pos[lastc];
-    jl = q == 0xFF ? -1 : q;
-  } else {
-    for (int j = 0; j < M; ++j) jl = mt[j] == lastc ? j : jl;
-  }
-  // stream 0: list entries still available to this prefix (my own last token goes to stream 1)
-  u64 avail = M >= 64 ? ~0ull : ((1ull << M) - 1ull);
-  if (jl >= 0) avail &= ~(1ull << jl);
-  bool s1_open = valid_beam, s2_open = valid_beam;
-
+  // index of my last token in my list (-1: not among its entries), the list entries still
+  // available to this prefix (stream 0; my own last token goes to stream 1), and the
   // ---- merge: an extension of kk that equals an existing prefix feeds that prefix --------
-  // (:804-837); only prefixes that have descendants in the beam are visited
+  // (:804-837); only prefixes that have descendants in the beam are visited.
+  // `c` = entries the list holds.  Run once per frame, and a second time (accumulate = false:
+  // the masses are already in `add`) if a short list had to be completed.
+  const int c_list = DENSE ? M : min(L.list_len, M);
+  const bool full_list = DENSE || c_list >= M;
+  int jl = -1;
+  u64 avail = 0ull;
+  bool s1_open = valid_beam, s2_open = valid_beam;
   float add = 0.0f;
-  u64 par = __ballot(live && (bm.isp & ~(1u << lane)) != 0u);
-  while (par) {
-    const int kk = (int)__builtin_ctzll(par);
-    par &= par - 1ull;
-    const unsigned isp_kk = (unsigned)__builtin_amdgcn_readlane((int)bm.isp, kk);
-    const int len_kk = __builtin_amdgcn_readlane(bm.len, kk);
-    const bool child = live && ((isp_kk >> lane) & 1u) && (len_kk + 1 == bm.len);
-    u64 cm = __ballot(child);
-    if (cm == 0ull) continue;
-    const float nb_kk = readlane_f(bm.nb, kk), b_kk = readlane_f(bm.b, kk);
-    const int last_kk = min(max(__builtin_amdgcn_readlane(bm.last, kk), 0), V - 1);
-    int jc = jl;  // index of my last token in kk's list
-    if (DENSE) {
-      jc = -1;
-      for (int j = 0; j < M; ++j) jc = L.tl_tok[kk * PDT_WAVE + j] == lastc ? j : jc;
+  auto index_pass = [&](const int c, const bool accumulate) {
+    jl = -1;
+    if (!DENSE) {
+      const int q = L.pos[lastc];
+      jl = q == 0xFF ? -1 : q;
+    } else {
+      for (int j = 0; j < M; ++j) jl = mt[j] == lastc ? j : jl;
     }
-    if (child) {
-      // to_match = the last token of the child (whose length is len_kk + 1)
-      const float w = (lastc == last_kk ? 0.0f : nb_kk) + b_kk;
-      const float e = DENSE ? dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv] : pl;
-      add += w * e;
+    avail = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
+    if (jl >= 0) avail &= ~(1ull << jl);
+    u64 par = __ballot(live && (bm.isp & ~(1u << lane)) != 0u);
+    while (par) {
+      const int kk = (int)__builtin_ctzll(par);
+      par &= par - 1ull;
+      const unsigned isp_kk = (unsigned)__builtin_amdgcn_readlane((int)bm.isp, kk);
+      const int len_kk = __builtin_amdgcn_readlane(bm.len, kk);
+      const bool child = live && ((isp_kk >> lane) & 1u) && (len_kk + 1 == bm.len);
+      u64 cm = __ballot(child);
+      if (cm == 0ull) continue;
+      const int last_kk = min(max(__builtin_amdgcn_readlane(bm.last, kk), 0), V - 1);
+      int jc = jl;  // index of my last token in kk's list
+      if (DENSE) {
+        jc = -1;
+        for (int j = 0; j < M; ++j) jc = L.tl_tok[kk * PDT_WAVE + j] == lastc ? j : jc;
+      }
+      if (accumulate) {
+        const float nb_kk = readlane_f(bm.nb, kk), b_kk = readlane_f(bm.b, kk);
+        if (child) {
+          // to_match = the last token of the child (whose length is len_kk + 1)
+          const float w = (lastc == last_kk ? 0.0f : nb_kk) + b_kk;
+          const float e = DENSE ? dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv] : pl;
+          add += w * e;
+        }
+      }
+      u64 rm = 0ull;
+      bool close1 = false;
+      while (cm) {
+        const int c2 = (int)__builtin_ctzll(cm);
+        cm &= cm - 1ull;
+        const int jcc = __builtin_amdgcn_readlane(jc, c2);
+        if (jcc >= 0) rm |= 1ull << jcc;
+        close1 = close1 || (__builtin_amdgcn_readlane(lastc, c2) == last_kk);
+      }
+      if (lane == kk) {
+        avail &= ~rm;
+        if (close1) s1_open = false;
+      }
     }
-    u64 rm = 0ull;
-    bool close1 = false;
-    while (cm) {
-      const int c = (int)__builtin_ctzll(cm);
-      cm &= cm - 1ull;
-      const int jcc = __builtin_amdgcn_readlane(jc, c);
-      if (jcc >= 0) rm |= 1ull << jcc;
-      close1 = close1 || (__builtin_amdgcn_readlane(lastc, c) == last_kk);
-    }
-    if (lane == kk) {
-      avail &= ~rm;
-      if (close1) s1_open = false;
-    }
-  }
+  };
+  index_pass(c_list, true);
   NB = NB + add;
   PDT_STAMP(2);
 
@@ -260,25 +294,30 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // (not resident here) could matter: the full tiers below decide the frame instead (5.6 %).
   if (G == 16 && M <= 32) {
     // this row's candidate of prefix kb: rows 0 / 1 read the list, rows 2 / 3 a stream mass
+    // A short list (c_list < M) may end before a prefix's entry 0 / 1: the row then holds an
+    // UPPER BOUND of the hidden entry (the mass with the list's last probability, key + 1 so it
+    // wins ties); if a bound ranks among the winners the frame needs the complete list.
     const unsigned avk = (unsigned)__shfl((int)(unsigned)avail, ksrc);
     const unsigned av = rr == 1 ? (avk & (avk - 1u)) : avk;
+    const bool hidden = !full_list && rr < 2 && av == 0u;
     // (a shuffle moves the SOURCE lane's operand: fetch both streams, then pick by row)
     const float ms1 = shfl_f(m1, ksrc), ms2 = shfl_f(m2, ksrc);
     const int open12 = __shfl((int)s1_open | ((int)s2_open << 1), ksrc);
     const float ms = rr == 2 ? ms1 : ms2;
     const bool os = ((open12 >> (rr == 2 ? 0 : 1)) & 1) != 0;
-    const int j = av ? __builtin_ctz(av) : 0;
+    const int j = av ? __builtin_ctz(av) : (hidden ? c_list - 1 : 0);
     const int tokj = L.tl_tok[(DENSE ? ksrc : 0) * PDT_WAVE + j];
     const float pj = L.tl_p[(DENSE ? ksrc : 0) * PDT_WAVE + j];
-    const bool has = kvalid && (rr < 2 ? av != 0u : os);
-    const unsigned keyL = has ? fkey_nonneg(rr < 2 ? tot_k * pj : ms) : 0u;
+    const bool has = kvalid && (rr < 2 ? (av != 0u || hidden) : os);
+    const unsigned keyL = has ? fkey_nonneg(rr < 2 ? tot_k * pj : ms) + (hidden ? 1u : 0u) : 0u;
     const int tokL = rr < 2 ? tokj : lastc_k;
-    const u64 s = wave_sort_desc<u64>(pack_key(keyL, (unsigned)lane));
+    const u64 s = wave_sort_desc<u64>(pack_key(keyL, (unsigned)lane | (hidden ? 64u : 0u)));
     const unsigned wkey = key_of(s);
     const bool isw = lane < K && wkey != 0u;
-    const int wl = isw ? (int)idx_of(s) : 0;
+    const int wid = isw ? (int)idx_of(s) : 0;
+    const int wl = wid & 63;
     const int rw = wl >> 4;
-    if (__ballot(isw && rw == 1) == 0ull) {
+    if (__ballot(isw && (rw == 1 || wid >= 64)) == 0ull) {
       const int wtok = __shfl(tokL, wl);
       if (isw) {
         new_src = wl & 15;
@@ -291,7 +330,18 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   }
 
   }
+  if (!DENSE && !selected && !full_list) {
+    // the producer handed over a short list and this frame needs more: complete it here (the
+    // short list is a prefix of the complete one, so the entries already indexed stay valid)
+    // and redo the bookkeeping that depends on list positions
+    PDT_STAT(4);
+    build_shared_list<false>(p, inv, V, M, reinterpret_cast<u64 *>(L.nxt_new), L.tl_tok, L.tl_p, L.pos);
+    if (lane == 0) L.hdr[2] = __int_as_float(M);
+    wave_sync();
+    index_pass(M, false);
+  }
   if (!selected) {  // the full tiers own their layout values: nothing of them is live above
+  PDT_STAT(5);
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
   // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
   // available list entries of stream 0 in order, entry 3R-2 is stream 1, entry 3R-1 stream 2.
@@ -382,7 +432,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       auto below = [&](u64 b) {
         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
       };
-      sel[lane] = 0ull;
+      sel[lane] = (u64)fresh_zero();
       wave_sync();
       if (p0) sel[below(b0)] = pack_key(key0, (unsigned)(lane * 4 + 0));
       if (p1) sel[c0 + below(b1)] = pack_key(key1, (unsigned)(lane * 4 + 1));
@@ -473,7 +523,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // from old entry j, so lane a visits  U_{j in isp(src_a)} chm[j]  (usually 1-3 entries).
   // nxt[a * W + b] = token of prefix b at position len(a), defined when a is a strict prefix.
   const int RS = W > Kp ? W : Kp;
-  if (lane < RS) L.chm[lane] = 0u;
+  if (lane < RS) L.chm[lane] = fresh_zero();
   wave_sync();
   if (is_valid) {
     atomicOr(&L.chm[new_src], 1u << lane);

@@ -113,12 +113,23 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     constexpr int kPrefetch = 8;
     constexpr int kBatch = 8;  // long rows: loads in flight beyond the prefetched part
     float pre[kPrefetch];
+    // Short lists (P == 1, K <= 16).  94 % of the frames are decided by each prefix's first one or
+    // two list entries (lean tier, ctc_frame.hpp), so the producer normally hands over only the
+    // exact top-c tokens for some c in [kShortMin, 32]: the tokens whose numerator is >= that of
+    // a GUESSED logit threshold  mean + thr_off  (counted and compacted while the exponentials
+    // are computed; one 32-key sort).  The guess comes from the previous frames -- seeded by
+    // the probe of a complete selection, then nudged to keep c near 20 -- and a miss (c outside
+    // the window) just takes the complete selection.  The consumer completes a short list itself
+    // in the frames that turn out to need more.
+    constexpr int kShortMin = 8, kShortMax = 32, kShortLo = 14, kShortHi = 26, kProbeRank = 18;
+    const bool short_ok = P == 1 && W <= 16 && V > PDT_WAVE;
+    float thr_off = PDT_INF;  // no guess yet
     if (pr < Tn) {
-      const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn;
+      const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
 #pragma unroll
       for (int i = 0; i < kPrefetch; ++i) {
         const int v = lane + i * PDT_WAVE;
-        pre[i] = v <= V ? row0[(int64_t)v * a.lg_sv] : 0.0f;
+        pre[i] = v <= V ? row0[(int64_t)(i * PDT_WAVE) * a.lg_sv] : 0.0f;
       }
     }
     for (int t = pr; t < Tn; t += P) {
@@ -138,31 +149,57 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       // softmax statistics of frame t (:1093): p[v] = exp(x[v] - max), sum over v in [0, V]
       float s = 0.0f;
       unsigned lmax = 0u;  // per-lane maximum ordering key over the tokens (not the blank)
+      unsigned tkey = 0xFFFFFFFFu;  // key of the guessed threshold (none: nothing survives)
+      int nshort = 0;               // tokens at or above it
+      float mean = 0.0f, mx_of_row = 0.0f;
       if constexpr (P == 1) {
         // the whole row (V + 1 <= 512) sits in the prefetch registers: maximum, exponentials
         // and ordering keys come straight from them -- one LDS store per element instead of
         // store + load + store + load
-        float mx = -PDT_INF;
+        float mx = -PDT_INF, sx = 0.0f;
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i)
-          if (lane + i * PDT_WAVE <= V) mx = fmaxf(mx, pre[i]);
+          if (lane + i * PDT_WAVE <= V) {
+            mx = fmaxf(mx, pre[i]);
+            sx += pre[i];
+          }
         mx = wave_max_f(mx);
+        mx_of_row = mx;
+        if (short_ok) {
+          mean = wave_sum_f(sx) / (float)(V + 1);
+          // survivors: numerator >= the numerator of the guessed threshold (same exp routine, so
+          // the set is an upper set of the list order)
+          if (t > 0 && thr_off < PDT_INF) tkey = fkey_nonneg(exp_nonpos(fminf(mean + thr_off - mx, 0.0f)));
+        }
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i) {
           const int v = lane + i * PDT_WAVE;
+          unsigned key = 0u;
           if (v <= V) {
             const float e = exp_nonpos(pre[i] - mx);
             p[v] = e;
             s += e;
-            if (v < V) lmax = max(lmax, fkey_nonneg(e));
+            if (v < V) {
+              key = fkey_nonneg(e);
+              lmax = max(lmax, key);
+            }
+          }
+          const bool pred = key >= tkey;
+          const u64 bal = __ballot(pred);
+          if (bal) {
+            const int at = nshort + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+            if (pred && at < kShortMax) surv[at] = pack_key(key, (unsigned)v);
+            nshort += __popcll(bal);
           }
         }
         if (t + P < Tn) {
-          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn;
+          // (lane term first: the per-element offsets are then wave-uniform scalars, not eight
+          // hoisted 64-bit vector products)
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
 #pragma unroll
           for (int i = 0; i < kPrefetch; ++i) {
             const int v = lane + i * PDT_WAVE;
-            if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
+            if (v <= V) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
           }
         }
       } else {
@@ -197,11 +234,13 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
           }
         }
         if (t + P < Tn) {
-          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn;
+          // (lane term first: the per-element offsets are then wave-uniform scalars, not eight
+          // hoisted 64-bit vector products)
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
 #pragma unroll
           for (int i = 0; i < kPrefetch; ++i) {
             const int v = lane + i * PDT_WAVE;
-            if (v <= V) pre[i] = nrow[(int64_t)v * a.lg_sv];
+            if (v <= V) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
           }
         }
         mx = wave_max_f(mx);
@@ -231,10 +270,31 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       wave_sync();
       const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
       const float inv = __fdiv_rn(1.0f, s);  // the only division of the frame
-      build_shared_list<(P > 1)>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos, P == 1 ? &lmax : nullptr);
+      int Ml = M;
+      if (short_ok && nshort >= kShortMin && nshort <= kShortMax) {
+        PDT_STAT(1);
+        const u64 tk = half_wave_sort_desc<u64>(lane < nshort ? surv[lane] : 0ull);
+        Ml = min(nshort, M);
+        if (lane < Ml) {
+          const int tok = (int)idx_of(tk);
+          tl_tok[lane] = tok;
+          slot_p(sl)[lane] = fkey_nonneg_inv(key_of(tk)) * inv;
+          pos[tok] = (unsigned char)lane;
+        }
+        const float step = fmaxf(fabsf(thr_off) * 0.03125f, 1e-3f);
+        thr_off += nshort > kShortHi ? step : (nshort < kShortLo ? -step : 0.0f);
+      } else {
+        PDT_STAT(nshort > kShortMax ? 3 : 2);
+        unsigned probe = 0u;
+        build_shared_list<(P > 1)>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos, P == 1 ? &lmax : nullptr,
+                                   &probe, kProbeRank);
+        // logit offset (from the row mean) of the kProbeRank-th largest per-lane maximum
+        if (short_ok) thr_off = mx_of_row + __logf(fkey_nonneg_inv(probe)) - mean;
+      }
+      PDT_STAT(0);
       if (lane == 0) {
         hdr[0] = inv;
-        hdr[2] = __int_as_float(M);
+        hdr[2] = __int_as_float(Ml);
       }
       wave_sync();
       // one producer: frames arrive in order and ready[0] is a plain frame counter
@@ -245,6 +305,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   }
 
   // ---- consumer: the sequential beam update ----------------------------------------------
+#ifndef PDT_NO_PRIO
+  // the consumer's dependency chain is the critical path of the utterance (the producers run
+  // ahead by up to nstage frames): its instructions issue first, the producers fill the gaps
+  __builtin_amdgcn_s_setprio(3);
+#endif
   FrameLds L;
   L.surv = surv;  // unused by the shared-list form
   L.nxt_old = reinterpret_cast<int *>(cs);  // 8-byte aligned: nxt_new doubles as u64 scratch
@@ -271,6 +336,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     L.tl_tok = slot_tok(sl);
     L.tl_p = slot_p(sl);
     L.pos = slot_pos(sl);
+    L.hdr = slot_hdr(sl);
+    L.list_len = __float_as_int(slot_hdr(sl)[2]);
     const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
 #ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
@@ -379,6 +446,17 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
 }
 
 }  // extern "C"
+
+#ifdef PDT_STATS
+extern "C" int pdt_debug_read_stats(unsigned long long *host16, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host16, HIP_SYMBOL(pdt::g_stats), sizeof(unsigned long long) * 16);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[16] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_stats), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
 
 #ifdef PDT_STAMPS
 extern "C" int pdt_debug_read_stamps(unsigned long long *host16, int reset) {

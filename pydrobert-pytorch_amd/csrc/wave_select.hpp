@@ -94,6 +94,18 @@ __device__ __forceinline__ T wave_sort_desc(T key) {
   return key;
 }
 
+// the same network stopped after 15 stages: lanes 0..31 hold THEIR 32 keys sorted descending
+// (lanes 32..63 theirs ascending)
+template <typename T>
+__device__ __forceinline__ T half_wave_sort_desc(T key) {
+  key = bitonic_merge<2, 1>(key);
+  key = bitonic_merge<4, 2>(key);
+  key = bitonic_merge<8, 4>(key);
+  key = bitonic_merge<16, 8>(key);
+  key = bitonic_merge<32, 16>(key);
+  return key;
+}
+
 // cur: sorted descending; add: arbitrary.  Returns the 64 largest of the union, sorted descending.
 __device__ __forceinline__ u64 wave_merge_top64(u64 cur, u64 add) {
   const int lane = lane_id();
@@ -151,11 +163,16 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // only read the indices do not care).
 // lmax_in: the caller already holds max over its lane's slice of the ordering keys (it had
 // the values in registers), so the first pass over x is skipped.
+// probe / probe_rank: if given (and V > 64), *probe receives the probe_rank-th largest per-lane
+// maximum (as a key) -- a by-product callers use to guess the next row's threshold.
 template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
                                                        int M, u64 *surv,
-                                                       const unsigned *lmax_in = nullptr) {
-  const int lane = lane_id();
+                                                       const unsigned *lmax_in = nullptr,
+                                                       unsigned *probe = nullptr,
+                                                       int probe_rank = 1) {
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));  // nothing lane-derived is hoisted out of the caller's frame loop
   auto X = [&](int v) { return xb[(int64_t)v * sx]; };
   auto fkey = [](float f) { return NONNEG ? fkey_nonneg(f) : pdt::fkey(f); };
   if (V <= PDT_WAVE) {
@@ -181,6 +198,7 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
   }
   const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
   const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+  if (probe) *probe = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, probe_rank - 1);
   int count = 0;
   for (int v0 = 0; v0 < V; v0 += B * PDT_WAVE) {
     unsigned keys[B];
@@ -215,8 +233,9 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
 }
 template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv,
-                                               const unsigned *lmax_in = nullptr) {
-  return wave_top_sorted_strided<LONG, NONNEG>(x, 1, V, M, surv, lmax_in);
+                                               const unsigned *lmax_in = nullptr,
+                                               unsigned *probe = nullptr, int probe_rank = 1) {
+  return wave_top_sorted_strided<LONG, NONNEG>(x, 1, V, M, surv, lmax_in, probe, probe_rank);
 }
 
 }  // namespace pdt
