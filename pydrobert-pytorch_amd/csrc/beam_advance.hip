@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   const int old_len = bm.len;
   (void)old_len;
   #ifdef PDT_STAMPS
-  unsigned long long pdt_stamp_acc[8] = {0};
+  unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
   ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
 

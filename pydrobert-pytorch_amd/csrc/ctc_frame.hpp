@@ -13,8 +13,8 @@ __device__ unsigned long long *g_stamp_lds_dummy;
 #define PDT_STAMP(ph)                                                        \
   do {                                                                       \
     const unsigned long long now_ = __builtin_readcyclecounter();           \
-    if (lane_id() == 0) pdt_stamp_acc[ph] += now_ - stamp_last_;             \
-    stamp_last_ = __builtin_readcyclecounter();                              \
+    pdt_stamp_acc[ph] += (unsigned)(now_ - stamp_last_);                     \
+    stamp_last_ = now_;                                                      \
   } while (0)
 #define PDT_STAMP_BEGIN unsigned long long stamp_last_ = __builtin_readcyclecounter()
 #else
@@ -40,7 +40,7 @@ struct CtcArgs {
   int64_t *y;           // (S, N, W) contiguous
   int64_t *y_lens;      // (N, W)
   float *y_probs;       // (N, W)
-  int2 *trie;           // (T, N, W) records (parent node, token)
+  int2 *trie;           // (N, T, W) records (parent node, token); node id = t * W + i
   int lds_per_wave, waves_per_wg;
 };
 
@@ -147,7 +147,7 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 // On return new_src / new_tok / new_kind describe where lane i's new prefix came from
 // (kind: 0/1 extension, 2 non-extension, -1 invalid).
 #ifdef PDT_STAMPS
-#define PDT_STAMP_PARAM , unsigned long long *pdt_stamp_acc
+#define PDT_STAMP_PARAM , unsigned *pdt_stamp_acc
 #define PDT_STAMP_ARG , pdt_stamp_acc
 #else
 #define PDT_STAMP_PARAM
@@ -311,14 +311,27 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     const bool has = kvalid && (rr < 2 ? (av != 0u || hidden) : os);
     const unsigned keyL = has ? fkey_nonneg(rr < 2 ? tot_k * pj : ms) + (hidden ? 1u : 0u) : 0u;
     const int tokL = rr < 2 ? tokj : lastc_k;
-    const u64 s = wave_sort_desc<u64>(pack_key(keyL, (unsigned)lane | (hidden ? 64u : 0u)));
-    const unsigned wkey = key_of(s);
+    // ONE 64-key sort of 32-bit keys: the mass key rounded up to a multiple of 64 with the lane
+    // (inverted: lowest lane first) in the freed bits -- 3 VALU per stage instead of the 5-6 of
+    // a (key, lane) pair, on the critical path of the utterance.  The order of the top K + 1 is
+    // exact unless two of them agree in the upper 26 bits; such a frame (and one where a row-1
+    // entry or a bound wins) goes to the full tiers.  No candidate = 0 (valid keys are >= 1, so
+    // their rounded keys are >= 64).
+    PDT_STAMP(7);
+    const unsigned kt = has ? (((keyL + 63u) & ~63u) | (63u - (unsigned)lane)) : (63u - (unsigned)lane);
+    const unsigned st = wave_sort_desc<unsigned>(kt);
+    PDT_STAMP(8);
+    const int wl = 63 - (int)(st & 63u);
+    const unsigned wkey = (unsigned)__shfl((int)keyL, wl);
+    const int wth = __shfl(tokL | (hidden ? (int)0x80000000u : 0), wl);
+    const unsigned st_next = (unsigned)__shfl((int)st, lane + 1);
+    const int wtok = wth & 0x7fffffff;
     const bool isw = lane < K && wkey != 0u;
-    const int wid = isw ? (int)idx_of(s) : 0;
-    const int wl = wid & 63;
     const int rw = wl >> 4;
-    if (__ballot(isw && (rw == 1 || wid >= 64)) == 0ull) {
-      const int wtok = __shfl(tokL, wl);
+    const bool tie = lane < K && (st >> 6) != 0u && (st >> 6) == (st_next >> 6);
+    const int wid = wth < 0 ? 64 : 0;
+    PDT_STAMP(9);
+    if (__ballot((isw && (rw == 1 || wid >= 64)) || tie) == 0ull) {
       if (isw) {
         new_src = wl & 15;
         new_tok = wtok;
@@ -515,7 +528,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   nw.len = !is_valid ? 0 : len_s + (is_ext ? 1 : 0);
   nw.node = !is_valid ? -1 : (is_ext ? t * W + lane : node_s);
   if (!DENSE && is_valid && is_ext)
-    a.trie[((int64_t)t * a.N + n) * W + lane] = make_int2(node_s, new_tok);
+    a.trie[((int64_t)n * a.T + t) * W + lane] = make_int2(node_s, new_tok);
 
   PDT_STAMP(4);
   // ---- is-prefix relation and next-token table of the new beam (:883-898) ---------------
@@ -531,6 +544,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     L.info[2 * lane + 1] = len_s | (new_src << 20) | ((is_ext ? 1 : 0) << 28);
   }
   wave_sync();
+  PDT_STAMP(10);
   unsigned isp_new = 0u;
   bool need_walk = false;
   if (is_valid) {
@@ -576,8 +590,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       if (need_walk && ((isp_new >> b) & 1u) && L.nxt_new[lane * W + b] == -(2 + b)) {
         int node = node_b, depth = lenB, tok = -1;
         while (node >= 0) {
-          const int tt = node / W, ii = node - tt * W;
-          const int2 *rec = a.trie + (((int64_t)tt * a.N + n) * W + ii);
+          const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
           const int par_ = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (depth == nw.len + 1) break;

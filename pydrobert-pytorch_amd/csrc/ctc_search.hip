@@ -39,6 +39,14 @@ __device__ __forceinline__ float exp_nonpos(float x) {
   return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
 }
 
+// max of two floats without the input canonicalisation fmaxf() has to add for values that come
+// straight from memory (NaN logits are outside the contract either way)
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 // LDS ring slot shared by the producer and consumer waves of one utterance.
 struct RingLayout {
   int row_floats;   // V + 1 padded to 4
@@ -100,6 +108,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   const int Tn = a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T;
   const int NS = rl.nstage;
 
+#ifdef PDT_STATS
+  {  // which SIMD hosts which role (HW_REG_HW_ID bits 5:4 = SIMD id)
+    const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    PDT_STAT(8 + (int)((hw >> 4) & 3u) * 2 + (producer ? 0 : 1));
+  }
+#endif
   if (producer) {
     for (int sl = pr; sl < NS; sl += P)
       for (int v = lane; v < rl.pos_bytes; v += PDT_WAVE) slot_pos(sl)[v] = 0xFF;
@@ -124,6 +138,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     constexpr int kShortMin = 8, kShortMax = 32, kShortLo = 14, kShortHi = 26, kProbeRank = 18;
     const bool short_ok = P == 1 && W <= 16 && V > PDT_WAVE;
     float thr_off = PDT_INF;  // no guess yet
+    const int nt = V / PDT_WAVE, rem = V - nt * PDT_WAVE;  // full token chunks; lane of the blank
+    const float inv_ntok = 1.0f / (float)(nt > 0 ? nt * PDT_WAVE : 1);
     if (pr < Tn) {
       const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
 #pragma unroll
@@ -155,51 +171,70 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       if constexpr (P == 1) {
         // the whole row (V + 1 <= 512) sits in the prefetch registers: maximum, exponentials
         // and ordering keys come straight from them -- one LDS store per element instead of
-        // store + load + store + load
+        // store + load + store + load.  Chunks i < nt hold tokens in every lane (wave-uniform
+        // branches, no lane masks); chunk nt ends with the blank in lane `rem`.
+        int lp = lane;
+        asm volatile("" : "+v"(lp));  // the two masks of chunk nt are recomputed, not hoisted
+        const bool in_row = lp <= rem, is_tok = lp < rem;
         float mx = -PDT_INF, sx = 0.0f;
 #pragma unroll
-        for (int i = 0; i < kPrefetch; ++i)
-          if (lane + i * PDT_WAVE <= V) {
-            mx = fmaxf(mx, pre[i]);
+        for (int i = 0; i < kPrefetch; ++i) {
+          if (i < nt) {
+            mx = fmax_raw(mx, pre[i]);
             sx += pre[i];
+          } else if (i == nt) {
+            mx = in_row ? fmax_raw(mx, pre[i]) : mx;
           }
+        }
         mx = wave_max_f(mx);
         mx_of_row = mx;
         if (short_ok) {
-          mean = wave_sum_f(sx) / (float)(V + 1);
+          mean = wave_sum_f(sx) * inv_ntok;  // over the tokens of the full chunks
           // survivors: numerator >= the numerator of the guessed threshold (same exp routine, so
           // the set is an upper set of the list order)
           if (t > 0 && thr_off < PDT_INF) tkey = fkey_nonneg(exp_nonpos(fminf(mean + thr_off - mx, 0.0f)));
         }
-#pragma unroll
-        for (int i = 0; i < kPrefetch; ++i) {
-          const int v = lane + i * PDT_WAVE;
-          unsigned key = 0u;
-          if (v <= V) {
-            const float e = exp_nonpos(pre[i] - mx);
-            p[v] = e;
-            s += e;
-            if (v < V) {
-              key = fkey_nonneg(e);
-              lmax = max(lmax, key);
-            }
-          }
-          const bool pred = key >= tkey;
+        auto survivors = [&](const unsigned key, const bool pred, const int v) {
           const u64 bal = __ballot(pred);
           if (bal) {
             const int at = nshort + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
             if (pred && at < kShortMax) surv[at] = pack_key(key, (unsigned)v);
             nshort += __popcll(bal);
           }
+        };
+#pragma unroll
+        for (int i = 0; i < kPrefetch; ++i) {
+          const int v = lp + i * PDT_WAVE;
+          if (i < nt) {
+            const float e = exp_nonpos(pre[i] - mx);
+            p[v] = e;
+            s += e;
+            const unsigned key = fkey_nonneg(e);
+            lmax = max(lmax, key);
+            survivors(key, key >= tkey, v);
+          } else if (i == nt) {
+            unsigned key = 0u;
+            if (in_row) {
+              const float e = exp_nonpos(pre[i] - mx);
+              p[v] = e;
+              s += e;
+              if (is_tok) key = fkey_nonneg(e);
+            }
+            lmax = max(lmax, key);
+            survivors(key, key >= tkey, v);
+          }
         }
         if (t + P < Tn) {
           // (lane term first: the per-element offsets are then wave-uniform scalars, not eight
           // hoisted 64-bit vector products)
-          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lp * a.lg_sv;
 #pragma unroll
           for (int i = 0; i < kPrefetch; ++i) {
-            const int v = lane + i * PDT_WAVE;
-            if (v <= V) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
+            if (i < nt) {
+              pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
+            } else if (i == nt) {
+              if (in_row) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
+            }
           }
         }
       } else {
@@ -325,7 +360,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   bm.isp = lane == 0 ? 1u : 0u;
   int Kp = 1;
 #ifdef PDT_STAMPS
-  unsigned long long pdt_stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
   for (int t = 0; t < Tn; ++t) {
     PDT_STAMP_BEGIN;
@@ -354,7 +389,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 
 #ifdef PDT_STAMPS
   if (lane == 0)
-    for (int i = 0; i < 8; ++i) atomicAdd(&g_stamps[i], pdt_stamp_acc[i]);
+    for (int i = 0; i < 14; ++i) atomicAdd(&g_stamps[i], (unsigned long long)pdt_stamp_acc[i]);
   unsigned long long stamp_last_ = __builtin_readcyclecounter();
 #endif
   // ---- outputs (:1188-1200): probabilities, lengths, and the prefixes read off the trie --
@@ -367,8 +402,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   if (lane < W) {
     int node = bm.node;
     for (int pos = bm.len - 1; pos >= 0 && node >= 0; --pos) {
-      const int tt = node / W, ii = node - tt * W;
-      const int2 *rec = a.trie + (((int64_t)tt * a.N + n) * W + ii);
+      const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
       const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       a.y[((int64_t)pos * a.N + n) * W + lane] = tok;

@@ -136,13 +136,19 @@ __device__ __forceinline__ unsigned row0_max_u32(unsigned x) {
 }
 __device__ __forceinline__ float wave_max_f(float x) { return fkey_inv(wave_max_u32(fkey(x))); }
 __device__ __forceinline__ float wave_sum_f(float x) {
+  // Written out: the compiler folds a masked DPP move into the add only for integer identities
+  // (three instructions per step otherwise).  Lanes a step leaves out keep their value; the
+  // s_nop covers the VALU-write -> DPP-read hazard the assembler does not track.
   float v = x;
-  v += dpp_or<PDT_DPP_ROW_SHR(1)>(v, 0.0f);
-  v += dpp_or<PDT_DPP_ROW_SHR(2)>(v, 0.0f);
-  v += dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(v, 0.0f);
-  v += dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(v, 0.0f);
-  v += dpp_or<PDT_DPP_ROW_BCAST15, 0xa>(v, 0.0f);
-  v += dpp_or<PDT_DPP_ROW_BCAST31, 0xc>(v, 0.0f);
+  asm volatile(
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
