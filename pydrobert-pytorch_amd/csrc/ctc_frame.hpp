@@ -41,6 +41,11 @@ struct CtcArgs {
   int64_t *y_lens;      // (N, W)
   float *y_probs;       // (N, W)
   int2 *trie;           // (N, T, W) records (parent node, token); node id = t * W + i
+  // Checkpoints for the output walk: every 2^ckpt_shift frames each beam entry records
+  // (node, length | origin << 24) -- origin = the entry of the previous checkpoint it descends
+  // from -- so the prefixes are read off the trie in parallel segments, not one 'T-hop chain.
+  int2 *ckpt;           // (N, ckpt_count, W)
+  int ckpt_shift, ckpt_count;
   int lds_per_wave, waves_per_wg;
 };
 
@@ -48,6 +53,7 @@ struct Beam {
   float nb, b;
   int last, len, node;
   unsigned isp;  // bit k' set <=> this prefix is a prefix of beam entry k' (beam width <= 32)
+  int origin = 0;  // trie form: the beam entry of the last checkpoint this prefix descends from
 };
 
 __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
@@ -58,7 +64,7 @@ __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
 __device__ __forceinline__ float readlane_f(float v, int l) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
-__device__ __forceinline__ float shfl_f(float v, int l) { return __shfl(v, l); }
+__device__ __forceinline__ float shfl_f(float v, int l) { return __int_as_float(shfl_i(__float_as_int(v), l)); }
 // a zero the compiler cannot hoist out of the frame loop (it kept hoisted zero registers live
 // across the whole loop, spilled them, and reloaded them from scratch before every LDS clear)
 __device__ __forceinline__ unsigned fresh_zero() {
@@ -283,9 +289,9 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   const int G = Kp <= 16 ? 16 : 32;
   const int kb = lane & (G - 1), rr = lane / G;
   const int ksrc = kb < Kp ? kb : 0;
-  const bool kvalid = kb < Kp && (__shfl((int)valid_beam, ksrc) != 0);
+  const bool kvalid = kb < Kp && (shfl_i((int)valid_beam, ksrc) != 0);
   const float tot_k = shfl_f(tot, ksrc);
-  const int lastc_k = __shfl(lastc, ksrc);
+  const int lastc_k = shfl_i(lastc, ksrc);
 
   // Lean tier (K' <= 16, K + K' <= 32): in 94 % of the frames of the bench input every winner
   // is a prefix's BEST available token, its last-token stream or its non-extension, so the four
@@ -297,12 +303,12 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     // A short list (c_list < M) may end before a prefix's entry 0 / 1: the row then holds an
     // UPPER BOUND of the hidden entry (the mass with the list's last probability, key + 1 so it
     // wins ties); if a bound ranks among the winners the frame needs the complete list.
-    const unsigned avk = (unsigned)__shfl((int)(unsigned)avail, ksrc);
+    const unsigned avk = (unsigned)shfl_i((int)(unsigned)avail, ksrc);
     const unsigned av = rr == 1 ? (avk & (avk - 1u)) : avk;
     const bool hidden = !full_list && rr < 2 && av == 0u;
     // (a shuffle moves the SOURCE lane's operand: fetch both streams, then pick by row)
     const float ms1 = shfl_f(m1, ksrc), ms2 = shfl_f(m2, ksrc);
-    const int open12 = __shfl((int)s1_open | ((int)s2_open << 1), ksrc);
+    const int open12 = shfl_i((int)s1_open | ((int)s2_open << 1), ksrc);
     const float ms = rr == 2 ? ms1 : ms2;
     const bool os = ((open12 >> (rr == 2 ? 0 : 1)) & 1) != 0;
     const int j = av ? __builtin_ctz(av) : (hidden ? c_list - 1 : 0);
@@ -322,9 +328,9 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     const unsigned st = wave_sort_desc<unsigned>(kt);
     PDT_STAMP(8);
     const int wl = 63 - (int)(st & 63u);
-    const unsigned wkey = (unsigned)__shfl((int)keyL, wl);
-    const int wth = __shfl(tokL | (hidden ? (int)0x80000000u : 0), wl);
-    const unsigned st_next = (unsigned)__shfl((int)st, lane + 1);
+    const unsigned wkey = (unsigned)shfl_i((int)keyL, wl);
+    const int wth = shfl_i(tokL | (hidden ? (int)0x80000000u : 0), wl);
+    const unsigned st_next = (unsigned)shfl_i((int)st, lane + 1);
     const int wtok = wth & 0x7fffffff;
     const bool isw = lane < K && wkey != 0u;
     const int rw = wl >> 4;
@@ -364,9 +370,9 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   const int G = Kp <= 16 ? 16 : 32, R = PDT_WAVE / G;
   const int kb = lane & (G - 1), rr = lane / G;
   const int ksrc = kb < Kp ? kb : 0;
-  const bool kvalid = kb < Kp && (__shfl((int)valid_beam, ksrc) != 0);
+  const bool kvalid = kb < Kp && (shfl_i((int)valid_beam, ksrc) != 0);
   const float tot_k = shfl_f(tot, ksrc);
-  const int lastc_k = __shfl(lastc, ksrc);
+  const int lastc_k = shfl_i(lastc, ksrc);
   unsigned key0 = 0u, key1 = 0u, key2 = 0u;
   int tk0 = 0, tk1 = 0, tk2 = 0;
   const int n_main = 3 * R - 2;
@@ -376,7 +382,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     const int *lt = L.tl_tok + (DENSE ? ksrc : 0) * PDT_WAVE;
     const float *lp = L.tl_p + (DENSE ? ksrc : 0) * PDT_WAVE;
     if (M <= 32) {  // the usual case (K + K' <= 32): half the work per bit operation
-      unsigned av = (unsigned)__shfl((int)(unsigned)avail, ksrc);
+      unsigned av = (unsigned)shfl_i((int)(unsigned)avail, ksrc);
       for (int i = 0; i < rr; ++i) av &= av - 1u;
 #pragma unroll
       for (int sl = 0; sl < 3; ++sl) {
@@ -421,7 +427,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     fill_main(true);
     // stream 1 / stream 2 live in slot 2 of rows R-2 / R-1
     const float m1_k = shfl_f(m1, ksrc), m2_k = shfl_f(m2, ksrc);
-    const bool o1 = __shfl((int)s1_open, ksrc) != 0, o2 = __shfl((int)s2_open, ksrc) != 0;
+    const bool o1 = shfl_i((int)s1_open, ksrc) != 0, o2 = shfl_i((int)s2_open, ksrc) != 0;
     if (rr == R - 2) { key2 = (kvalid && o1) ? fkey_nonneg(m1_k) : 0u; tk2 = lastc_k; }
     if (rr == R - 1) { key2 = (kvalid && o2) ? fkey_nonneg(m2_k) : 0u; tk2 = lastc_k; }
   }
@@ -471,7 +477,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       const int wl = id >> 2, sw = id & 3;
       const int e = (wl / G) + R * sw;
       if (__ballot(isw && e == n_main - 1) == 0ull) {
-        const int t0 = __shfl(tk0, wl), t1 = __shfl(tk1, wl), t2 = __shfl(tk2, wl);
+        const int t0 = shfl_i(tk0, wl), t1 = shfl_i(tk1, wl), t2 = shfl_i(tk2, wl);
         if (isw) {
           new_src = wl & (G - 1);
           new_tok = sw == 0 ? t0 : (sw == 1 ? t1 : t2);
@@ -517,8 +523,8 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // ---- new beam state of lane i (:868-880) ---------------------------------------------
   const int srcl = new_kind >= 0 ? new_src : lane;
   const float NB_s = shfl_f(NB, srcl), B_s = shfl_f(B, srcl);
-  const int last_s = __shfl(lastc, srcl), len_s = __shfl(bm.len, srcl), node_s = __shfl(bm.node, srcl);
-  const unsigned isp_s = (unsigned)__shfl((int)bm.isp, srcl);
+  const int last_s = shfl_i(lastc, srcl), len_s = shfl_i(bm.len, srcl), node_s = shfl_i(bm.node, srcl);
+  const unsigned isp_s = (unsigned)shfl_i((int)bm.isp, srcl);
   const bool is_ext = new_kind == 0 || new_kind == 1;
   const bool is_valid = new_kind >= 0;
   Beam nw;
@@ -527,6 +533,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   nw.last = !is_valid ? 0 : (is_ext ? new_tok : last_s);
   nw.len = !is_valid ? 0 : len_s + (is_ext ? 1 : 0);
   nw.node = !is_valid ? -1 : (is_ext ? t * W + lane : node_s);
+  if (!DENSE) nw.origin = shfl_i(bm.origin, srcl);
   if (!DENSE && is_valid && is_ext)
     a.trie[((int64_t)n * a.T + t) * W + lane] = make_int2(node_s, new_tok);
 

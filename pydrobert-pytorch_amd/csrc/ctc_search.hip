@@ -85,7 +85,9 @@ __global__ void __launch_bounds__(256, P == 1 ? 8 : 4) __attribute__((amdgpu_num
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
+  // (wave-uniform by construction; telling the compiler keeps the utterance index and every
+  // address derived from it in scalar registers)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int u = wave / (P + 1);
   const int role = wave - u * (P + 1);  // 0 .. P-1: producer, P: consumer
   const bool producer = role < P;
@@ -358,6 +360,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   bm.len = 0;
   bm.node = -1;
   bm.isp = lane == 0 ? 1u : 0u;
+  bm.origin = lane;
   int Kp = 1;
 #ifdef PDT_STAMPS
   unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
@@ -385,6 +388,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     L.nxt_new = tmp;
     Kp = W;
     if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
+      const int c = ((t + 1) >> a.ckpt_shift) - 1;
+      if (lane < W)
+        a.ckpt[((int64_t)n * a.ckpt_count + c) * W + lane] = make_int2(bm.node, bm.len | (bm.origin << 24));
+      bm.origin = lane;
+    }
   }
 
 #ifdef PDT_STAMPS
@@ -399,16 +408,43 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   // rows beyond a prefix's length stay 0: the caller hands in a zero-filled y
-  if (lane < W) {
-    int node = bm.node;
-    for (int pos = bm.len - 1; pos >= 0 && node >= 0; --pos) {
-      const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
-      const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a.y[((int64_t)pos * a.N + n) * W + lane] = tok;
-      node = par;
+#ifndef PDT_SKIP_WALK  // diagnostic build: cost of the output walk
+  {
+    // One chain of bm.len dependent loads per prefix would be ~T global-memory latencies with
+    // nothing to overlap (every utterance of the launch ends at about the same time).  Instead:
+    // (1) each prefix follows its `origin` links back through the C checkpoints -- C hops --
+    // leaving (node, length) of its ancestor at every checkpoint in LDS (the ring is free now);
+    // (2) the (C + 1) x W segments between consecutive checkpoints are walked by all 64 lanes.
+    const int C = Tn >> a.ckpt_shift;
+    int2 *tab = reinterpret_cast<int2 *>(ring);  // [(C + 1) x W]: fits, see launch_ctc_search
+    if (lane < W) {
+      const bool ok = bm.node >= 0;
+      tab[C * W + lane] = make_int2(bm.node, bm.len);
+      int cur = bm.origin;
+      for (int c = C - 1; c >= 0; --c) {
+        const int2 *rec = a.ckpt + (((int64_t)n * a.ckpt_count + c) * W + cur);
+        const int nd = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lo = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tab[c * W + lane] = ok ? make_int2(nd, lo & 0xFFFFFF) : make_int2(-1, 0);
+        cur = lo >> 24;
+      }
+    }
+    wave_sync();
+    for (int sg = lane; sg < (C + 1) * W; sg += PDT_WAVE) {
+      const int c = sg / W, k = sg - c * W;
+      const int2 top = tab[sg];
+      const int stop = c > 0 ? tab[sg - W].y : 0;
+      int node = top.x;
+      for (int pos = top.y - 1; pos >= stop && node >= 0; --pos) {
+        const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
+        const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.y[((int64_t)pos * a.N + n) * W + k] = tok;
+        node = par;
+      }
     }
   }
+#endif
 #ifdef PDT_STAMPS
   if (lane == 0) atomicAdd(&g_stamps[6], __builtin_readcyclecounter() - stamp_last_);
 #endif
@@ -426,6 +462,15 @@ static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream
   hipLaunchKernelGGL(ctc_search_kernel<P>, dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
                      stream, a, rl);
   return (int)hipGetLastError();
+}
+
+// checkpoint spacing: 32 frames, doubled until the (C + 1) x W table of the output walk fits in
+// the smallest ring any launch configuration uses (2 slots)
+__host__ inline int ckpt_shift_for(int T, int V, int W) {
+  const size_t ring2 = (size_t)ring_layout(V, W, 2, 1, 1).slot_bytes * 2;
+  int sh = 5;
+  while (((size_t)(T >> sh) + 1) * W * sizeof(int2) > ring2) ++sh;
+  return sh;
 }
 
 int launch_ctc_search(CtcArgs a, hipStream_t stream) {
@@ -457,7 +502,8 @@ extern "C" {
 
 int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t width) {
   if (T < 0 || N < 0 || width < 0) return 0;
-  return T * N * width * (int64_t)sizeof(int2) + 16;
+  // trie records + checkpoints (at most one per 32 frames)
+  return (T + T / 32 + 1) * N * width * (int64_t)sizeof(int2) + 16;
 }
 
 int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st,
@@ -469,13 +515,16 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   if (N == 0) return PDT_OK;
   if (!y_lens || !y_probs || (T > 0 && (!logits || !workspace)) || (S > 0 && !y)) return PDT_E_ARG;
   if (width > kMaxWidth) return PDT_E_TOO_LONG;
-  if (T * width >= (1ll << 31) || V >= (1 << 30) || N >= (1ll << 31)) return PDT_E_TOO_LONG;
+  if (T * width >= (1ll << 31) || V >= (1 << 30) || N >= (1ll << 31) || T >= (1 << 24)) return PDT_E_TOO_LONG;
   CtcArgs a{};
   a.logits = logits; a.lg_st = lg_st; a.lg_sn = lg_sn; a.lg_sv = lg_sv;
   a.lens = lens;
   a.T = (int)T; a.N = (int)N; a.V = (int)V; a.W = (int)width; a.S = (int)S;
   a.y = y; a.y_lens = y_lens; a.y_probs = y_probs;
   a.trie = reinterpret_cast<int2 *>(workspace);
+  a.ckpt = a.trie + T * N * width;
+  a.ckpt_shift = pdt::ckpt_shift_for((int)T, (int)V, (int)width);
+  a.ckpt_count = (int)(T >> a.ckpt_shift) + 1;
   return launch_ctc_search(a, (hipStream_t)stream);
 }
 

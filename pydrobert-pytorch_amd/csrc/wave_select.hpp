@@ -28,9 +28,12 @@ __device__ __forceinline__ u64 pack_key(unsigned key, unsigned idx) {
 __device__ __forceinline__ unsigned key_of(u64 k) { return (unsigned)(k >> 32); }
 __device__ __forceinline__ unsigned idx_of(u64 k) { return 0xffffffffu - (unsigned)k; }
 
+// value of lane `src` (0..63; taken mod 64): the bare LDS-crossbar permute.  HIP's __shfl adds
+// two VALU instructions of width arithmetic that a 64-wide wave does not need.
+__device__ __forceinline__ int shfl_i(int v, int src) { return __builtin_amdgcn_ds_bpermute(src << 2, v); }
 __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
-  const unsigned lo = (unsigned)__shfl((int)(unsigned)v, src);
-  const unsigned hi = (unsigned)__shfl((int)(unsigned)(v >> 32), src);
+  const unsigned lo = (unsigned)shfl_i((int)(unsigned)v, src);
+  const unsigned hi = (unsigned)shfl_i((int)(unsigned)(v >> 32), src);
   return ((u64)hi << 32) | lo;
 }
 
