@@ -140,8 +140,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     constexpr int kShortMin = 8, kShortMax = 32, kShortLo = 14, kShortHi = 26, kProbeRank = 18;
     const bool short_ok = P == 1 && W <= 16 && V > PDT_WAVE;
     float thr_off = PDT_INF;  // no guess yet
-    const int nt = V / PDT_WAVE, rem = V - nt * PDT_WAVE;  // full token chunks; lane of the blank
-    const float inv_ntok = 1.0f / (float)(nt > 0 ? nt * PDT_WAVE : 1);
+    const int nt_ = V / PDT_WAVE, rem_ = V - nt_ * PDT_WAVE;  // full token chunks; lane of the blank
+    const float inv_ntok = 1.0f / (float)(nt_ > 0 ? nt_ * PDT_WAVE : 1);
     if (pr < Tn) {
       const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
 #pragma unroll
@@ -150,8 +150,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         pre[i] = v <= V ? row0[(int64_t)(i * PDT_WAVE) * a.lg_sv] : 0.0f;
       }
     }
-    for (int t = pr; t < Tn; t += P) {
-      const int sl = t % NS;
+    int sl = pr % NS;  // t % NS, kept by add / compare: no division in the loop
+    for (int t = pr; t < Tn; t += P, sl = sl + P >= NS ? sl + P - NS : sl + P) {
       // wait for the slot to be free: at most NS frames in flight
       while (t - __hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
         __builtin_amdgcn_s_sleep(2);
@@ -175,8 +175,10 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         // and ordering keys come straight from them -- one LDS store per element instead of
         // store + load + store + load.  Chunks i < nt hold tokens in every lane (wave-uniform
         // branches, no lane masks); chunk nt ends with the blank in lane `rem`.
-        int lp = lane;
-        asm volatile("" : "+v"(lp));  // the two masks of chunk nt are recomputed, not hoisted
+        // (laundered: chunk predicates and the two masks of chunk nt are recomputed by a scalar
+        // compare where used, not hoisted out of the frame loop into scalar registers that spill)
+        int lp = lane, nt = nt_, rem = rem_;
+        asm volatile("" : "+v"(lp), "+s"(nt), "+s"(rem));
         const bool in_row = lp <= rem, is_tok = lp < rem;
         float mx = -PDT_INF, sx = 0.0f;
 #pragma unroll
@@ -365,9 +367,9 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #ifdef PDT_STAMPS
   unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
-  for (int t = 0; t < Tn; ++t) {
+  int sl = 0;  // t % NS
+  for (int t = 0; t < Tn; ++t, sl = sl + 1 == NS ? 0 : sl + 1) {
     PDT_STAMP_BEGIN;
-    const int sl = t % NS;
     while (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t)
       __builtin_amdgcn_s_sleep(2);
     PDT_STAMP(0);

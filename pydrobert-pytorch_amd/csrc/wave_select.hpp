@@ -71,10 +71,22 @@ constexpr u64 bitonic_keep_max_mask(int k, int j) {
   return m;
 }
 
+// The mask as a lane predicate.  Materialised where it is used by two s_mov_b32 the compiler
+// may not hoist: left to itself it hoists all 21 stage masks (42 scalar registers) out of the
+// frame loops, runs out of scalar registers, and pays for the spills with v_readlane /
+// v_writelane in a VALU-bound kernel.  The scalar unit has the slack for the moves.
+template <u64 MASK>
+__device__ __forceinline__ bool lane_predicate() {
+  unsigned lo, hi;
+  asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((unsigned)MASK));
+  asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((unsigned)(MASK >> 32)));
+  return __builtin_amdgcn_inverse_ballot_w64(((u64)hi << 32) | lo);
+}
+
 template <int K, int J, typename T>
 __device__ __forceinline__ T bitonic_stage(T key) {
   const T other = xor_shfl<J>(key);
-  const bool keep_max = __builtin_amdgcn_inverse_ballot_w64(bitonic_keep_max_mask(K, J));
+  const bool keep_max = lane_predicate<bitonic_keep_max_mask(K, J)>();
   return ((key > other) == keep_max) ? key : other;
 }
 template <int K, int J, typename T>
