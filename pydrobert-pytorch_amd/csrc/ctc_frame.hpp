@@ -287,7 +287,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // a wave max + clearing the winning slot; only when a prefix uses up ALL its resident
   // stream-0 entries are its slots refilled with the next 3R-2.
   const int G = Kp <= 16 ? 16 : 32;
-  const int kb = lane & (G - 1), rr = lane / G;
+  const int kb = lane & (G - 1), rr = lane >> (G == 16 ? 4 : 5);  // (a shift, not a division by a runtime G)
   const int ksrc = kb < Kp ? kb : 0;
   const bool kvalid = kb < Kp && (shfl_i((int)valid_beam, ksrc) != 0);
   const float tot_k = shfl_f(tot, ksrc);
@@ -367,8 +367,8 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   // A prefix's resident entries are consumed in order (they are sorted), so a round is just
   // a wave max + clearing the winning slot; only when a prefix uses up ALL its resident
   // stream-0 entries are its slots refilled with the next 3R-2.
-  const int G = Kp <= 16 ? 16 : 32, R = PDT_WAVE / G;
-  const int kb = lane & (G - 1), rr = lane / G;
+  const int G = Kp <= 16 ? 16 : 32, GS = Kp <= 16 ? 4 : 5, R = PDT_WAVE >> GS;
+  const int kb = lane & (G - 1), rr = lane >> (G == 16 ? 4 : 5);  // (a shift, not a division by a runtime G)
   const int ksrc = kb < Kp ? kb : 0;
   const bool kvalid = kb < Kp && (shfl_i((int)valid_beam, ksrc) != 0);
   const float tot_k = shfl_f(tot, ksrc);
@@ -475,7 +475,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
       const bool isw = lane < K && wkey != 0u;
       const int id = isw ? (int)idx_of(s) : 0;
       const int wl = id >> 2, sw = id & 3;
-      const int e = (wl / G) + R * sw;
+      const int e = (wl >> GS) + R * sw;
       if (__ballot(isw && e == n_main - 1) == 0ull) {
         const int t0 = shfl_i(tk0, wl), t1 = shfl_i(tk1, wl), t2 = shfl_i(tk2, wl);
         if (isw) {
@@ -499,7 +499,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     const int sw = __builtin_amdgcn_readlane(sw_l, win);
     const int wtok = __builtin_amdgcn_readlane(tw_l, win);
     const int wbeam = win & (G - 1);
-    const int e = (win / G) + R * sw;
+    const int e = (win >> GS) + R * sw;
     const int wkind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
     const bool rec = lane == i;
     new_src = rec ? wbeam : new_src;

@@ -100,6 +100,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
   const int pr = (P == 1 || !producer) ? 0 : role;                   // producer index
   u64 *surv = surv0 + pr * PDT_SURV_CAP;                             // one scratch per producer
+  unsigned *surv32 = reinterpret_cast<unsigned *>(surv);             // (short lists: 32-bit sort keys)
   int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
   int *ready = consumed + 1;                                          // [nstage] frame + 1 held by a slot
   auto slot_row = [&](int sl) { return reinterpret_cast<float *>(ring + (size_t)sl * rl.slot_bytes); };
@@ -196,13 +197,17 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
           mean = wave_sum_f(sx) * inv_ntok;  // over the tokens of the full chunks
           // survivors: numerator >= the numerator of the guessed threshold (same exp routine, so
           // the set is an upper set of the list order)
-          if (t > 0 && thr_off < PDT_INF) tkey = fkey_nonneg(exp_nonpos(fminf(mean + thr_off - mx, 0.0f)));
+          // (any threshold value gives an exact top-c list: v_exp_f32 accuracy is plenty)
+          if (t > 0 && thr_off < PDT_INF)
+            tkey = fkey_nonneg(__builtin_amdgcn_exp2f(fminf(mean + thr_off - mx, 0.0f) * 0x1.715476p+0f));
         }
         auto survivors = [&](const unsigned key, const bool pred, const int v) {
           const u64 bal = __ballot(pred);
           if (bal) {
             const int at = nshort + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-            if (pred && at < kShortMax) surv[at] = pack_key(key, (unsigned)v);
+            // 32-bit sort key: the value key rounded up to a multiple of 512, token (inverted:
+            // lowest first) in the freed bits; V <= 511 here
+            if (pred && at < kShortMax) surv32[at] = ((key + 511u) & ~511u) | (511u - (unsigned)v);
             nshort += __popcll(bal);
           }
         };
@@ -308,16 +313,27 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       s = wave_sum_f(s);
       wave_sync();
       const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
-      const float inv = __fdiv_rn(1.0f, s);  // the only division of the frame
+      // reciprocal of the normaliser: v_rcp_f32 + one Newton step (within 1 ulp of the quotient;
+      // the IEEE division sequence is 12 VALU instructions)
+      const float inv0 = __builtin_amdgcn_rcpf(s);
+      const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
       int Ml = M;
       if (short_ok && nshort >= kShortMin && nshort <= kShortMax) {
         PDT_STAT(1);
-        const u64 tk = half_wave_sort_desc<u64>(lane < nshort ? surv[lane] : 0ull);
+        // one 32-key sort of 32-bit keys; exact unless two survivors agree in the upper 23 bits
+        // (then the (value, token) pairs are sorted instead)
+        unsigned st = half_wave_sort_desc<unsigned>(lane < nshort ? surv32[lane] : 0u);
+        const unsigned st_next = (unsigned)__builtin_amdgcn_mov_dpp((int)st, 0x130, 0xf, 0xf, true);  // wave_shl:1
+        int tok = 511 - (int)(st & 511u);
+        if (__ballot(lane + 1 < nshort && (st >> 9) == (st_next >> 9)) != 0ull) {
+          const int tk0 = 511 - (int)((lane < nshort ? surv32[lane] : 0u) & 511u);
+          const u64 tk = half_wave_sort_desc<u64>(lane < nshort ? pack_key(fkey_nonneg(p[tk0]), (unsigned)tk0) : 0ull);
+          tok = (int)idx_of(tk);
+        }
         Ml = min(nshort, M);
         if (lane < Ml) {
-          const int tok = (int)idx_of(tk);
           tl_tok[lane] = tok;
-          slot_p(sl)[lane] = fkey_nonneg_inv(key_of(tk)) * inv;
+          slot_p(sl)[lane] = p[tok] * inv;
           pos[tok] = (unsigned char)lane;
         }
         const float step = fmaxf(fabsf(thr_off) * 0.03125f, 1e-3f);

@@ -45,12 +45,14 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 // crossbar instead lengthens the dependency chain too much (4.23 ms).
 template <int J>
 __device__ __forceinline__ unsigned xor_shfl(unsigned v) {
+  // (mov_dpp: every lane has a source, so no "old" value -- update_dpp(v, v, ...) costs a
+  // register copy per stage)
   if constexpr (J == 1) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xf, 0xf, false);
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
   } else if constexpr (J == 2) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xf, 0xf, false);
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
   } else if constexpr (J == 8) {
-    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
   } else {
     static_assert(J == 4 || J == 16 || J == 32, "xor_shfl: J must be a power of two <= 32");
     return (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ J) << 2), (int)v);
@@ -149,7 +151,20 @@ __device__ __forceinline__ unsigned row0_max_u32(unsigned x) {
   v = max(v, (unsigned)dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>((int)v, 0));
   return (unsigned)__builtin_amdgcn_readlane((int)v, 15);
 }
-__device__ __forceinline__ float wave_max_f(float x) { return fkey_inv(wave_max_u32(fkey(x))); }
+// maximum over the wave of floats that are not NaN (same written-out DPP chain as wave_sum_f)
+__device__ __forceinline__ float wave_max_f(float x) {
+  float v = x;
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 __device__ __forceinline__ float wave_sum_f(float x) {
   // Written out: the compiler folds a masked DPP move into the add only for integer identities
   // (three instructions per step otherwise).  Lanes a step leaves out keep their value; the
