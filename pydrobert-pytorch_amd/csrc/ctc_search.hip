@@ -184,6 +184,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         float mx = -PDT_INF, sx = 0.0f;
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i) {
+          if (i > nt) break;  // (one scalar compare + branch; the chunks beyond are not visited)
           if (i < nt) {
             mx = fmax_raw(mx, pre[i]);
             sx += pre[i];
@@ -214,6 +215,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #pragma unroll
         for (int i = 0; i < kPrefetch; ++i) {
           const int v = lp + i * PDT_WAVE;
+          if (i > nt) break;
           if (i < nt) {
             const float e = exp_nonpos(pre[i] - mx);
             p[v] = e;
@@ -239,6 +241,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
           const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lp * a.lg_sv;
 #pragma unroll
           for (int i = 0; i < kPrefetch; ++i) {
+            if (i > nt) break;
             if (i < nt) {
               pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
             } else if (i == nt) {
