@@ -37,46 +37,51 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 
-// value of lane (lane ^ J), J a power of two.  One DPP move where one exists (quad_perm for
-// J = 1, 2; row_ror:8 for J = 8).  J = 4 would take two bank-masked row shifts and J = 16 / 32
-// a v_permlane*_swap plus a select: the kernels that sort are VALU-issue-bound while their LDS
-// pipe is nearly idle, so those three go through the LDS crossbar (ds_bpermute: no LDS memory
-// is touched) -- measured 3.88 -> 3.80 ms on the CTC search; routing EVERY stage through the
-// crossbar instead lengthens the dependency chain too much (4.23 ms).
-template <int J>
+// value of lane (lane ^ X).  One DPP move where one exists: quad_perm for X = 1, 2, 3,
+// row_half_mirror / row_mirror for X = 7 / 15, row_ror:8 for X = 8.  The others (4, 16, 31, 32,
+// 63) would take two or three VALU instructions each; the kernels that sort are VALU-issue-bound
+// while their LDS pipe is nearly idle, so those go through the LDS crossbar (ds_bpermute: no LDS
+// memory is touched) -- measured 3.88 -> 3.80 ms on the CTC search; routing EVERY stage through
+// the crossbar instead lengthens the dependency chain too much (4.23 ms).
+// (mov_dpp: every lane has a source, so there is no "old" value to copy.)
+template <int X>
+constexpr bool xor_is_dpp() { return X == 1 || X == 2 || X == 3 || X == 7 || X == 8 || X == 15; }
+template <int X>
 __device__ __forceinline__ unsigned xor_shfl(unsigned v) {
-  // (mov_dpp: every lane has a source, so no "old" value -- update_dpp(v, v, ...) costs a
-  // register copy per stage)
-  if constexpr (J == 1) {
-    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);
-  } else if constexpr (J == 2) {
-    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);
-  } else if constexpr (J == 8) {
+  if constexpr (X == 1) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+  } else if constexpr (X == 2) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+  } else if constexpr (X == 3) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x1B, 0xf, 0xf, true);   // quad_perm [3,2,1,0]
+  } else if constexpr (X == 7) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x141, 0xf, 0xf, true);  // row_half_mirror
+  } else if constexpr (X == 15) {
+    return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x140, 0xf, 0xf, true);  // row_mirror
+  } else if constexpr (X == 8) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
   } else {
-    static_assert(J == 4 || J == 16 || J == 32, "xor_shfl: J must be a power of two <= 32");
-    return (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ J) << 2), (int)v);
+    static_assert(X == 4 || X == 16 || X == 31 || X == 32 || X == 63, "xor_shfl: unsupported pattern");
+    return (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ X) << 2), (int)v);
   }
 }
-template <int J>
+template <int X>
 __device__ __forceinline__ u64 xor_shfl(u64 v) {
-  return ((u64)xor_shfl<J>((unsigned)(v >> 32)) << 32) | xor_shfl<J>((unsigned)v);
+  return ((u64)xor_shfl<X>((unsigned)(v >> 32)) << 32) | xor_shfl<X>((unsigned)v);
 }
 
-// lanes that keep the LARGER key at bitonic stage (k, j) of a descending sort
-constexpr u64 bitonic_keep_max_mask(int k, int j) {
+// lanes whose index has bit B clear: the lower lane of every pair (l, l ^ X) when B is the top
+// set bit of X
+constexpr u64 lanes_with_bit_clear(int B) {
   u64 m = 0;
-  for (int l = 0; l < 64; ++l) {
-    const bool up = (k == 64) || ((l & k) == 0);
-    if (((l & j) == 0) == up) m |= 1ull << l;
-  }
+  for (int l = 0; l < 64; ++l)
+    if ((l & B) == 0) m |= 1ull << l;
   return m;
 }
 
-// The mask as a lane predicate.  Materialised where it is used by two s_mov_b32 the compiler
-// may not hoist: left to itself it hoists all 21 stage masks (42 scalar registers) out of the
-// frame loops, runs out of scalar registers, and pays for the spills with v_readlane /
-// v_writelane in a VALU-bound kernel.  The scalar unit has the slack for the moves.
+// The mask as a lane predicate, materialised where it is used by two s_mov_b32 the compiler
+// may not hoist (hoisted masks filled the scalar registers of the frame loops, and their spills
+// are v_readlane / v_writelane in a VALU-bound kernel).
 template <u64 MASK>
 __device__ __forceinline__ bool lane_predicate() {
   unsigned lo, hi;
@@ -85,41 +90,58 @@ __device__ __forceinline__ bool lane_predicate() {
   return __builtin_amdgcn_inverse_ballot_w64(((u64)hi << 32) | lo);
 }
 
-template <int K, int J, typename T>
-__device__ __forceinline__ T bitonic_stage(T key) {
-  const T other = xor_shfl<J>(key);
-  const bool keep_max = lane_predicate<bitonic_keep_max_mask(K, J)>();
-  return ((key > other) == keep_max) ? key : other;
+// One compare-exchange stage of a DESCENDING sort: partners (l, l ^ X), the lower lane keeps the
+// larger key.  B = top set bit of X.
+template <int X, int B, typename T>
+__device__ __forceinline__ T cmpx_stage(T key) {
+  const T other = xor_shfl<X>(key);
+  const bool lower = lane_predicate<lanes_with_bit_clear(B)>();
+  if constexpr (sizeof(T) == 4 && xor_is_dpp<X>()) {
+    // max / min fold the DPP move into themselves: 3 VALU, no scalar work
+    return lower ? max(key, other) : min(key, other);
+  } else {
+    return ((key > other) == lower) ? key : other;
+  }
 }
-template <int K, int J, typename T>
+// half-cleaners of a bitonic sequence of 2 * J lanes: l ^ J, l ^ J/2, ..., l ^ 1
+template <int J, typename T>
 __device__ __forceinline__ T bitonic_merge(T key) {
-  key = bitonic_stage<K, J>(key);
-  if constexpr (J > 1) key = bitonic_merge<K, J / 2>(key);
+  key = cmpx_stage<J, J>(key);
+  if constexpr (J > 1) key = bitonic_merge<J / 2>(key);
+  return key;
+}
+// sorts every aligned group of S lanes, given sorted groups of S / 2: a "flip" (l ^ (S - 1):
+// both halves descending become one bitonic exchange) and the half-cleaners below it.  All
+// groups come out descending, so the lane predicates are the six single-bit masks.
+template <int S, typename T>
+__device__ __forceinline__ T sort_groups(T key) {
+  key = cmpx_stage<S - 1, S / 2>(key);
+  if constexpr (S > 2) key = bitonic_merge<S / 4>(key);
   return key;
 }
 
 // bitonic sort of one key per lane, DESCENDING (lane 0 ends with the maximum); 21
-// compare-exchange stages of ~5 (u64) / ~3 (u32) VALU instructions
+// compare-exchange stages, 6 of them through the LDS crossbar
 template <typename T>
 __device__ __forceinline__ T wave_sort_desc(T key) {
-  key = bitonic_merge<2, 1>(key);
-  key = bitonic_merge<4, 2>(key);
-  key = bitonic_merge<8, 4>(key);
-  key = bitonic_merge<16, 8>(key);
-  key = bitonic_merge<32, 16>(key);
-  key = bitonic_merge<64, 32>(key);
+  key = sort_groups<2>(key);
+  key = sort_groups<4>(key);
+  key = sort_groups<8>(key);
+  key = sort_groups<16>(key);
+  key = sort_groups<32>(key);
+  key = sort_groups<64>(key);
   return key;
 }
 
-// the same network stopped after 15 stages: lanes 0..31 hold THEIR 32 keys sorted descending
-// (lanes 32..63 theirs ascending)
+// the same network stopped after 15 stages: each half of the wave holds ITS 32 keys sorted
+// descending
 template <typename T>
 __device__ __forceinline__ T half_wave_sort_desc(T key) {
-  key = bitonic_merge<2, 1>(key);
-  key = bitonic_merge<4, 2>(key);
-  key = bitonic_merge<8, 4>(key);
-  key = bitonic_merge<16, 8>(key);
-  key = bitonic_merge<32, 16>(key);
+  key = sort_groups<2>(key);
+  key = sort_groups<4>(key);
+  key = sort_groups<8>(key);
+  key = sort_groups<16>(key);
+  key = sort_groups<32>(key);
   return key;
 }
 
@@ -129,7 +151,7 @@ __device__ __forceinline__ u64 wave_merge_top64(u64 cur, u64 add) {
   add = wave_sort_desc<u64>(add);
   const u64 rev = shfl_u64(add, PDT_WAVE - 1 - lane);
   const u64 key = cur > rev ? cur : rev;  // bitonic
-  return bitonic_merge<64, 32>(key);
+  return bitonic_merge<32>(key);
 }
 
 __device__ __forceinline__ unsigned wave_max_u32(unsigned x) {
