@@ -84,10 +84,7 @@ constexpr u64 lanes_with_bit_clear(int B) {
 // are v_readlane / v_writelane in a VALU-bound kernel).
 template <u64 MASK>
 __device__ __forceinline__ bool lane_predicate() {
-  unsigned lo, hi;
-  asm volatile("s_mov_b32 %0, %1" : "=s"(lo) : "n"((unsigned)MASK));
-  asm volatile("s_mov_b32 %0, %1" : "=s"(hi) : "n"((unsigned)(MASK >> 32)));
-  return __builtin_amdgcn_inverse_ballot_w64(((u64)hi << 32) | lo);
+  return __builtin_amdgcn_inverse_ballot_w64(MASK);
 }
 
 // One compare-exchange stage of a DESCENDING sort: partners (l, l ^ X), the lower lane keeps the
