@@ -37,16 +37,22 @@ __device__ __forceinline__ int dpp_or(int v, int ident) {
   return __builtin_amdgcn_update_dpp(ident, v, CTRL, ROW_MASK, BANK_MASK, false);
 }
 
-// inclusive wave-wide min scan (7 DPP steps, identity +inf)
+// inclusive wave-wide min scan of floats that are not NaN: six v_min_f32_dpp.  Written out --
+// left to the compiler every step is a move of the identity, a DPP move, a canonicalising
+// v_max and the v_min (the row loops that scan once per DP row are VALU-bound).  A lane a step
+// does not reach (no source lane, or masked out) keeps its value; the s_nop covers the
+// VALU-write -> DPP-read hazard the assembler does not track.
 __device__ __forceinline__ float wave_incl_scan_min(float x) {
   float v = x;
-  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(1)>(x, PDT_INF));
-  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(2)>(x, PDT_INF));
-  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(3)>(x, PDT_INF));
-  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(v, PDT_INF));
-  v = fminf(v, dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(v, PDT_INF));
-  v = fminf(v, dpp_or<PDT_DPP_ROW_BCAST15, 0xa>(v, PDT_INF));
-  v = fminf(v, dpp_or<PDT_DPP_ROW_BCAST31, 0xc>(v, PDT_INF));
+  asm volatile(
+      "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
   return v;
 }
 
