@@ -122,7 +122,8 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *          prefix's length are left untouched (the reference leaves them undefined);
  *   y_lens (N, width) int64, y_probs (N, width) float32 (probabilities, not logs).
  *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, width) bytes of scratch
- *          (the prefix trie: one (parent, token) record per frame and beam entry).
+ *          (the prefix trie: one (parent, token) record per frame and beam entry, and the
+ *          checkpoints of the output walk).
  *   width <= 32.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t width);
