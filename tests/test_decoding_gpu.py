@@ -88,6 +88,21 @@ def test_ctc_prefix_search_long(device):
         _check_search(act, exp, ("long", T, V, K))
 
 
+def test_ctc_prefix_search_many_checkpoints(device):
+    """Long utterances: the output walk goes through many checkpoints, and with a small ring
+    (small V) the checkpoint spacing doubles until the table fits; ragged lengths end between
+    checkpoints.  Very peaky frames keep the float32 masses away from 0."""
+    rng = np.random.default_rng(77)
+    for T, V, K, N in [(1200, 4, 6, 4), (700, 30, 16, 3), (333, 2, 3, 5)]:
+        lg = _peaky_logits(rng, T, N, V, scale=14.0)
+        lens = rng.integers(T // 3, T + 1, N)
+        lens[0] = T
+        exp = oracle.ctc_prefix_search(lg, K, lens)
+        assert exp[2][:, 0].min() > 0.0
+        act = F.ctc_prefix_search(torch.from_numpy(lg).to(device), K, torch.from_numpy(lens).to(device))
+        _check_search(act, exp, ("checkpoints", T, V, K))
+
+
 def test_ctc_wide_beam(device):
     """width > V + 1: the kernel treats padded entries as absent (documented superset of the
     reference, which degenerates to NaN).  Checks: no NaN, valid prefixes are distinct, their
