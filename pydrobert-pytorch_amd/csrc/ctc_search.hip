@@ -47,6 +47,19 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
   return r;
 }
 
+// two at a time: the multiplies / fmas / adds of the range reduction as packed fp32 (one
+// instruction for both); identical arithmetic per element, so identical results
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x) {
+  const f32x2 L = {0x1.715476p+0f, 0x1.715476p+0f}, L2 = {0x1.4ae0bep-26f, 0x1.4ae0bep-26f};
+  const f32x2 t = x * L;
+  const f32x2 lo = __builtin_elementwise_fma(x, L, -t);
+  const f32x2 n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  const f32x2 f = (t - n) + __builtin_elementwise_fma(x, L2, lo);
+  return f32x2{__builtin_ldexpf(__builtin_amdgcn_exp2f(f.x), (int)n.x),
+               __builtin_ldexpf(__builtin_amdgcn_exp2f(f.y), (int)n.y)};
+}
+
 // LDS ring slot shared by the producer and consumer waves of one utterance.
 struct RingLayout {
   int row_floats;   // V + 1 padded to 4
@@ -212,27 +225,40 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
             nshort += __popcll(bal);
           }
         };
-#pragma unroll
-        for (int i = 0; i < kPrefetch; ++i) {
+        auto token_chunk = [&](const int i, const float e) {
           const int v = lp + i * PDT_WAVE;
+          p[v] = e;
+          s += e;
+          const unsigned key = fkey_nonneg(e);
+          lmax = max(lmax, key);
+          survivors(key, key >= tkey, v);
+        };
+#pragma unroll
+        for (int i = 0; i < kPrefetch; i += 2) {
           if (i > nt) break;
-          if (i < nt) {
-            const float e = exp_nonpos(pre[i] - mx);
-            p[v] = e;
-            s += e;
-            const unsigned key = fkey_nonneg(e);
-            lmax = max(lmax, key);
-            survivors(key, key >= tkey, v);
-          } else if (i == nt) {
-            unsigned key = 0u;
-            if (in_row) {
-              const float e = exp_nonpos(pre[i] - mx);
-              p[v] = e;
-              s += e;
-              if (is_tok) key = fkey_nonneg(e);
+          if (i + 1 < nt) {
+            // two full chunks: the range reduction in packed fp32 (v_pk_mul / fma / add)
+            const f32x2 e2 = exp_nonpos2(f32x2{pre[i], pre[i + 1]} - f32x2{mx, mx});
+            token_chunk(i, e2.x);
+            token_chunk(i + 1, e2.y);
+            continue;
+          }
+#pragma unroll
+          for (int j = i; j < i + 2; ++j) {
+            if (j < nt) {
+              token_chunk(j, exp_nonpos(pre[j] - mx));
+            } else if (j == nt) {
+              const int v = lp + j * PDT_WAVE;
+              unsigned key = 0u;
+              if (in_row) {
+                const float e = exp_nonpos(pre[j] - mx);
+                p[v] = e;
+                s += e;
+                if (is_tok) key = fkey_nonneg(e);
+              }
+              lmax = max(lmax, key);
+              survivors(key, key >= tkey, v);
             }
-            lmax = max(lmax, key);
-            survivors(key, key >= tkey, v);
           }
         }
         if (t + P < Tn) {

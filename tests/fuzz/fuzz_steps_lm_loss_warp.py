@@ -38,6 +38,10 @@ while time.time() < t_end:
             ok = False
         if not ok:
             bad += 1; print("MISMATCH beam_advance", N, Kp, V, W, S, ypl is not None)
+            os.makedirs("gpurun_out", exist_ok=True)
+            np.savez("gpurun_out/fuzz_beam_%d.npz" % bad, lpt=lpt, lpp=lpp, yp=yp, W=W,
+                     ypl=np.zeros(0) if ypl is None else ypl, act1=act[1].cpu().numpy(),
+                     act2=act[2].cpu().numpy(), act3=act[3].cpu().numpy())
     elif kind == 1:  # LM lookup vs oracle brute force
         key = (int(rng.integers(2, 7)), int(rng.integers(1, 5)), int(rng.integers(0, 2)))
         if key not in lms:
