@@ -27,6 +27,10 @@
 // leaves ties unspecified); parity is defined on tie-free inputs.
 #include "ctc_frame.hpp"
 
+#ifndef PDT_SPIN_SLEEP
+#define PDT_SPIN_SLEEP 2
+#endif
+
 namespace pdt {
 
 // exp(x) for x <= 0 (softmax numerators): OCML's expf without its overflow / underflow guards --
@@ -415,8 +419,19 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   int sl = 0;  // t % NS
   for (int t = 0; t < Tn; ++t, sl = sl + 1 == NS ? 0 : sl + 1) {
     PDT_STAMP_BEGIN;
-    while (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t)
-      __builtin_amdgcn_s_sleep(2);
+    if (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t) {
+      // the producer is behind: wait at low priority (the polling loop itself issues VALU
+      // instructions that would otherwise outrank the producer this wave is waiting for)
+#ifndef PDT_NO_PRIO
+      __builtin_amdgcn_s_setprio(0);
+#endif
+      do {
+        __builtin_amdgcn_s_sleep(PDT_SPIN_SLEEP);
+      } while (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t);
+#ifndef PDT_NO_PRIO
+      __builtin_amdgcn_s_setprio(3);
+#endif
+    }
     PDT_STAMP(0);
     L.tl_tok = slot_tok(sl);
     L.tl_p = slot_p(sl);
