@@ -200,7 +200,7 @@ def main():
         "error_rate": "pdt::lev_skewed_kernel<false>",
         "prefix_error_rates": "pdt::lev_skewed_kernel<false>",
         "optimal_completion": "pdt::lev_rowsync_kernel<false,false> + pdt::oc_expand_kernel",
-        "ctc_prefix_search": "pdt::ctc_search_kernel<1>",
+        "ctc_prefix_search": "pdt::ctc_search_kernel<1, 4>",
     }
     # HBM bytes per launch from rocprofv3 PMC passes (profiles/), only for the profiled config
     traffic = None

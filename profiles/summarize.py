@@ -7,7 +7,7 @@ import csv, glob, json, os, shutil, sys
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
 here = os.path.dirname(os.path.abspath(__file__))
-KERNEL = "ctc_search_kernel<1>"
+KERNEL = "ctc_search_kernel<1, 4>"
 
 
 def one(pattern):
@@ -56,7 +56,7 @@ scale = known / 1024.0 / cal_kb
 f_kb, w_kb = mean(fetch[k]["FETCH_SIZE"]), mean(write[k]["WRITE_SIZE"])
 sq = counters(one("sq1/**/*counter_collection.csv"))[k]
 rec = {
-    "kernel": "pdt::ctc_search_kernel<1>",
+    "kernel": "pdt::ctc_search_kernel<1, 4>",
     "config": {"N": 4096, "T": 512, "V": 256, "beam": 16},
     "raw": {"FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb},
     "calibration": {

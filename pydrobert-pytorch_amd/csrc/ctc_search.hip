@@ -97,7 +97,10 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 // frames t = p, p + P, ... in turn.  Hand-off through LDS words per utterance
 // (workgroup-scope release / acquire): ready[slot] = t + 1 once frame t is in its slot,
 // consumed = number of frames the consumer has finished.
-template <int P>
+// NT >= 0 (P = 1 only): the number of full 64-token chunks of a row, V / 64, as a compile-time
+// constant -- the row pass then has no chunk predicates to evaluate (instantiated for the
+// byte-sized vocabularies V = 256..319; NT = -1: any V).
+template <int P, int NT = -1>
 __global__ void __launch_bounds__(256, P == 1 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -158,7 +161,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     constexpr int kShortMin = 8, kShortMax = 32, kShortLo = 14, kShortHi = 26, kProbeRank = 18;
     const bool short_ok = P == 1 && W <= 16 && V > PDT_WAVE;
     float thr_off = PDT_INF;  // no guess yet
-    const int nt_ = V / PDT_WAVE, rem_ = V - nt_ * PDT_WAVE;  // full token chunks; lane of the blank
+    const int nt_ = NT >= 0 ? NT : V / PDT_WAVE, rem_ = V - nt_ * PDT_WAVE;  // full token chunks; lane of the blank
     const float inv_ntok = 1.0f / (float)(nt_ > 0 ? nt_ * PDT_WAVE : 1);
     if (pr < Tn) {
       const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
@@ -196,7 +199,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         // (laundered: chunk predicates and the two masks of chunk nt are recomputed by a scalar
         // compare where used, not hoisted out of the frame loop into scalar registers that spill)
         int lp = lane, nt = nt_, rem = rem_;
-        asm volatile("" : "+v"(lp), "+s"(nt), "+s"(rem));
+        if constexpr (NT >= 0) {
+          asm volatile("" : "+v"(lp), "+s"(rem));
+          nt = NT;
+        } else {
+          asm volatile("" : "+v"(lp), "+s"(nt), "+s"(rem));
+        }
         const bool in_row = lp <= rem, is_tok = lp < rem;
         float mx = -PDT_INF, sx = 0.0f;
 #pragma unroll
@@ -512,16 +520,16 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #endif
 }
 
-template <int P>
+template <int P, int NT = -1>
 static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL(ctc_search_kernel<P>, dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
+  hipLaunchKernelGGL((ctc_search_kernel<P, NT>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
                      stream, a, rl);
   return (int)hipGetLastError();
 }
@@ -555,6 +563,7 @@ int launch_ctc_search(CtcArgs a, hipStream_t stream) {
     rl = ring_layout(a.V, a.W, nstage, upw, 1);
   }
   if ((size_t)rl.utt_bytes * upw > hard_cap) return PDT_E_TOO_LONG;
+  if (a.V / PDT_WAVE == 4) return launch_ctc_search_p<1, 4>(a, rl, stream);
   return launch_ctc_search_p<1>(a, rl, stream);
 }
 
