@@ -55,14 +55,17 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
   const bool mask_mode = a.bitmask != nullptr;
   const int cbase = lane * CPL + 1;
   int rid[CPL], rnext[CPL];
-  float prev[CPL], cdel[CPL];
+  float prev[CPL], cdel[CPL], cdel_back[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int c = cbase + j;
     rid[j] = -2;
     if (c <= ref_len) rid[j] = class_of(ctok, U, a.ref[(int64_t)(c - 1) * a.ref_st + n * a.ref_sn]);
     cdel[j] = (float)c * del;
-    prev[j] = c <= ref_len ? cdel[j] : PDT_INF;  // row 0 (:258-263) / masked_fill(inf) (:332)
+    // added back after the scan: +inf beyond ref_len, which IS the masked_fill(inf) of :332
+    // (the scan's operands stay finite there, so no select per column and row is needed)
+    cdel_back[j] = c <= ref_len ? cdel[j] : PDT_INF;
+    prev[j] = cdel_back[j];  // row 0 (:258-263)
   }
   // class of ref[c]: the optimal "next token" when the row minimum sits in column c
   const int rid_right = __shfl_down(rid[0], 1);
@@ -113,7 +116,7 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
       const float incl = wave_incl_scan_min(run);
       const float carry = fminf(shr1(incl, PDT_INF), col0_new);
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) prev[j] = fminf(loc[j], carry) + cdel[j];
+      for (int j = 0; j < CPL; ++j) prev[j] = fminf(loc[j], carry) + cdel_back[j];
     } else {
       // row[c] = min_{k<=c} ((row0[c] - row0[k]) + t[k])   (_string.py:264-266, :317)
       wave_sync();
@@ -136,9 +139,11 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
 #pragma unroll
       for (int j = 0; j < CPL; ++j) prev[j] = best[j];
     }
+    if (EXACT) {
 #pragma unroll
-    for (int j = 0; j < CPL; ++j)
-      if (cbase + j > ref_len) prev[j] = PDT_INF;  // :332
+      for (int j = 0; j < CPL; ++j)
+        if (cbase + j > ref_len) prev[j] = PDT_INF;  // :332
+    }
     col0 = col0_new;
 
     if (mask_mode) {
@@ -160,7 +165,7 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
         a.bitmask[((int64_t)h * a.N + n) * W + lane] = w;
         cnt = __popc(w);
       }
-      cnt = wave_sum(cnt);
+      cnt = W <= 16 ? row0_sum(cnt) : wave_sum(cnt);  // (only lanes < W hold words)
       max_cnt = cnt > max_cnt ? cnt : max_cnt;
       wave_sync();
     } else if (a.mode == PDT_MODE_PREFIX) {

@@ -73,6 +73,15 @@ __device__ __forceinline__ float wave_min(float x) {
   const float s = wave_incl_scan_min(x);
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), 63));
 }
+// sum over lanes 0..15 only (one DPP row): 4 steps
+__device__ __forceinline__ int row0_sum(int x) {
+  int v = x;
+  v += dpp_or<PDT_DPP_ROW_SHR(1)>(v, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(2)>(v, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(v, 0);
+  v += dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(v, 0);
+  return __builtin_amdgcn_readlane(v, 15);
+}
 __device__ __forceinline__ int wave_sum(int x) {
   return __builtin_amdgcn_readlane(wave_incl_scan_add(x), 63);
 }
