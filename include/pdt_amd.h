@@ -118,8 +118,8 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *
  *   logits (T, N, V + 1) float32 through element strides, blank = index V.
  *   lens   (N,) int64 or NULL (all T).  S = number of rows of y = max(lens) (T if NULL).
- *   y      (S, N, width) int64 contiguous, MUST BE ZERO-FILLED by the caller: rows beyond a
- *          prefix's length are left untouched (the reference leaves them undefined);
+ *   y      (S, N, width) int64 contiguous; every element is written (rows beyond a prefix's
+ *          length are 0; the reference leaves them undefined);
  *   y_lens (N, width) int64, y_probs (N, width) float32 (probabilities, not logs).
  *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, width) bytes of scratch
  *          (the prefix trie: one (parent, token) record per frame and beam entry, and the

@@ -477,7 +477,6 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     a.y_lens[n * W + lane] = bm.len;
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  // rows beyond a prefix's length stay 0: the caller hands in a zero-filled y
 #ifndef PDT_SKIP_WALK  // diagnostic build: cost of the output walk
   {
     // One chain of bm.len dependent loads per prefix would be ~T global-memory latencies with
@@ -512,6 +511,14 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         a.y[((int64_t)pos * a.N + n) * W + k] = tok;
         node = par;
       }
+    }
+    // rows beyond a prefix's length are 0: the kernel writes every element of y (a separate
+    // fill of the whole tensor costs 2 % of the launch; here it is a few stores per prefix)
+    int lmin = lane < W ? bm.len : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) lmin = min(lmin, shfl_i(lmin, lane ^ off));
+    for (int f = lmin * W + lane; f < a.S * W; f += PDT_WAVE) {
+      const int pos = f / W, k = f - pos * W;
+      if (pos >= tab[C * W + k].y) a.y[((int64_t)pos * a.N + n) * W + k] = 0;
     }
   }
 #endif

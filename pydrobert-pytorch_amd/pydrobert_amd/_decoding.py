@@ -297,7 +297,7 @@ def _ctc_prefix_search_op(
         S = max(0, min(S, T))
     L = _cabi.lib()
     with torch.cuda.device(device):
-        y = torch.zeros((S, N, width), device=device, dtype=torch.long)
+        y = torch.empty((S, N, width), device=device, dtype=torch.long)
         y_lens = torch.empty((N, width), device=device, dtype=torch.long)
         y_probs = torch.empty((N, width), device=device, dtype=torch.float)
         ws = torch.empty(
