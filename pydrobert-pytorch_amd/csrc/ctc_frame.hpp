@@ -160,8 +160,10 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 #define PDT_STAMP_ARG
 #endif
 
+// Returns whether the lean tier decided the frame (the search kernel's producers hand over short
+// lists only while it mostly does).
 template <bool DENSE>
-__device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float inv, const int V,
+__device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float inv, const int V,
                                           const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
                                           const FrameLds &L, int &new_src, int &new_tok,
@@ -359,6 +361,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
     wave_sync();
     index_pass(M, false);
   }
+  const bool lean_decided = selected;
   if (!selected) {  // the full tiers own their layout values: nothing of them is live above
   PDT_STAT(5);
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
@@ -612,6 +615,7 @@ __device__ __forceinline__ void ctc_frame(Beam &bm, const float *p, const float 
   bm = nw;
   wave_sync();
   PDT_STAMP(5);
+  return lean_decided;
 }
 
 }  // namespace pdt

@@ -123,6 +123,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   unsigned *surv32 = reinterpret_cast<unsigned *>(surv);             // (short lists: 32-bit sort keys)
   int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
   int *ready = consumed + 1;                                          // [nstage] frame + 1 held by a slot
+  int *want_full = ready + 4;  // consumer -> producers: the lean tier keeps failing, send complete lists
   auto slot_row = [&](int sl) { return reinterpret_cast<float *>(ring + (size_t)sl * rl.slot_bytes); };
   auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(slot_row(sl) + rl.row_floats); };
   auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
@@ -140,7 +141,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   if (producer) {
     for (int sl = pr; sl < NS; sl += P)
       for (int v = lane; v < rl.pos_bytes; v += PDT_WAVE) slot_pos(sl)[v] = 0xFF;
-    if (pr == 0 && lane <= NS)  // consumed and ready[0 .. NS)
+    if (pr == 0 && lane <= 5)  // consumed, ready[0 .. 4), want_full
       __hip_atomic_store(&consumed[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();  // flags / pos tables initialised (the only workgroup barrier)
@@ -186,6 +187,10 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         if (lane < Mprev) pos[tl_tok[lane]] = 0xFF;
       }
       // softmax statistics of frame t (:1093): p[v] = exp(x[v] - max), sum over v in [0, V]
+      // short lists only while the consumer's lean tier mostly decides the frames (its own
+      // completion of a short list is far dearer than a complete selection here)
+      const bool short_now = short_ok &&
+          __hip_atomic_load(want_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
       float s = 0.0f;
       unsigned lmax = 0u;  // per-lane maximum ordering key over the tokens (not the blank)
       unsigned tkey = 0xFFFFFFFFu;  // key of the guessed threshold (none: nothing survives)
@@ -224,7 +229,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
           // survivors: numerator >= the numerator of the guessed threshold (same exp routine, so
           // the set is an upper set of the list order)
           // (any threshold value gives an exact top-c list: v_exp_f32 accuracy is plenty)
-          if (t > 0 && thr_off < PDT_INF)
+          if (short_now && t > 0 && thr_off < PDT_INF)
             tkey = fkey_nonneg(__builtin_amdgcn_exp2f(fminf(mean + thr_off - mx, 0.0f) * 0x1.715476p+0f));
         }
         auto survivors = [&](const unsigned key, const bool pred, const int v) {
@@ -421,6 +426,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   bm.isp = lane == 0 ? 1u : 0u;
   bm.origin = lane;
   int Kp = 1;
+  int fail_score = 0, full_mode = 0;
 #ifdef PDT_STAMPS
   unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
@@ -449,7 +455,15 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
 #ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
-    ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+    const bool lean = ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+    // feedback to the producers: +8 per frame the lean tier could not decide, -1 per frame it
+    // did (balance at one failure in nine); complete lists above 32, short ones again below 8
+    fail_score = lean ? max(fail_score - 1, 0) : min(fail_score + 8, 64);
+    const int wf = fail_score > 32 ? 1 : (fail_score < 8 ? 0 : full_mode);
+    if (wf != full_mode) {
+      full_mode = wf;
+      if (lane == 0) __hip_atomic_store(want_full, wf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
 #else
     ns = nt = nk = 0; (void)s;
 #endif
