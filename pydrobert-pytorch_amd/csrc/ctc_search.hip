@@ -35,7 +35,10 @@ namespace pdt {
 
 // exp(x) for x <= 0 (softmax numerators): OCML's expf without its overflow / underflow guards --
 // the same hi/lo range reduction around v_exp_f32; v_ldexp_f32 flushes what underflows.
+// Arguments below -200 (masked vocabulary entries: -inf logits) are clamped first: the result
+// underflows to 0 either way, but -inf would turn the rounding-error term into inf - inf.
 __device__ __forceinline__ float exp_nonpos(float x) {
+  x = fmaxf(x, -200.0f);
   const float t = x * 0x1.715476p+0f;                       // x * log2(e), rounded
   const float lo = __builtin_fmaf(x, 0x1.715476p+0f, -t);   // its rounding error
   const float n = __builtin_rintf(t);
@@ -56,6 +59,7 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x) {
   const f32x2 L = {0x1.715476p+0f, 0x1.715476p+0f}, L2 = {0x1.4ae0bep-26f, 0x1.4ae0bep-26f};
+  x = __builtin_elementwise_max(x, f32x2{-200.0f, -200.0f});
   const f32x2 t = x * L;
   const f32x2 lo = __builtin_elementwise_fma(x, L, -t);
   const f32x2 n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};

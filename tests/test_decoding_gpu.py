@@ -103,6 +103,22 @@ def test_ctc_prefix_search_many_checkpoints(device):
         _check_search(act, exp, ("checkpoints", T, V, K))
 
 
+def test_ctc_prefix_search_masked_tokens(device):
+    """-inf logits (masked vocabulary entries) and rows with a huge dynamic range: the
+    threshold guess of the short lists sees a -inf / overflowing row mean and must fall back to
+    the complete selection."""
+    rng = np.random.default_rng(99)
+    for T, V, K in [(40, 70, 8), (33, 300, 16)]:
+        lg = _peaky_logits(rng, T, 5, V, scale=9.0)
+        dead = rng.random((T, 5, V + 1)) < 0.3
+        dead[np.arange(T)[:, None], np.arange(5)[None], lg.argmax(2)] = False  # keep the peak
+        lg[dead] = -np.inf
+        lg[T // 2] *= 1e30  # finite, but the row sum overflows
+        exp = oracle.ctc_prefix_search(lg, K)
+        act = F.ctc_prefix_search(torch.from_numpy(lg).to(device), K)
+        _check_search(act, exp, ("masked", T, V, K))
+
+
 def test_ctc_wide_beam(device):
     """width > V + 1: the kernel treats padded entries as absent (documented superset of the
     reference, which degenerates to NaN).  Checks: no NaN, valid prefixes are distinct, their
