@@ -339,7 +339,27 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     const bool tie = lane < K && (st >> 6) != 0u && (st >> 6) == (st_next >> 6);
     const int wid = wth < 0 ? 64 : 0;
     PDT_STAMP(9);
-    if (__ballot((isw && (rw == 1 || wid >= 64)) || tie) == 0ull) {
+    bool lean_ok = __ballot((isw && wid >= 64) || tie) == 0ull;
+    if (lean_ok && __ballot(isw && rw == 1) != 0ull) {
+      // A prefix's entry 1 is among the winners: its entry 2 (not resident here) matters only
+      // if it, too, beats the K-th winner.  Entries are sorted, so usually it does not: look the
+      // one mass up (or bound it by the list's last probability when the list is short) instead
+      // of handing the whole frame to the full tiers.
+      const unsigned kth = (unsigned)__builtin_amdgcn_readlane((int)wkey, K - 1);  // 0: fewer than K candidates
+      const int kw = wl & 15;
+      unsigned a2 = (unsigned)shfl_i((int)(unsigned)avail, kw);
+      const float tot2 = shfl_f(tot, kw);
+      a2 &= a2 - 1u;
+      a2 &= a2 - 1u;  // entries 0 and 1 gone
+      const int j2 = a2 ? __builtin_ctz(a2) : c_list - 1;
+      const float p2 = L.tl_p[(DENSE ? kw : 0) * PDT_WAVE + j2];
+      unsigned key2 = 0u;
+      if (a2 != 0u) key2 = fkey_nonneg(tot2 * p2);
+      else if (!full_list) key2 = fkey_nonneg(tot2 * p2) + 1u;  // upper bound of a hidden entry
+      const bool third_wins = isw && rw == 1 && key2 != 0u && key2 >= kth;
+      lean_ok = __ballot(third_wins) == 0ull;
+    }
+    if (lean_ok) {
       if (isw) {
         new_src = wl & 15;
         new_tok = wtok;

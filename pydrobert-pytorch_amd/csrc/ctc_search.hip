@@ -460,10 +460,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     int ns, nt, nk;
 #ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
     const bool lean = ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
-    // feedback to the producers: +8 per frame the lean tier could not decide, -1 per frame it
-    // did (balance at one failure in nine); complete lists above 32, short ones again below 8
-    fail_score = lean ? max(fail_score - 1, 0) : min(fail_score + 8, 64);
-    const int wf = fail_score > 32 ? 1 : (fail_score < 8 ? 0 : full_mode);
+    // feedback to the producers: a complete selection costs the producer about what two list
+    // completions cost this wave, so the balance is at one undecided frame in two: +1 per
+    // frame the lean tier could not decide, -1 per frame it did (0 .. 32); complete lists
+    // above 16, short ones again below 4
+    fail_score = lean ? max(fail_score - 1, 0) : min(fail_score + 1, 32);
+    const int wf = fail_score > 16 ? 1 : (fail_score < 4 ? 0 : full_mode);
     if (wf != full_mode) {
       full_mode = wf;
       if (lane == 0) __hip_atomic_store(want_full, wf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
