@@ -160,8 +160,8 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 #define PDT_STAMP_ARG
 #endif
 
-// Returns whether the lean tier decided the frame (the search kernel's producers hand over short
-// lists only while it mostly does).
+// Returns whether the list as handed over was enough (false: this wave had to complete a short
+// list -- the search kernel's producers send short lists only while that stays rare).
 template <bool DENSE>
 __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float inv, const int V,
                                           const int W, const int Kp, const int t,
@@ -371,17 +371,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   }
 
   }
-  if (!DENSE && !selected && !full_list) {
-    // the producer handed over a short list and this frame needs more: complete it here (the
-    // short list is a prefix of the complete one, so the entries already indexed stay valid)
-    // and redo the bookkeeping that depends on list positions
-    PDT_STAT(4);
-    build_shared_list<false>(p, inv, V, M, reinterpret_cast<u64 *>(L.nxt_new), L.tl_tok, L.tl_p, L.pos);
-    if (lane == 0) L.hdr[2] = __int_as_float(M);
-    wave_sync();
-    index_pass(M, false);
-  }
-  const bool lean_decided = selected;
+  bool list_sufficed = true;
   if (!selected) {  // the full tiers own their layout values: nothing of them is live above
   PDT_STAT(5);
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
@@ -390,6 +380,10 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // A prefix's resident entries are consumed in order (they are sorted), so a round is just
   // a wave max + clearing the winning slot; only when a prefix uses up ALL its resident
   // stream-0 entries are its slots refilled with the next 3R-2.
+  // (a lambda, expanded twice: on the list as handed over and, if a bound won, on the completed
+  // list.  As a loop the second pass made the first one's values loop-carried, and the spills
+  // landed in every frame's state update.)
+  auto full_tiers = [&](const bool list_done) -> bool {
   const int G = Kp <= 16 ? 16 : 32, GS = Kp <= 16 ? 4 : 5, R = PDT_WAVE >> GS;
   const int kb = lane & (G - 1), rr = lane >> (G == 16 ? 4 : 5);  // (a shift, not a division by a runtime G)
   const int ksrc = kb < Kp ? kb : 0;
@@ -401,11 +395,16 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   const int n_main = 3 * R - 2;
   // fills the stream-0 slots of every lane whose prefix is in `mask_k` from that prefix's
   // current `avail`
+  // While the list is short (list_done = false) the first entry a prefix does NOT have is an
+  // UPPER BOUND of whatever the complete list holds there (token -1, the mass with the list's
+  // last probability, key + 1): if a bound is ever taken as a winner the list is completed and
+  // the tiers run again; otherwise the short list was all this frame needed.
   auto fill_main = [&](bool mine) {
     const int *lt = L.tl_tok + (DENSE ? ksrc : 0) * PDT_WAVE;
     const float *lp = L.tl_p + (DENSE ? ksrc : 0) * PDT_WAVE;
     if (M <= 32) {  // the usual case (K + K' <= 32): half the work per bit operation
       unsigned av = (unsigned)shfl_i((int)(unsigned)avail, ksrc);
+      const int n_av = __popc(av);
       for (int i = 0; i < rr; ++i) av &= av - 1u;
 #pragma unroll
       for (int sl = 0; sl < 3; ++sl) {
@@ -416,6 +415,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
           const int j = __builtin_ctz(av);
           tok = lt[j];
           key = fkey_nonneg(tot_k * lp[j]);
+        } else if (!DENSE && !list_done && e == n_av && e < n_main && kvalid) {
+          tok = -1;
+          key = fkey_nonneg(tot_k * lp[c_list - 1]) + 1u;
         }
         if (mine && e < n_main) {
           if (sl == 0) { key0 = key; tk0 = tok; }
@@ -446,6 +448,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       for (int i = 0; i < R; ++i) av &= av - 1ull;  // next entry of this lane: e + R
     }
   };
+  bool bound_won = false;
   {
     fill_main(true);
     // stream 1 / stream 2 live in slot 2 of rows R-2 / R-1
@@ -501,17 +504,22 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       const int e = (wl >> GS) + R * sw;
       if (__ballot(isw && e == n_main - 1) == 0ull) {
         const int t0 = shfl_i(tk0, wl), t1 = shfl_i(tk1, wl), t2 = shfl_i(tk2, wl);
-        if (isw) {
-          new_src = wl & (G - 1);
-          new_tok = sw == 0 ? t0 : (sw == 1 ? t1 : t2);
-          new_kind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
-          new_mass = fkey_nonneg_inv(wkey);
+        const int tw = sw == 0 ? t0 : (sw == 1 ? t1 : t2);
+        if (__ballot(isw && tw < 0) != 0ull) {
+          bound_won = true;
+        } else {
+          if (isw) {
+            new_src = wl & (G - 1);
+            new_tok = tw;
+            new_kind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
+            new_mass = fkey_nonneg_inv(wkey);
+          }
+          selected = true;
         }
-        selected = true;
       }
     }
   }
-  if (!selected)
+  if (!selected && !bound_won)
   for (int i = 0; i < K; ++i) {
     const unsigned lk = max(max(key0, key1), key2);
     const unsigned mx = wave_max_u32(lk);
@@ -521,6 +529,10 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     const int tw_l = key0 == mx ? tk0 : (key1 == mx ? tk1 : tk2);
     const int sw = __builtin_amdgcn_readlane(sw_l, win);
     const int wtok = __builtin_amdgcn_readlane(tw_l, win);
+    if (wtok < 0) {  // a bound: the short list is not enough for this frame
+      bound_won = true;
+      break;
+    }
     const int wbeam = win & (G - 1);
     const int e = (win >> GS) + R * sw;
     const int wkind = e == n_main ? 1 : (e == n_main + 1 ? 2 : 0);
@@ -540,6 +552,23 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
         for (int q = 0; q < n_main; ++q) avail &= avail - 1ull;
       fill_main(kb == wbeam);
     }
+  }
+  return bound_won;
+  };
+  if (full_tiers(full_list)) {
+    list_sufficed = false;
+    // complete the list here (the short list is a prefix of the complete one, so the entries
+    // already indexed stay valid), redo the bookkeeping that depends on list positions, and
+    // run the tiers again from a clean slate
+    PDT_STAT(4);
+    build_shared_list<false>(p, inv, V, M, reinterpret_cast<u64 *>(L.nxt_new), L.tl_tok, L.tl_p, L.pos);
+    if (lane == 0) L.hdr[2] = __int_as_float(M);
+    wave_sync();
+    index_pass(M, false);
+    selected = false;
+    new_src = 0, new_tok = 0, new_kind = -1;
+    new_mass = -PDT_INF;
+    full_tiers(true);
   }
   }
   PDT_STAMP(3);
@@ -635,7 +664,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   bm = nw;
   wave_sync();
   PDT_STAMP(5);
-  return lean_decided;
+  return list_sufficed;
 }
 
 }  // namespace pdt

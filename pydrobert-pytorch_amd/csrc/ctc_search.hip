@@ -459,12 +459,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
 #ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
-    const bool lean = ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+    const bool enough = ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
     // feedback to the producers: a complete selection costs the producer about what two list
-    // completions cost this wave, so the balance is at one undecided frame in two: +1 per
-    // frame the lean tier could not decide, -1 per frame it did (0 .. 32); complete lists
-    // above 16, short ones again below 4
-    fail_score = lean ? max(fail_score - 1, 0) : min(fail_score + 1, 32);
+    // completions cost this wave, so the balance is at one completed list in two frames: +1
+    // per frame this wave had to complete a short list, -1 per frame it did not (0 .. 32);
+    // complete lists above 16, short ones again below 4
+    fail_score = enough ? max(fail_score - 1, 0) : min(fail_score + 1, 32);
     const int wf = fail_score > 16 ? 1 : (fail_score < 4 ? 0 : full_mode);
     if (wf != full_mode) {
       full_mode = wf;
