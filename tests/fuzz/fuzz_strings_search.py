@@ -45,7 +45,12 @@ while time.time() < t_end:
         if not ok:
             bad += 1; print("MISMATCH", name, N, R, H, V, kw, bf, exp.shape, act.shape)
     elif kind == 1:  # ctc search
-        V = int(rng.integers(1, 80)); K = int(rng.integers(1, min(V + 1, 32) + 1))
+        # small vocabularies mostly; the short-list producers (64 < V < 512, K <= 16) and the
+        # compile-time-chunk instantiation (V = 256..319) regularly; long rows now and then
+        u = rng.random()
+        V = int(rng.integers(1, 80)) if u < 0.5 else (int(rng.integers(65, 340)) if u < 0.9 else int(rng.integers(513, 640)))
+        K = int(rng.integers(1, min(V + 1, 32) + 1))
+        if V > 64 and rng.random() < 0.7: K = int(rng.integers(1, 17))
         Tn, N = int(rng.integers(0, 70)), int(rng.integers(1, 7))
         lg = rng.normal(size=(Tn, N, V + 1)).astype(np.float32)
         if Tn:
