@@ -27,6 +27,12 @@
 // leaves ties unspecified); parity is defined on tie-free inputs.
 #include "ctc_frame.hpp"
 
+#ifndef PDT_SHORT_MIN  // window and target of the short lists' survivor count
+#define PDT_SHORT_MIN 8
+#define PDT_SHORT_LO 14
+#define PDT_SHORT_HI 26
+#define PDT_SHORT_PROBE 18
+#endif
 #ifndef PDT_SPIN_SLEEP
 #define PDT_SPIN_SLEEP 2
 #endif
@@ -163,7 +169,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     // the probe of a complete selection, then nudged to keep c near 20 -- and a miss (c outside
     // the window) just takes the complete selection.  The consumer completes a short list itself
     // in the frames that turn out to need more.
-    constexpr int kShortMin = 8, kShortMax = 32, kShortLo = 14, kShortHi = 26, kProbeRank = 18;
+    constexpr int kShortMin = PDT_SHORT_MIN, kShortMax = 32, kShortLo = PDT_SHORT_LO, kShortHi = PDT_SHORT_HI, kProbeRank = PDT_SHORT_PROBE;
     const bool short_ok = P == 1 && W <= 16 && V > PDT_WAVE;
     float thr_off = PDT_INF;  // no guess yet
     const int nt_ = NT >= 0 ? NT : V / PDT_WAVE, rem_ = V - nt_ * PDT_WAVE;  // full token chunks; lane of the blank
@@ -372,7 +378,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         PDT_STAT(1);
         // one 32-key sort of 32-bit keys; exact unless two survivors agree in the upper 23 bits
         // (then the (value, token) pairs are sorted instead)
-        unsigned st = half_wave_sort_desc<unsigned>(lane < nshort ? surv32[lane] : 0u);
+        const unsigned sk = lane < nshort ? surv32[lane] : 0u;
+        unsigned st = nshort <= 16 ? row_sort_desc<unsigned>(sk) : half_wave_sort_desc<unsigned>(sk);
         const unsigned st_next = (unsigned)__builtin_amdgcn_mov_dpp((int)st, 0x130, 0xf, 0xf, true);  // wave_shl:1
         int tok = 511 - (int)(st & 511u);
         if (__ballot(lane + 1 < nshort && (st >> 9) == (st_next >> 9)) != 0ull) {

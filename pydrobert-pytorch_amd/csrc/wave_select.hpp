@@ -142,6 +142,16 @@ __device__ __forceinline__ T half_wave_sort_desc(T key) {
   return key;
 }
 
+// ... and after 10 stages: every aligned group of 16 lanes sorted descending
+template <typename T>
+__device__ __forceinline__ T row_sort_desc(T key) {
+  key = sort_groups<2>(key);
+  key = sort_groups<4>(key);
+  key = sort_groups<8>(key);
+  key = sort_groups<16>(key);
+  return key;
+}
+
 // cur: sorted descending; add: arbitrary.  Returns the 64 largest of the union, sorted descending.
 __device__ __forceinline__ u64 wave_merge_top64(u64 cur, u64 add) {
   const int lane = lane_id();
