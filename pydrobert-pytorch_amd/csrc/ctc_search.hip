@@ -7,7 +7,9 @@
 // gather over the whole (t,N,K) history among them).  Here the whole T-frame search of one
 // utterance runs inside one workgroup slice:
 //   * producer wave(s): stage a frame's logits in an LDS ring slot, softmax statistics by DPP
-//     reductions, and the sorted list of the top (K + K') tokens (wave_top_sorted);
+//     reductions, and the sorted list of the top tokens: all K + K' that can matter
+//     (wave_top_sorted), or -- rows of up to 511 tokens, K <= 16 -- only the exact top c for
+//     a guessed threshold, which the consumer completes in the rare frame that needs more;
 //   * consumer wave: beam state (nb, b, last token, length, trie node, is-prefix row as a
 //     32-bit mask) lives in the registers of lane k; candidates are never materialised: the
 //     mass of extending prefix k with token v is w_k(v) * p[v], monotone in p[v] for fixed k,
@@ -17,7 +19,9 @@
 //   * prefixes are a trie in HBM ((parent, token) per created node) instead of dense
 //     (t, N, K) histories, so a frame writes K records instead of gathering t*K tokens; the
 //     only history look-ups the algorithm needs (token of prefix b at the position where
-//     prefix a ends) are served from a K x K table in LDS maintained incrementally.
+//     prefix a ends) are served from a K x K table in LDS maintained incrementally.  The
+//     prefixes are read off the trie at the end through checkpoints (CtcArgs::ckpt), in
+//     parallel segments.
 //
 // K + K' list entries suffice: a prefix can take at most K winners, lose at most K' - 1 list
 // entries to extensions that merge into existing beam prefixes, and its own last token is a
