@@ -281,6 +281,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   new_src = 0, new_tok = 0, new_kind = -1;
   float new_mass = -PDT_INF;
   bool selected = false;
+  // a lower bound of the K-th winner's key the lean tier leaves behind for the full tiers
+  // (0: none): its candidates are a subset of theirs, so its K-th largest cannot exceed theirs
+  unsigned tau_hint = 0u;
   {  // scope of the lean tier's per-lane layout values
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
   // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
@@ -340,6 +343,12 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     const int wid = wth < 0 ? 64 : 0;
     PDT_STAMP(9);
     bool lean_ok = __ballot((isw && wid >= 64) || tie) == 0ull;
+    if (__ballot(isw && wid >= 64) == 0ull) {
+      // (not when an upper bound ranks among the first K: that is no real candidate.)  The keys
+      // of a bucket of the rounded sort lie in (r - 64, r].
+      const unsigned rk = (unsigned)__builtin_amdgcn_readlane((int)st, K - 1) >> 6;
+      tau_hint = rk ? (rk << 6) - 63u : 1u;
+    }
     if (lean_ok && __ballot(isw && rw == 1) != 0ull) {
       // A prefix's entry 1 is among the winners: its entry 2 (not resident here) matters only
       // if it, too, beats the K-th winner.  Entries are sorted, so usually it does not: look the
@@ -466,9 +475,12 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // entry of its prefix (the rounds would refill that prefix's slots).
   if (!selected) {
     u64 *sel = DENSE ? L.surv : reinterpret_cast<u64 *>(L.nxt_new);
-    const unsigned lk = max(max(key0, key1), key2);
-    const unsigned slk = wave_sort_desc<unsigned>(lk);
-    const unsigned tau = max((unsigned)__builtin_amdgcn_readlane((int)slk, K - 1), 1u);
+    unsigned tau = tau_hint;
+    if (tau == 0u) {
+      const unsigned lk = max(max(key0, key1), key2);
+      const unsigned slk = wave_sort_desc<unsigned>(lk);
+      tau = max((unsigned)__builtin_amdgcn_readlane((int)slk, K - 1), 1u);
+    }
     const bool p0 = key0 >= tau, p1 = key1 >= tau, p2 = key2 >= tau;
     const u64 b0 = __ballot(p0), b1 = __ballot(p1), b2 = __ballot(p2);
     const int c0 = __popcll(b0), c1 = __popcll(b1), c2 = __popcll(b2);
