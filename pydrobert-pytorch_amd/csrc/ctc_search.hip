@@ -40,6 +40,9 @@
 #ifndef PDT_SPIN_SLEEP
 #define PDT_SPIN_SLEEP 2
 #endif
+#ifndef PDT_CONSUMER_PRIO
+#define PDT_CONSUMER_PRIO 3
+#endif
 
 namespace pdt {
 
@@ -424,7 +427,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #ifndef PDT_NO_PRIO
   // the consumer's dependency chain is the critical path of the utterance (the producers run
   // ahead by up to nstage frames): its instructions issue first, the producers fill the gaps
-  __builtin_amdgcn_s_setprio(3);
+  __builtin_amdgcn_s_setprio(PDT_CONSUMER_PRIO);
 #endif
   FrameLds L;
   L.surv = surv;  // unused by the shared-list form
@@ -458,7 +461,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         __builtin_amdgcn_s_sleep(PDT_SPIN_SLEEP);
       } while (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t);
 #ifndef PDT_NO_PRIO
-      __builtin_amdgcn_s_setprio(3);
+      __builtin_amdgcn_s_setprio(PDT_CONSUMER_PRIO);
 #endif
     }
     PDT_STAMP(0);
