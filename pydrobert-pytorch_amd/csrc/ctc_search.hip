@@ -40,6 +40,10 @@
 #ifndef PDT_SPIN_SLEEP
 #define PDT_SPIN_SLEEP 2
 #endif
+#ifndef PDT_UTT_PER_WG  // one-producer form: utterances per workgroup and ring depth (LDS permitting)
+#define PDT_UTT_PER_WG 2
+#define PDT_RING_STAGES 4
+#endif
 #ifndef PDT_CONSUMER_PRIO
 #define PDT_CONSUMER_PRIO 3
 #endif
@@ -597,7 +601,7 @@ int launch_ctc_search(CtcArgs a, hipStream_t stream) {
     if ((size_t)rl.utt_bytes <= hard_cap) return launch_ctc_search_p<2>(a, rl, stream);
   }
   // ring depth and utterances per workgroup from the LDS budget
-  int nstage = 4, upw = 2;
+  int nstage = PDT_RING_STAGES, upw = PDT_UTT_PER_WG;
   RingLayout rl = ring_layout(a.V, a.W, nstage, upw, 1);
   while ((size_t)rl.utt_bytes * upw > soft_cap && (upw > 1 || nstage > 2)) {
     if (upw > 1) upw = 1; else nstage = 2;
