@@ -4,16 +4,23 @@
 A step = one pass of the hot path over one synthetic batch that is already resident in
 HBM: BASELINE.json's configs[1] shapes (N=4096 utterances per GPU, T=512, V=256)
 
-    error_rate -> prefix_error_rates -> optimal_completion -> [CTC prefix beam search]
-    -> all-gather of the per-shard error counts (multi-GPU only)
+    error_rate -> prefix_error_rates -> optimal_completion -> CTC prefix beam search (K=16)
+    -> all-gather of the per-shard error rates (multi-GPU only)
 
-Prints ONE JSON line on rank 0.  `value` = utterances / s over all ranks (weak scaling:
-every rank owns its own N utterances).  Per-op times come from HIP events recorded on the
-launch stream inside the timed region.
+`python bench.py --gpus N` starts its own N ranks (one process per GPU, RCCL) when it is not
+already running under torchrun; rank 0 prints ONE JSON line.  `value` = utterances / s over all
+ranks (weak scaling: every rank owns its own N utterances).  Per-op times come from HIP events
+recorded on the launch stream inside the timed region.  After the timed region the line also
+carries the other BASELINE configs (C3 search and step functions, C4 SpecAugment / sparse warp,
+the C5 shard: error_rate + decode at V=5000 with its gather) as `other_configs`, and at N=1 the
+CPU baseline (the reference's tensor algorithm on the host cores, per operator).
 """
 import argparse
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +33,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRIC = "utterances/sec (N=4096,T=512) error_rate+ctc_beam at 1/2/4/8 GPU"
 
 
 def parse():
@@ -39,60 +47,316 @@ def parse():
     ap.add_argument("--beam", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-decode", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-extra", action="store_true", help="skip the other BASELINE configs")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="preflight: bring the ranks up, check one all-gather, run no workload (needs no GPU "
+                         "with PDT_BENCH_BACKEND=gloo)")
     return ap.parse_args()
 
 
-def make_inputs(args, rank, device):
-    """Synthetic tokens (and logits) of BASELINE config 2's shape; seed 0x5EED0002 + rank."""
+# ------------------------------------------------------------------------------------------
+# launcher: one child process per rank, started before anything here touches a GPU
+# ------------------------------------------------------------------------------------------
+def launch_ranks(args):
+    """Start args.gpus copies of this script as ranks 0..N-1 (the spawn-then-init pattern of the
+    reference's own distributed tests, tests/test_dataloaders.py:818-904).  This process never
+    initialises the GPU (device_count() does not); it only waits and forwards the exit code."""
+    backend = os.environ.get("PDT_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        print("bench.py: --gpus {} but only {} device(s) are visible".format(args.gpus, have), file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, deadline = 0, time.time() + 1500
+    pending = set(range(args.gpus))
+    while pending and time.time() < deadline:
+        for r in sorted(pending):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            pending.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                print("bench.py: rank {} exited with {}; stopping the others".format(r, code), file=sys.stderr)
+                for q in pending:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    for r in pending:  # timed out
+        procs[r].kill()
+        rc = rc or 3
+    return rc
+
+
+# ------------------------------------------------------------------------------------------
+# inputs
+# ------------------------------------------------------------------------------------------
+def make_tokens(args, rank, device):
+    """Synthetic tokens of BASELINE config 2's shape; seed 0x5EED0002 + rank (any rank can
+    regenerate any other rank's shard: the gather check relies on it)."""
     rng = np.random.default_rng(0x5EED0002 + rank)
     ref = torch.from_numpy(rng.integers(0, args.V, (args.T, args.N))).to(device)
     hyp = torch.from_numpy(rng.integers(0, args.V, (args.T, args.N))).to(device)
     return ref, hyp
 
 
-def cpu_baseline(args, with_decode):
-    """The oracle's reference-faithful C restatement (O(H*R^2) per utterance like
-    _string.py:316-317; dense candidate tables per frame like _decoding.py:842-846) timed on
-    ONE host core on a bounded sample of the same workload."""
-    import oracle
+def peaky_logits(T, N, V, device, seed, chunk=64):
+    """N(0,1) + 12 on one class per frame (blank included)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    lg = torch.empty((T, N, V + 1), device=device)
+    for t0 in range(0, T, chunk):
+        part = lg[t0:t0 + chunk]
+        part.normal_(generator=g)
+        peak = torch.randint(0, V + 1, (part.shape[0], N, 1), device=device, generator=g)
+        part.scatter_add_(2, peak, torch.full((part.shape[0], N, 1), 12.0, device=device))
+    return lg
 
+
+def event_ms(fn, reps=5, warm=2):
+    """Median HIP-event time of fn() on the current (= launch) stream."""
+    for _ in range(warm):
+        fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in ev:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    return float(np.median([a.elapsed_time(b) for a, b in ev]))
+
+
+# ------------------------------------------------------------------------------------------
+# CPU baseline (rank 0, N = 1 only)
+# ------------------------------------------------------------------------------------------
+def cpu_baseline(args, with_decode, op_ms):
+    """the reference's tensor algorithm restated in torch CPU ops
+    (oracle/torch_cpu.py -- what a user of the reference experiences), per operator, on a
+    bounded sample, all host threads and 8 threads; the scalar C restatement on one core is
+    reported separately ("c_port") and is not the denominator of any ratio."""
+    import oracle
+    from oracle import torch_cpu as tc
+
+    T, V, K = args.T, args.V, args.beam
     rng = np.random.default_rng(0x5EED0002)
-    T, V = args.T, args.V
-    n, done, t_used = 2, 0, 0.0
-    while t_used < args.cpu_seconds and done < args.N:
-        ref = rng.integers(0, V, (T, n))
-        hyp = rng.integers(0, V, (T, n))
-        lg = rng.normal(size=(T, n, V + 1)).astype(np.float32)
-        np.put_along_axis(lg, rng.integers(0, V + 1, (T, n, 1)), 12.0, 2)
+    host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # utterances per call, sized so one call takes ~0.1-1 s (optimal_completion's (H, n, R, R)
+    # closure is 134 MB per utterance at T = 512)
+    chunk = {"error_rate": 16, "prefix_error_rates": 16, "optimal_completion": 2, "ctc_prefix_search": 16}
+    fns = {"error_rate": lambda r, h, lg: tc.error_rate(r, h),
+           "prefix_error_rates": lambda r, h, lg: tc.prefix_error_rates(r, h),
+           "optimal_completion": lambda r, h, lg: tc.optimal_completion(r, h),
+           "ctc_prefix_search": lambda r, h, lg: tc.ctc_prefix_search(lg, K)}
+    names = [o for o in fns if with_decode or o != "ctc_prefix_search"]
+    budget = args.cpu_seconds / (2.0 * len(names))
+    old_threads = torch.get_num_threads()
+    res = {}
+    for threads in sorted({host, min(8, host)}, reverse=True):
+        torch.set_num_threads(threads)
+        per = {}
+        for name in names:
+            n = chunk[name]
+            ref = torch.from_numpy(rng.integers(0, V, (T, n)))
+            hyp = torch.from_numpy(rng.integers(0, V, (T, n)))
+            lg = None
+            if name == "ctc_prefix_search":
+                lg = torch.from_numpy(rng.normal(size=(T, n, V + 1)).astype(np.float32))
+                lg.scatter_add_(2, torch.from_numpy(rng.integers(0, V + 1, (T, n, 1))), torch.full((T, n, 1), 12.0))
+            times, t_begin = [], time.perf_counter()
+            for rep in range(2 + 5):  # 2 warm-ups, then >= 5 timed repetitions
+                t0 = time.perf_counter()
+                fns[name](ref, hyp, lg)
+                if rep >= 2:
+                    times.append(time.perf_counter() - t0)
+            while time.perf_counter() - t_begin < budget and len(times) < 25:
+                t0 = time.perf_counter()
+                fns[name](ref, hyp, lg)
+                times.append(time.perf_counter() - t0)
+            per[name] = {"utt_per_s_median": n / float(np.median(times)), "utt_per_s_best": n / min(times),
+                         "utterances_per_call": n, "reps": len(times)}
+        step = 1.0 / sum(1.0 / p["utt_per_s_median"] for p in per.values())
+        res[threads] = {"step_utt_per_s": step, "per_op": per}
+    torch.set_num_threads(old_threads)
+    # the scalar C restatement (oracle/pdt_oracle_*.c), one core, for comparison
+    c_port = {}
+    n = 8
+    ref, hyp = rng.integers(0, V, (T, n)), rng.integers(0, V, (T, n))
+    lg = rng.normal(size=(T, n, V + 1)).astype(np.float32)
+    np.put_along_axis(lg, rng.integers(0, V + 1, (T, n, 1)), 12.0, 2)
+    for name, fn in (("error_rate", lambda: oracle.error_rate(ref, hyp)),
+                     ("prefix_error_rates", lambda: oracle.prefix_error_rates(ref, hyp)),
+                     ("optimal_completion", lambda: oracle.optimal_completion(ref, hyp)),
+                     ("ctc_prefix_search", lambda: oracle.ctc_prefix_search(lg, K))):
+        if name not in names:
+            continue
         t0 = time.perf_counter()
-        oracle.error_rate(ref, hyp)
-        oracle.prefix_error_rates(ref, hyp)
-        oracle.optimal_completion(ref, hyp)
-        if with_decode:
-            oracle.ctc_prefix_search(lg, args.beam)
-        t_used += time.perf_counter() - t0
-        done += n
-        n = min(n * 2, 16)
+        fn()
+        c_port[name] = n / (time.perf_counter() - t0)
+    top = res[host]
+    gpu = {o: args.N / (op_ms[o] * 1e-3) for o in names}
     return {
-        "value": done / t_used,
+        "value": top["step_utt_per_s"],
         "unit": "utterances/s",
-        "cores": 1,
+        "cores": host,
         "kind": "port",
-        "sample": "{} utterances of T={} V={}: the step's operators ({}) with the oracle's "
-        "reference-faithful C restatement".format(
-            done, T, V, "string ops + ctc_prefix_search" if with_decode else "string ops"
-        ),
+        "sample": "torch-CPU restatement of the reference's tensor algorithm (oracle/torch_cpu.py), T={} V={} K={}: "
+                  "per operator 2 warm-ups + >=5 timed calls of 16 utterances (optimal_completion: 2); "
+                  "value = utterances/s of the whole step from the per-op medians".format(T, V, K),
+        "per_op": top["per_op"],
+        "threads_8": res[min(8, host)],
+        "gpu_over_cpu": {o: gpu[o] / top["per_op"][o]["utt_per_s_median"] for o in names},
+        "c_port": {"cores": 1, "utt_per_s": c_port,
+                   "what": "scalar C restatement (oracle/pdt_oracle_*.c), 8 utterances, one call per operator"},
     }
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------
+# the other BASELINE configs, after the timed region
+# ------------------------------------------------------------------------------------------
+def other_configs(F, M, device, world, rank, dist, gather_check):
+    out = {}
+    K = 16
+    # C5 shard: N=4096 x T=512, V=5000 per GPU -- error_rate + fused CTC decode + the gathers
+    T, N, V = 512, 4096, 5000
+    rng = np.random.default_rng(0x5EED0005 + rank)
+    ref = torch.from_numpy(rng.integers(0, V, (T, N))).to(device)
+    hyp = torch.from_numpy(rng.integers(0, V, (T, N))).to(device)
+    lg = peaky_logits(T, N, V, device, 0x5EED0006 + rank)
+    from pydrobert_amd import distributed as D
+
+    def c5():
+        er = F.error_rate(ref, hyp, warn=False)
+        y, yl, yp = F.ctc_prefix_search(lg, K)
+        if world > 1 and dist.get_backend() == "nccl":
+            er = D.gather_utterance_values(er, world * N)
+            yl = D.gather_utterance_values(yl, world * N)
+            yp = D.gather_utterance_values(yp, world * N)
+        return er, y, yl, yp
+
+    er, y, yl, yp = c5()
+    ok = bool(torch.isfinite(yp[:, 0]).all()) and bool((yl <= T).all()) and er.shape[0] == world * N
+    if world > 1 and dist.get_backend() == "nccl":
+        ok = ok and gather_check(er[rank * N:(rank + 1) * N], F.error_rate(ref, hyp, warn=False))
+    ms_dec = event_ms(lambda: F.ctc_prefix_search(lg, K), reps=3, warm=0)
+    ms_er = event_ms(lambda: F.error_rate(ref, hyp, warn=False), reps=3, warm=1)
+    ms_all = event_ms(c5, reps=3, warm=0)
+    out["C5_shard"] = {
+        "workload": "per GPU: error_rate + ctc_prefix_search, N=4096 T=512 V=5000 K=16, "
+                    "all-gather of rates / lens / probs over {} rank(s)".format(world),
+        "ms": ms_all, "error_rate_ms": ms_er, "decode_ms": ms_dec, "utt_per_s_job": world * N / ms_all * 1e3,
+        "decode_GBs": lg.numel() * 4 / ms_dec / 1e6, "checked": ok,
+    }
+    del lg, ref, hyp
+    if rank != 0:
+        return out
+    # C3: fused search N=1024, T=1000, V=1000
+    T, N, V = 1000, 1024, 1000
+    lg = peaky_logits(T, N, V, device, 0x5EED0003)
+    ms = event_ms(lambda: F.ctc_prefix_search(lg, K), reps=3, warm=1)
+    out["C3_search"] = {"workload": "ctc_prefix_search N=1024 T=1000 V=1000 K=16", "ms": ms,
+                        "utt_per_s": N / ms * 1e3, "GBs": lg.numel() * 4 / ms / 1e6}
+    # C3: the bare step functions with S=100 rows of real history
+    S = 100
+    nb, b = torch.zeros((N, 1), device=device), torch.ones((N, 1), device=device)
+    yh = torch.zeros((0, N, 1), dtype=torch.long, device=device)
+    last = lens = torch.zeros((N, 1), dtype=torch.long, device=device)
+    isp = torch.ones((N, 1, 1), dtype=torch.bool, device=device)
+    step_args = None
+    for t in range(S + 1):
+        p = lg[t].softmax(1)
+        nonext, blank = p[:, :V].contiguous(), p[:, V].contiguous()
+        step_args = ((nonext.unsqueeze(1).expand(N, nb.shape[1], V), nonext, blank), K, (nb, b), yh, last, lens, isp)
+        if t < S:
+            yh, last, lens, (nb, b), isp, _, _ = F.ctc_prefix_search_advance(*step_args)
+    ms = event_ms(lambda: F.ctc_prefix_search_advance(*step_args))
+    out["C3_ctc_prefix_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms}
+    g = torch.Generator(device=device).manual_seed(4)
+    lpt = torch.randn((N, K, V), device=device, generator=g).log_softmax(-1)
+    lpp = torch.randn((N, K), device=device, generator=g)
+    yb = torch.randint(0, V, (S, N, K), device=device, generator=g)
+    ybl = torch.full((N, K), S, device=device)
+    ms = event_ms(lambda: F.beam_search_advance(lpt, K, lpp, yb, ybl))
+    out["C3_beam_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms}
+    del lg, lpt, yb, step_args
+    # C4: SpecAugment N=2048 x 1000 x 80
+    N, T, Fq = 2048, 1000, 80
+    g = torch.Generator(device=device).manual_seed(7)
+    feats = torch.randn((N, T, Fq), device=device, generator=g)
+    lens = torch.randint(500, T + 1, (N,), device=device, generator=g)
+    sa = M.SpecAugment(max_time_warp=80.0, max_freq_warp=0.0, max_time_mask=100, max_freq_mask=27,
+                       max_time_mask_proportion=0.04, num_time_mask=2, num_time_mask_proportion=1.0,
+                       num_freq_mask=2, interpolation_order=1)
+    params = sa.draw_parameters(feats, lens)
+    ms = event_ms(lambda: sa.apply_parameters(feats, params, lens))
+    out["C4_spec_augment_apply"] = {"workload": "N=2048 T=1000 F=80, 2 time + 2 freq masks + time warp", "ms": ms,
+                                    "utt_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6}
+    ms = event_ms(lambda: sa(feats, lens))
+    out["C4_SpecAugment_forward"] = {"workload": "draw + apply", "ms": ms, "utt_per_s": N / ms * 1e3}
+    img = feats.view(N, 1, T, Fq)
+    src = torch.rand((N, 3, 2), device=device, generator=g) * torch.tensor([T - 1.0, Fq - 1.0], device=device)
+    dst = src + torch.randn((N, 3, 2), device=device, generator=g)
+    ms = event_ms(lambda: F.sparse_image_warp(img, src, dst, pinned_boundary_points=1, include_flow=False),
+                  reps=3, warm=1)
+    out["C4_sparse_image_warp"] = {"workload": "(2048,1,1000,80), 3 control + 4 pinned points, order 2", "ms": ms,
+                                   "img_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6}
+    return out
+
+
+def ctc_kernel_name(V, W):
+    """The instantiation the library launches for this row length (include/pdt_amd.h)."""
+    from pydrobert_amd import _cabi
+
+    plan = (ctypes.c_int32 * 4)()
+    if _cabi.lib().pdt_ctc_prefix_search_plan(V, W, plan) != 0:
+        return "pdt::ctc_search_kernel"
+    nt = V // 64 if (plan[3] and V // 64 == 4) else -1
+    return "pdt::ctc_search_kernel<{}, {}, {}>".format(plan[0], nt, "true" if plan[3] else "false")
+
+
+def rendezvous_only(args, world, rank):
+    """Preflight of the launch path alone: N ranks, one all-gather, no kernels."""
+    import torch.distributed as dist
+
+    backend = os.environ.get("PDT_BENCH_BACKEND", "nccl")
+    dev = torch.device("cpu")
+    if backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dev = torch.device("cuda", torch.cuda.current_device())
+    if world > 1:
+        dist.init_process_group(backend)
+    mine = torch.full((3,), float(rank), device=dev)
+    parts = [torch.empty_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, mine)
+    else:
+        parts = [mine]
+    ok = all(bool((p == r).all()) for r, p in enumerate(parts))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"rendezvous": "ok" if ok else "failed", "n_gpus": world, "backend": backend}), flush=True)
+    if not ok:
+        raise SystemExit(4)
+
+
+def run_rank(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus {} but WORLD_SIZE={}".format(args.gpus, world))
+    if args.rendezvous_only:
+        return rendezvous_only(args, world, rank)
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
@@ -107,26 +371,44 @@ def main():
             dist.init_process_group("nccl", device_id=device)
         else:
             dist.init_process_group(backend)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("asked for {} ranks, {} came up".format(args.gpus, dist.get_world_size()))
 
     from pydrobert_amd import functional as F
+    from pydrobert_amd import modules as M
 
-    ref, hyp = make_inputs(args, rank, device)
+    ref, hyp = make_tokens(args, rank, device)
     N, T = args.N, args.T
     gathered = torch.empty((world * N,), device=device, dtype=torch.float) if world > 1 else None
 
     ops = ["error_rate", "prefix_error_rates", "optimal_completion"]
-    have_decode = (not args.no_decode) and hasattr(F, "ctc_prefix_search")
+    have_decode = not args.no_decode
     logits = None
     if have_decode:
         ops.append("ctc_prefix_search")
-        g = torch.Generator(device=device).manual_seed(0x5EED0003 + rank)
-        logits = torch.randn((T, N, args.V + 1), device=device, generator=g)
-        peak = torch.randint(0, args.V + 1, (T, N, 1), device=device, generator=g)
-        logits.scatter_add_(2, peak, torch.full((T, N, 1), 12.0, device=device))
-        del peak
+        logits = peaky_logits(T, N, args.V, device, 0x5EED0003 + rank, chunk=T)
     if world > 1:
         ops.append("all_gather")
     C_seen = [0]
+
+    def gather(er):
+        if dist.get_backend() == "nccl":
+            dist.all_gather_into_tensor(gathered, er)
+        else:
+            parts = [torch.empty(N) for _ in range(world)]
+            dist.all_gather(parts, er.cpu())
+            gathered.copy_(torch.cat(parts))
+
+    def agree(flag):
+        """True on every rank only if `flag` holds on every rank."""
+        if world == 1:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], device=device if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    def gather_check(got, want):
+        return agree(torch.equal(got, want))
 
     def step(events=None):
         k = 0
@@ -149,17 +431,22 @@ def main():
             F.ctc_prefix_search(logits, args.beam)
             mark()
         if world > 1:
-            if dist.get_backend() == "nccl":
-                dist.all_gather_into_tensor(gathered, er)
-            else:
-                parts = [torch.empty(N) for _ in range(world)]
-                dist.all_gather(parts, er.cpu())
-                gathered.copy_(torch.cat(parts))
+            gather(er)
             mark()
         return er
 
     for _ in range(args.warmup):
         step()
+    if world > 1:
+        # once, before timing: the gathered vector is the concatenation of every rank's shard
+        # (each rank regenerates every shard's tokens from the rank's seed and scores them itself)
+        step()
+        good = True
+        for r in range(world):
+            rr, hh = make_tokens(args, r, device)
+            good = good and torch.equal(gathered[r * N:(r + 1) * N], F.error_rate(rr, hh, warn=False))
+        if not agree(good):
+            raise SystemExit("rank {}: gathered error rates differ from the shards'".format(rank))
     evs = [
         [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
         for _ in range(args.steps)
@@ -200,29 +487,34 @@ def main():
         "error_rate": "pdt::lev_skewed_kernel<false>",
         "prefix_error_rates": "pdt::lev_skewed_kernel<false>",
         "optimal_completion": "pdt::lev_rowsync_kernel<false,false> + pdt::oc_expand_kernel",
-        "ctc_prefix_search": "pdt::ctc_search_kernel<1, 4>",
+        "ctc_prefix_search": ctc_kernel_name(args.V, args.beam),
     }
-    # HBM bytes per launch from rocprofv3 PMC passes (profiles/), only for the profiled config
-    traffic = None
-    valu = None
-    tpath = os.path.join(ROOT, "profiles", "r01_ctc_traffic.json")
+    # HBM bytes per launch and instruction counts from the rocprofv3 PMC passes (profiles/), only
+    # when they were collected for this very configuration
+    traffic, valu = None, None
+    tpath = os.path.join(ROOT, "profiles", "r02_ctc_traffic.json")
     if dom == "ctc_prefix_search" and os.path.exists(tpath):
         rec = json.load(open(tpath))
-        if rec["config"] == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
-            traffic = rec["hbm_bytes_per_launch"]
+        if rec.get("config") == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
+            traffic = rec.get("hbm_bytes_per_launch")
             if "sq" in rec:
-                # what actually bounds this kernel: VALU issue.  A wave64 VALU instruction holds
-                # its SIMD for 4 cycles; 256 CUs x 4 SIMDs at 2.4 GHz (MI355X_MICROARCH.md).
                 insts = rec["sq"]["SQ_INSTS_VALU_per_launch"]
+                cyc = rec["sq"].get("valu_issue_cycles_per_inst_measured")
                 valu = {
                     "wave_insts_per_launch": insts,
-                    "pipe_busy_frac": insts * 4 / (1024 * 2.4e9 * op_ms[dom] * 1e-3),
-                    "source": "profiles/r01_ctc_sq_counters.csv (rocprofv3 --pmc SQ_INSTS_VALU)",
+                    "issue_cycles_per_wave_inst": cyc,
+                    "pipe_busy_frac": None if cyc is None else insts * cyc / (1024 * 2.4e9 * op_ms[dom] * 1e-3),
+                    "source": "profiles/r02_ctc_sq_counters.csv (SQ_INSTS_VALU), profiles/r02_valu_issue.json "
+                              "(measured issue cycles per wave64 VALU instruction at 8 waves/SIMD)",
                 }
+
+    extra = None
+    if not args.no_extra and have_decode:
+        extra = other_configs(F, M, device, world, rank, dist, gather_check)
 
     if rank == 0:
         out = {
-            "metric": "utterances/sec (N=4096,T=512) error_rate+ctc_beam at 1/2/4/8 GPU",
+            "metric": METRIC,
             "value": world * N * args.steps / dt,
             "unit": "utterances/s",
             "n_gpus": world,
@@ -235,9 +527,10 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE configs[1] shapes per GPU: " + " + ".join(ops),
+                "workload": "BASELINE configs[1] shapes on every GPU (its own N utterances): " + " + ".join(ops),
                 "N_per_gpu": N, "T_ref": T, "T_hyp": T, "V": args.V, "beam": args.beam,
                 "optimal_completion_C": C, "sharding": "batch axis, {} rank(s)".format(world),
+                "gather_verified": world > 1,
             },
             "op_ms": op_ms,
             "roofline": {
@@ -252,13 +545,27 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "valu": valu,
+                "note": "priced against HBM as the contract asks; the kernel's own limiter is the "
+                        "consumer wave's dependent instruction chain (DESIGN.md section 4.3)",
             },
         }
+        if extra is not None:
+            out["other_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, have_decode)
-        print(json.dumps(out))
+            out["cpu_baseline"] = cpu_baseline(args, have_decode, op_ms)
+        print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be positive")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
+    run_rank(args)
 
 
 if __name__ == "__main__":

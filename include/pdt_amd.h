@@ -124,9 +124,17 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, width) bytes of scratch
  *          (the prefix trie: one (parent, token) record per frame and beam entry, and the
  *          checkpoints of the output walk).
- *   width <= 32.
+ *   width <= 32.  S must be at least min(T, max lens): frames beyond S are not decoded.
+ *   Rows of up to about 16 000 tokens fit (one row of probabilities per ring slot in the
+ *   160 KB of LDS); longer ones return PDT_E_TOO_LONG.
+ * pdt_ctc_prefix_search_plan (host only, no device work): the launch configuration the library
+ *   picks for rows of V tokens and this width -- plan4 = {producer waves per utterance, ring
+ *   slots, utterances per workgroup, 1 if a row is held in the producer's registers} -- or
+ *   PDT_E_TOO_LONG.  Lets callers and tests see where the configurations change.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t width);
+
+int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4);
 
 int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st,
                           int64_t lg_sn, int64_t lg_sv, const int64_t *lens, int64_t width,

@@ -121,9 +121,14 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 // NT >= 0 (P = 1 only): the number of full 64-token chunks of a row, V / 64, as a compile-time
 // constant -- the row pass then has no chunk predicates to evaluate (instantiated for the
 // byte-sized vocabularies V = 256..319; NT = -1: any V).
-template <int P, int NT = -1>
-__global__ void __launch_bounds__(256, P == 1 ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
+// INREG (P = 1 only): the whole row, V + 1 <= 512 elements, sits in the eight prefetch registers
+// of the producer's lanes.  P = 1 without it is the last resort for rows so long that only a
+// two-slot ring of one producer fits in LDS: the generic LDS-staged row pass of the P > 1 forms.
+template <int P, int NT = -1, bool INREG = (P == 1)>
+__global__ void __launch_bounds__(256, INREG ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
+  static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
+  static_assert(NT < 0 || INREG, "compile-time chunk counts belong to the register-resident row pass");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   // (wave-uniform by construction; telling the compiler keeps the utterance index and every
@@ -132,8 +137,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   const int u = wave / (P + 1);
   const int role = wave - u * (P + 1);  // 0 .. P-1: producer, P: consumer
   const bool producer = role < P;
-  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
-  if (u >= rl.utt_per_wg || n >= a.N) return;
+  // (clamped: the odd utterance of the last workgroup has no work, but its waves still reach the
+  // workgroup barrier below)
+  const int64_t n_raw = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
+  const bool idle = u >= rl.utt_per_wg || n_raw >= a.N;
+  const int64_t n = idle ? 0 : n_raw;
   const int V = a.V, W = a.W;
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
@@ -150,7 +158,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
   auto slot_pos = [&](int sl) { return reinterpret_cast<unsigned char *>(slot_p(sl) + PDT_WAVE); };
   auto slot_hdr = [&](int sl) { return reinterpret_cast<float *>(slot_pos(sl) + rl.pos_bytes); };
-  const int Tn = a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T;
+  // frames of this utterance; never more than the S rows of y the caller allocated
+  const int Tn = min(a.S, a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T);
   const int NS = rl.nstage;
 
 #ifdef PDT_STATS
@@ -159,13 +168,14 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     PDT_STAT(8 + (int)((hw >> 4) & 3u) * 2 + (producer ? 0 : 1));
   }
 #endif
-  if (producer) {
+  if (producer && !idle) {
     for (int sl = pr; sl < NS; sl += P)
       for (int v = lane; v < rl.pos_bytes; v += PDT_WAVE) slot_pos(sl)[v] = 0xFF;
     if (pr == 0 && lane <= 5)  // consumed, ready[0 .. 4), want_full
       __hip_atomic_store(&consumed[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   }
   __syncthreads();  // flags / pos tables initialised (the only workgroup barrier)
+  if (idle) return;
 
   if (producer) {
     // elements of the NEXT row of this wave held in registers while the current one is processed
@@ -181,7 +191,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     // the window) just takes the complete selection.  The consumer completes a short list itself
     // in the frames that turn out to need more.
     constexpr int kShortMin = PDT_SHORT_MIN, kShortMax = 32, kShortLo = PDT_SHORT_LO, kShortHi = PDT_SHORT_HI, kProbeRank = PDT_SHORT_PROBE;
-    const bool short_ok = P == 1 && W <= 16 && V > PDT_WAVE;
+    const bool short_ok = INREG && W <= 16 && V > PDT_WAVE;
     float thr_off = PDT_INF;  // no guess yet
     const int nt_ = NT >= 0 ? NT : V / PDT_WAVE, rem_ = V - nt_ * PDT_WAVE;  // full token chunks; lane of the blank
     const float inv_ntok = 1.0f / (float)(nt_ > 0 ? nt_ * PDT_WAVE : 1);
@@ -217,7 +227,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       unsigned tkey = 0xFFFFFFFFu;  // key of the guessed threshold (none: nothing survives)
       int nshort = 0;               // tokens at or above it
       float mean = 0.0f, mx_of_row = 0.0f;
-      if constexpr (P == 1) {
+      if constexpr (INREG) {
         // the whole row (V + 1 <= 512) sits in the prefetch registers: maximum, exponentials
         // and ordering keys come straight from them -- one LDS store per element instead of
         // store + load + store + load.  Chunks i < nt hold tokens in every lane (wave-uniform
@@ -326,7 +336,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         {
           const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
           int v = lane + kPrefetch * PDT_WAVE;
-          if constexpr (P > 1) {  // long rows: kBatch loads in flight
+          if constexpr (!INREG) {  // long rows: kBatch loads in flight
             for (; v + (kBatch - 1) * PDT_WAVE <= V; v += kBatch * PDT_WAVE) {
               float x[kBatch];
 #pragma unroll
@@ -357,7 +367,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         mx = wave_max_f(mx);
         {
           int v = lane;
-          if constexpr (P > 1) {
+          if constexpr (!INREG) {
             for (; v + 7 * PDT_WAVE <= V; v += 8 * PDT_WAVE) {
               float x[8];
 #pragma unroll
@@ -409,8 +419,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       } else {
         PDT_STAT(nshort > kShortMax ? 3 : 2);
         unsigned probe = 0u;
-        build_shared_list<(P > 1)>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos, P == 1 ? &lmax : nullptr,
-                                   &probe, kProbeRank);
+        build_shared_list<!INREG>(p, inv, V, M, surv, tl_tok, slot_p(sl), pos, INREG ? &lmax : nullptr,
+                                  &probe, kProbeRank);
         // logit offset (from the row mean) of the kProbeRank-th largest per-lane maximum
         if (short_ok) thr_off = mx_of_row + __logf(fkey_nonneg_inv(probe)) - mean;
       }
@@ -565,16 +575,16 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #endif
 }
 
-template <int P, int NT = -1>
+template <int P, int NT = -1, bool INREG = (P == 1)>
 static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL((ctc_search_kernel<P, NT>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
+  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
                      stream, a, rl);
   return (int)hipGetLastError();
 }
@@ -588,26 +598,46 @@ __host__ inline int ckpt_shift_for(int T, int V, int W) {
   return sh;
 }
 
-int launch_ctc_search(CtcArgs a, hipStream_t stream) {
-  if (a.W < 1 || a.W > kMaxWidth) return PDT_E_TOO_LONG;
+// Launch configuration for rows of V tokens and beam width W: producer waves per utterance
+// (P), ring depth, utterances per workgroup, whether the row lives in the producer's registers.
+struct CtcPlan {
+  int producers, nstage, utt_per_wg, inreg;
+};
+__host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl) {
+  if (W < 1 || W > kMaxWidth) return PDT_E_TOO_LONG;
   const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
   // Long rows: one producer wave per frame is the bottleneck and LDS (not registers) bounds
   // the occupancy, so three producers share the frames of an utterance (one utterance per
-  // workgroup); fall back to two, then one, when the ring does not fit.
-  if (a.V + 1 > 8 * PDT_WAVE) {
-    RingLayout rl = ring_layout(a.V, a.W, 4, 1, 3);
-    if ((size_t)rl.utt_bytes * 2 <= hard_cap) return launch_ctc_search_p<3>(a, rl, stream);
-    rl = ring_layout(a.V, a.W, 3, 1, 2);
-    if ((size_t)rl.utt_bytes <= hard_cap) return launch_ctc_search_p<2>(a, rl, stream);
+  // workgroup); fall back to two, then to one producer with a two-slot ring.
+  if (V + 1 > 8 * PDT_WAVE) {
+    *rl = ring_layout(V, W, 4, 1, 3);
+    if ((size_t)rl->utt_bytes * 2 <= hard_cap) return *plan = CtcPlan{3, 4, 1, 0}, PDT_OK;
+    *rl = ring_layout(V, W, 3, 1, 2);
+    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{2, 3, 1, 0}, PDT_OK;
+    // the longest rows LDS can hold at all
+    *rl = ring_layout(V, W, 2, 1, 1);
+    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{1, 2, 1, 0}, PDT_OK;
+    return PDT_E_TOO_LONG;
   }
   // ring depth and utterances per workgroup from the LDS budget
   int nstage = PDT_RING_STAGES, upw = PDT_UTT_PER_WG;
-  RingLayout rl = ring_layout(a.V, a.W, nstage, upw, 1);
-  while ((size_t)rl.utt_bytes * upw > soft_cap && (upw > 1 || nstage > 2)) {
+  *rl = ring_layout(V, W, nstage, upw, 1);
+  while ((size_t)rl->utt_bytes * upw > soft_cap && (upw > 1 || nstage > 2)) {
     if (upw > 1) upw = 1; else nstage = 2;
-    rl = ring_layout(a.V, a.W, nstage, upw, 1);
+    *rl = ring_layout(V, W, nstage, upw, 1);
   }
-  if ((size_t)rl.utt_bytes * upw > hard_cap) return PDT_E_TOO_LONG;
+  if ((size_t)rl->utt_bytes * upw > hard_cap) return PDT_E_TOO_LONG;
+  return *plan = CtcPlan{1, nstage, upw, 1}, PDT_OK;
+}
+
+int launch_ctc_search(CtcArgs a, hipStream_t stream) {
+  CtcPlan plan;
+  RingLayout rl;
+  const int rc = plan_ctc_search(a.V, a.W, &plan, &rl);
+  if (rc != PDT_OK) return rc;
+  if (plan.producers == 3) return launch_ctc_search_p<3>(a, rl, stream);
+  if (plan.producers == 2) return launch_ctc_search_p<2>(a, rl, stream);
+  if (!plan.inreg) return launch_ctc_search_p<1, -1, false>(a, rl, stream);
   if (a.V / PDT_WAVE == 4) return launch_ctc_search_p<1, 4>(a, rl, stream);
   return launch_ctc_search_p<1>(a, rl, stream);
 }
@@ -620,6 +650,17 @@ int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t widt
   if (T < 0 || N < 0 || width < 0) return 0;
   // trie records + checkpoints (at most one per 32 frames)
   return (T + T / 32 + 1) * N * width * (int64_t)sizeof(int2) + 16;
+}
+
+int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4) {
+  if (V < 1 || width < 1 || !plan4) return PDT_E_ARG;
+  if (V >= (1 << 30)) return PDT_E_TOO_LONG;
+  pdt::CtcPlan plan;
+  pdt::RingLayout rl;
+  const int rc = pdt::plan_ctc_search((int)V, (int)width, &plan, &rl);
+  if (rc != PDT_OK) return rc;
+  plan4[0] = plan.producers; plan4[1] = plan.nstage; plan4[2] = plan.utt_per_wg; plan4[3] = plan.inreg;
+  return PDT_OK;
 }
 
 int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st,

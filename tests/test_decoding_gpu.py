@@ -50,19 +50,68 @@ def test_ctc_prefix_search_random(device, V, K):
         _check_search(act, exp, (V, K, T, N))
 
 
-@pytest.mark.parametrize("V,K", [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4)])
+def _ctc_plan(V, K):
+    """(status, (producers, ring slots, utterances per workgroup, row in registers)) the library
+    picks for rows of V tokens (host arithmetic only: include/pdt_amd.h)."""
+    import ctypes
+
+    from pydrobert_amd import _cabi
+
+    out = (ctypes.c_int32 * 4)()
+    rc = _cabi.lib().pdt_ctc_prefix_search_plan(V, K, out)
+    return rc, tuple(out)
+
+
+def _plan_boundaries(K, hi=17000):
+    """Every V at which the launch configuration changes, found from the library's own answer."""
+    edges, lo = [], 1
+    while True:
+        cur = _ctc_plan(lo, K)
+        if _ctc_plan(hi, K) == cur:
+            return edges
+        a, b = lo, hi  # plan(a) == cur != plan(b): bisect the first change
+        while b - a > 1:
+            m = (a + b) // 2
+            if _ctc_plan(m, K) == cur:
+                a = m
+            else:
+                b = m
+        edges.append(b)
+        lo = b
+
+
+def _long_row_cases():
+    cases = [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4), (11000, 16), (15000, 8)]
+    for K in (16, 32):
+        for edge in _plan_boundaries(K):
+            if _ctc_plan(edge, K)[0] == 0:
+                cases += [(edge - 1, K), (edge, K)]  # one V on each side of every change
+            else:
+                cases += [(edge - 1, K)]  # the longest row that still fits
+    return sorted(set(cases))
+
+
+@pytest.mark.parametrize("V,K", _long_row_cases())
 def test_ctc_prefix_search_long_rows(device, V, K):
-    """Vocabularies beyond 512: several producer waves share an utterance's frames (three for
-    V = 513..~3700, two beyond, one when even that ring does not fit); ragged lens shorter than
-    the number of producers included."""
+    """Vocabularies beyond 511: several producer waves share an utterance's frames (three, then
+    two as the ring grows), finally one producer with a two-slot ring; one V on each side of
+    every change of configuration, ragged lens shorter than the number of producers included."""
     rng = np.random.default_rng(7000 + V)
-    for it, (T, N) in enumerate([(2, 3), (25, 5), (61, 2)]):
-        lg = _peaky_logits(rng, T, N, V, scale=11.0)
+    for it, (T, N) in enumerate([(2, 3), (25, 5), (61, 2)] if V < 10000 else [(2, 3), (23, 3)]):
+        lg = _peaky_logits(rng, T, N, V, scale=11.0 if V < 10000 else 13.0)
         lens = None if it == 1 else rng.integers(0, T + 1, N)
         exp = oracle.ctc_prefix_search(lg, K, lens)
         act = F.ctc_prefix_search(torch.from_numpy(lg).to(device), K,
                                   None if lens is None else torch.from_numpy(lens).to(device))  # fmt: skip
-        _check_search(act, exp, (V, K, T, N))
+        _check_search(act, exp, (V, K, T, N, _ctc_plan(V, K)))
+
+
+def test_ctc_prefix_search_rows_too_long(device):
+    """Rows that no ring holds raise (the reference has no limit)."""
+    edge = _plan_boundaries(16)[-1]
+    assert _ctc_plan(edge, 16)[0] != 0 and _ctc_plan(edge - 1, 16)[0] == 0
+    with pytest.raises(RuntimeError, match="too long"):
+        F.ctc_prefix_search(torch.zeros(2, 1, edge + 1, device=device), 16)
 
 
 def test_ctc_prefix_search_golden_shape(device):
