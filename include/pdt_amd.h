@@ -63,6 +63,17 @@ int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
             int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * fill_after_eos (_string.py:30-42): out = value, except that every position strictly after
+ * the first `eos` along the sequence dimension holds the fill value.
+ *   tokens int64, value / out of elem_bytes (1, 2, 4 or 8) per element, all contiguous and
+ *   viewed as (outer, L, inner) around the sequence dimension; fill_bits = the fill value's bit
+ *   pattern in the low elem_bytes bytes.
+ * ------------------------------------------------------------------------------------- */
+int pdt_fill_after_eos(const int64_t *tokens, int64_t outer, int64_t L, int64_t inner,
+                       int64_t eos, const void *value, int64_t elem_bytes, int64_t fill_bits,
+                       void *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimal completion, two phases (optimal_completion, _string.py:464-517; the DP is
  * _string_matching with return_mask=True, :271-278, :319-355).
  *

@@ -1,8 +1,9 @@
 """ORACLE -- TEST INFRASTRUCTURE ONLY.  numpy restatement of ctc_greedy_search (reference
-_decoding.py:507-558) and sequence_log_probs on tensors (_decoding.py:1516-1551)."""
+_decoding.py:507-558), sequence_log_probs on tensors (_decoding.py:1516-1551) and
+fill_after_eos (_string.py:30-42)."""
 import numpy as np
 
-__all__ = ["ctc_greedy_search", "sequence_log_probs"]
+__all__ = ["ctc_greedy_search", "fill_after_eos", "sequence_log_probs"]
 
 
 def _np(x, dt=None):
@@ -58,3 +59,15 @@ def sequence_log_probs(logits, hyp, dim=0, eos=None):
     idx = np.where(mask, 0, h)
     lp = np.take_along_axis(x, idx[..., None], -1)[..., 0]
     return np.where(mask, 0.0, lp).sum(dim).astype(np.float32)
+
+
+def fill_after_eos(tokens, eos, dim=0, fill=None, value=None):
+    """_string.py:30-42: positions strictly after the first eos along dim take the fill value
+    (default: eos), converted to the dtype of the tensor being filled."""
+    tok = _np(tokens)
+    out = (tok if value is None else _np(value)).copy()
+    hit = tok == eos
+    seen = np.cumsum(hit, axis=dim) - hit  # eos occurrences at earlier positions
+    fill_ = float(eos) if fill is None else fill
+    out[np.broadcast_to(seen > 0, out.shape)] = np.asarray(fill_).astype(out.dtype)
+    return out

@@ -33,6 +33,7 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
         + [_INT, _INT, _INT, _F, _INT, _P, _I64, _I64, _P, _P, _P, _P],
     ),
+    "pdt_fill_after_eos": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P]),
     "pdt_oc_mask_words": (_I64, [_I64]),
     "pdt_oc_mask": (
         _INT,

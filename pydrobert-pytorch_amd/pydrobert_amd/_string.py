@@ -34,6 +34,69 @@ __all__ = [
 ]
 
 
+@custom_op("pydrobert_amd::fill_after_eos", mutates_args=())
+def _fill_after_eos_op(tokens: torch.Tensor, eos: int, dim: int, fill: float, value: torch.Tensor) -> torch.Tensor:
+    """One walk along ``dim`` (reference _string.py:30-42; csrc/fill_after_eos.hip)."""
+    device = _cabi.require_hip(tokens, value)
+    if value.shape != tokens.shape:  # masked_fill would broadcast; the reference's callers never do
+        value = value.expand(torch.broadcast_shapes(value.shape, tokens.shape))
+        tokens = tokens.expand(value.shape)
+    nd = tokens.dim()
+    if nd == 0:
+        return value.clone()
+    if dim < -nd or dim >= nd:
+        raise IndexError(
+            "Dimension out of range (expected to be in range of [{}, {}], but got {})".format(-nd, nd - 1, dim)
+        )
+    dim = dim % nd
+    if tokens.dtype == torch.long:
+        tok, eos_ = tokens.detach().contiguous(), int(eos)
+    else:  # any dtype compares against eos the way ``tokens == eos`` does
+        tok, eos_ = (tokens.detach() == eos).long().contiguous(), 1
+    val = value.detach().contiguous()
+    if val.dtype.is_complex:
+        raise RuntimeError("fill_after_eos: complex values are not supported")
+    out = torch.empty_like(val)
+    # the fill value converted the way masked_fill converts its scalar, then its raw bits
+    one = torch.full((1,), fill, dtype=val.dtype)
+    bits = int(one.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[val.element_size()]).item())
+    outer = 1
+    for d in range(dim):
+        outer *= tok.shape[d]
+    L = tok.shape[dim]
+    inner = tok.numel() // max(1, outer * L) if outer * L else 0
+    with torch.cuda.device(device):
+        rc = _cabi.lib().pdt_fill_after_eos(
+            _cabi.ptr(tok), outer, L, inner, eos_, _cabi.ptr(val), val.element_size(),
+            bits, _cabi.ptr(out), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_fill_after_eos")
+    return out
+
+
+@_fill_after_eos_op.register_fake
+def _(tokens, eos, dim, fill, value):
+    return torch.empty_like(value.expand(torch.broadcast_shapes(value.shape, tokens.shape)), memory_format=torch.contiguous_format)
+
+
+def _fill_after_eos_backward(ctx, grad):
+    # masked_fill's adjoint: the gradient passes where the value was kept
+    tokens, = ctx.saved_tensors
+    g = torch.ops.pydrobert_amd.fill_after_eos(tokens, ctx.eos, ctx.dim, 0.0, grad)
+    if g.shape != ctx.value_shape:
+        g = g.sum_to_size(ctx.value_shape)
+    return None, None, None, None, g
+
+
+def _fill_after_eos_setup(ctx, inputs, output):
+    tokens, eos, dim, fill, value = inputs
+    ctx.save_for_backward(tokens)
+    ctx.eos, ctx.dim, ctx.value_shape = eos, dim, value.shape
+
+
+register_autograd("pydrobert_amd::fill_after_eos", _fill_after_eos_backward, setup_context=_fill_after_eos_setup)
+
+
 def fill_after_eos(
     tokens: torch.Tensor,
     eos: int,
@@ -44,10 +107,7 @@ def fill_after_eos(
     """Fill everything after the first ``eos`` along ``dim`` (reference _string.py:30-42)."""
     out = tokens if value is None else value
     fill_ = float(eos) if fill is None else fill
-    is_eos = tokens == eos
-    # strictly after the first eos: an eos has been seen at an earlier index
-    seen = is_eos.long().cumsum(dim) - is_eos.long()
-    return out.masked_fill(seen > 0, fill_)
+    return torch.ops.pydrobert_amd.fill_after_eos(tokens, eos, dim, fill_, out)
 
 
 def _seq_strides(t: torch.Tensor, batch_first: bool):

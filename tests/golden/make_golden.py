@@ -464,3 +464,27 @@ def search_sweep_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "sweep"):
     search_sweep_goldens()
+
+
+def fill_goldens():
+    """fill_after_eos (_string.py:30-42): every dim of a 3-D tensor, default and explicit fill,
+    a separate value tensor (float and bool), rows with no / several / leading eos."""
+    rng = np.random.default_rng(0x5EED0009)
+    tok = rng.integers(0, 4, (7, 5, 6))
+    tok[:, 0, 0] = 1  # no eos in this column
+    tok[0, 1, :] = 3  # eos first along dim 0
+    val = rng.normal(size=tok.shape).astype(np.float32)
+    valb = rng.integers(0, 2, tok.shape).astype(bool)
+    d = dict(tokens=tok, value=val, value_bool=valb, eos=np.array(3))
+    t = torch.from_numpy(tok)
+    for dim in (0, 1, 2, -1):
+        d["default_d%d" % dim] = F.fill_after_eos(t, 3, dim)
+        d["fill_d%d" % dim] = F.fill_after_eos(t, 3, dim, -7.0)
+        d["value_d%d" % dim] = F.fill_after_eos(t, 3, dim, 0.5, torch.from_numpy(val))
+        d["bool_d%d" % dim] = F.fill_after_eos(t, 3, dim, 1.0, torch.from_numpy(valb))
+    d["module"] = M.FillAfterEndOfSequence(3, 1, 9.0)(t)
+    save("fill", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "fill"):
+    fill_goldens()

@@ -117,13 +117,13 @@ def test_shape_errors_precede_device_checks():
         F.spec_augment(torch.zeros(2, 4, 3), 1.0, 0.0, 1, 1, 0.1, 1, 0.1, 1, 1, torch.tensor([0, 4]))
 
 
-def test_fill_after_eos_semantics():
+def test_fill_after_eos_needs_a_device():
+    """No CPU path in the product (the semantics are checked on the GPU, tests/test_string_gpu.py)."""
     tok = torch.tensor([[1, 2], [0, 3], [4, 0], [0, 5]])
-    out = F.fill_after_eos(tok, 0, 0, -1)
-    assert out.t().tolist() == [[1, 0, -1, -1], [2, 3, 0, -1]]
-    assert M.FillAfterEndOfSequence(0)(tok).t().tolist() == [[1, 0, 0, 0], [2, 3, 0, 0]]
-    val = torch.arange(8.0).view(4, 2)
-    assert F.fill_after_eos(tok, 0, 0, 9.0, val)[:, 0].tolist() == [0.0, 2.0, 9.0, 9.0]
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.fill_after_eos(tok, 0, 0, -1)
+    with pytest.raises(RuntimeError, match="ROCm"):
+        M.FillAfterEndOfSequence(0)(tok)
 
 
 def test_lm_interface_forward_idx_normalisation():

@@ -288,3 +288,46 @@ def test_optimal_completion_long_reference(device):
     too_long = torch.zeros((2049, 2), dtype=torch.long, device=device)
     with pytest.raises(RuntimeError, match="too long|limit|supported"):
         F.optimal_completion(too_long, hyp2, warn=False)
+
+
+def test_fill_after_eos(device):
+    """a7: the reference's own outputs (tests/golden/fill.npz), the oracle on random shapes, every
+    dtype class of the value tensor, strided views, the module, and the gradient w.r.t. value."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "fill.npz"))
+    tok, eos = torch.from_numpy(g["tokens"]).to(device), int(g["eos"])
+    val, valb = torch.from_numpy(g["value"]).to(device), torch.from_numpy(g["value_bool"]).to(device)
+    for dim in (0, 1, 2, -1):
+        assert np.array_equal(F.fill_after_eos(tok, eos, dim).cpu().numpy(), g["default_d%d" % dim])
+        assert np.array_equal(F.fill_after_eos(tok, eos, dim, -7.0).cpu().numpy(), g["fill_d%d" % dim])
+        assert np.array_equal(F.fill_after_eos(tok, eos, dim, 0.5, val).cpu().numpy(), g["value_d%d" % dim])
+        assert np.array_equal(F.fill_after_eos(tok, eos, dim, 1.0, valb).cpu().numpy(), g["bool_d%d" % dim])
+    assert np.array_equal(M.FillAfterEndOfSequence(eos, 1, 9.0)(tok).cpu().numpy(), g["module"])
+    # hand case of the reference's docstring form
+    t2 = torch.tensor([[1, 2], [0, 3], [4, 0], [0, 5]], device=device)
+    assert F.fill_after_eos(t2, 0, 0, -1).t().tolist() == [[1, 0, -1, -1], [2, 3, 0, -1]]
+    assert M.FillAfterEndOfSequence(0)(t2).t().tolist() == [[1, 0, 0, 0], [2, 3, 0, 0]]
+    rng = np.random.default_rng(17)
+    for shape in [(1,), (130,), (70, 3), (3, 70), (5, 129, 4), (2, 3, 4, 5), (0, 4), (64, 64)]:
+        tk = rng.integers(0, 5, shape)
+        for dim in range(-1, len(shape)):
+            for dt in (np.float32, np.float64, np.int64, np.int32, np.int16, np.uint8, np.float16):
+                v = (rng.normal(size=shape) * 20).astype(dt)
+                exp = oracle.fill_after_eos(tk, 2, dim, 3.0, v)
+                act = F.fill_after_eos(torch.from_numpy(tk).to(device), 2, dim, 3.0, torch.from_numpy(v).to(device))
+                assert act.dtype == torch.from_numpy(v).dtype and np.array_equal(act.cpu().numpy(), exp), (shape, dim, dt)
+    # non-int64 tokens and a strided (transposed) view
+    tk = rng.integers(0, 4, (33, 9))
+    tt = torch.from_numpy(np.ascontiguousarray(tk.T)).to(device).t()
+    assert not tt.is_contiguous()
+    assert np.array_equal(F.fill_after_eos(tt, 1, 0).cpu().numpy(), oracle.fill_after_eos(tk, 1, 0))
+    assert np.array_equal(F.fill_after_eos(tt.int(), 1, 1).cpu().numpy(), oracle.fill_after_eos(tk.astype(np.int32), 1, 1))
+    assert np.array_equal(F.fill_after_eos(tt.float(), 1, 0, 7.5).cpu().numpy(),
+                          oracle.fill_after_eos(tk.astype(np.float32), 1, 0, 7.5))
+    # gradient: passes where the value was kept
+    v = torch.randn((33, 9), device=device, requires_grad=True)
+    out = F.fill_after_eos(tt, 1, 0, 0.25, v)
+    (gv,) = torch.autograd.grad(out.sum(), v)
+    kept = torch.from_numpy(oracle.fill_after_eos(tk, 1, 0, 0.0, np.ones((33, 9), np.float32))).to(device)
+    assert torch.equal(gv, kept)
