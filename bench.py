@@ -148,7 +148,10 @@ def cpu_baseline(args, with_decode, op_ms):
 
     T, V, K = args.T, args.V, args.beam
     rng = np.random.default_rng(0x5EED0002)
+    # the box's CPU share, not the machine's core count: a GPU box gives 16 cores per GPU whatever
+    # the affinity mask says, and torch threads beyond the share only fight each other
     host = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    host = max(1, min(host, int(os.environ.get("PDT_BENCH_CPU_THREADS", "16"))))
     # utterances per call, sized so one call takes ~0.1-1 s (optimal_completion's (H, n, R, R)
     # closure is 134 MB per utterance at T = 512)
     chunk = {"error_rate": 16, "prefix_error_rates": 16, "optimal_completion": 2, "ctc_prefix_search": 16}
@@ -164,6 +167,7 @@ def cpu_baseline(args, with_decode, op_ms):
         torch.set_num_threads(threads)
         per = {}
         for name in names:
+            print("bench.py: cpu baseline, {} threads, {}".format(threads, name), file=sys.stderr, flush=True)
             n = chunk[name]
             ref = torch.from_numpy(rng.integers(0, V, (T, n)))
             hyp = torch.from_numpy(rng.integers(0, V, (T, n)))
@@ -508,9 +512,15 @@ def run_rank(args):
                               "(measured issue cycles per wave64 VALU instruction at 8 waves/SIMD)",
                 }
 
+    def say(msg):
+        if rank == 0:
+            print("bench.py: " + msg, file=sys.stderr, flush=True)
+
+    say("timed region done: {:.3f} ms per step".format(dt / args.steps * 1e3))
     extra = None
     if not args.no_extra and have_decode:
         extra = other_configs(F, M, device, world, rank, dist, gather_check)
+        say("other configs done")
 
     if rank == 0:
         out = {
@@ -553,6 +563,7 @@ def run_rank(args):
             out["other_configs"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, have_decode, op_ms)
+            say("cpu baseline done")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -424,11 +424,219 @@ oc_expand_kernel(const uint32_t *__restrict__ bitmask, const int64_t *__restrict
   }
 }
 
+// ---- phase 2, tiled form ---------------------------------------------------------------------
+// Two things hold the row-at-a-time form at 3.6 TB/s (measured, profiles/microbench `stores`):
+// a row is C * 8 bytes (992 at the bench shape), so almost every store instruction starts and
+// ends inside a 128-byte line (62-lane stores of such rows: 3.4 TB/s whatever their order, against
+// 5.5-6.2 for whole KiB); and vmcnt counts loads and stores together, in order, so a wave that
+// loads the next bitmask words after storing a row waits for that store to reach memory.
+// Here (a) the rows of NB consecutive utterances at one h -- or, batch-first, of NB consecutive h
+// of one utterance -- are ONE contiguous run of NB * C * 8 bytes: a wave expands them into an LDS
+// image of the run and streams it out with 16-byte stores, 1 KiB of consecutive bytes per
+// instruction; (b) a workgroup loads every bitmask word and class-token table it will need into
+// LDS up front, so its main loop issues no global load at all and never waits for a store.
+//   over_n = 1: tile = utterances n0 .. n0 + NB at one h; the workgroup owns `chunk` values of h
+//               and its four waves take them in turn;
+//   over_n = 0: tile = rows h0 .. h0 + NB of one utterance (one table); the workgroup owns
+//               `chunk` tiles.
+// A pass expands 64 / Wp rows at once (Wp = bitmask words per row rounded up to a power of two:
+// lane = (row, word)); positions inside a row come from one wave scan minus the scan value at
+// the row's first lane.  The image holds int32 indices into the token tables (-1 = padding), so
+// the per-bit loop only writes LDS and the tokens are looked up on the way out by all 64 lanes.
+struct OcTileArgs {
+  const uint32_t *bitmask;
+  const int64_t *class_tokens;
+  int64_t *targets;
+  int64_t N, padding, outer_stride;  // outer_stride: elements between tiles' outer index
+  int R, W, lgWp, Hout, C, NB, over_n, chunk, ntiles, wide;
+};
+
+__host__ __device__ inline size_t oc_tile_lds(int R, int W, int C, int NB, int over_n, int chunk, size_t *bm_off,
+                                              size_t *stage_off) {
+  const size_t ctok = (((size_t)(over_n ? NB : 1) * R + 1) & ~(size_t)1) * 8;
+  const size_t bm = (((size_t)chunk * NB * W + 3) & ~(size_t)3) * 4;  // rows of the chunk x W words
+  const size_t stage = (((size_t)NB * C + 3) & ~(size_t)3) * 4;
+  if (bm_off) *bm_off = ctok;
+  if (stage_off) *stage_off = ctok + bm;
+  return ctok + bm + 4 * stage;
+}
+
+__global__ void __launch_bounds__(256) oc_expand_tiles_kernel(const OcTileArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int C = a.C, NB = a.NB, W = a.W, R = a.R;
+  size_t bm_off, stage_off;
+  oc_tile_lds(R, W, C, NB, a.over_n, a.chunk, &bm_off, &stage_off);
+  int64_t *ctok = reinterpret_cast<int64_t *>(smem);
+  unsigned *bm = reinterpret_cast<unsigned *>(smem + bm_off);
+  int *stage = reinterpret_cast<int *>(smem + stage_off) + (size_t)wave * (((size_t)NB * C + 3) & ~(size_t)3);
+  const unsigned item = xcd_remap(blockIdx.x, gridDim.x);
+  // over_n: item = (h chunk, n tile); else item = (utterance, chunk of h tiles)
+  const int inner_items = a.over_n ? a.ntiles : (a.ntiles + a.chunk - 1) / a.chunk;
+  const int64_t outer = item / inner_items;
+  const int inner = (int)(item - outer * inner_items);
+  const int64_t n_first = a.over_n ? (int64_t)inner * NB : outer;
+  const int tabs_valid = a.over_n ? (int)min((int64_t)NB, a.N - n_first) : 1;
+  // the h rows this workgroup covers, and (over_n) the utterances of its tile
+  const int h_base = a.over_n ? (int)outer * a.chunk : inner * a.chunk * NB;
+  const int h_count = min(a.Hout - h_base, a.over_n ? a.chunk : a.chunk * NB);
+  // (eight loads in flight per thread: left to itself the compiler waits for every load before
+  // the LDS write that follows it, and a workgroup's preamble becomes 32 round trips to L2)
+  {  // the tables of consecutive utterances are one contiguous block of class_tokens
+    const int64_t *src = a.class_tokens + n_first * (int64_t)R;
+    const int total = tabs_valid * R;
+    for (int k0 = (int)threadIdx.x; k0 < total; k0 += 256 * 8) {
+      int64_t v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = k0 + q * 256 < total ? src[k0 + q * 256] : 0;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (k0 + q * 256 < total) ctok[k0 + q * 256] = v[q];
+    }
+  }
+  {  // bm[(hi * tabs_valid + u) * W + word]: tabs_valid * W consecutive words per h
+    const int per_h = tabs_valid * W, total = h_count * per_h;
+    for (int k0 = (int)threadIdx.x; k0 < total; k0 += 256 * 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = k0 + q * 256;
+        const int hi = k / per_h, r = k - hi * per_h;
+        v[q] = k < total ? a.bitmask[((int64_t)(h_base + hi) * a.N + n_first) * W + r] : 0u;
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (k0 + q * 256 < total) bm[k0 + q * 256] = v[q];
+    }
+  }
+  __syncthreads();  // from here on: LDS reads and global stores only
+  const int Wp = 1 << a.lgWp, rows_per_pass = PDT_WAVE >> a.lgWp;
+  const int ur = lane >> a.lgWp, word = lane & (Wp - 1);
+  const int seg = lane & ~(Wp - 1);
+  // the jobs of this wave: over_n -> h = h_base + wave, + 4, ...; else tiles of NB rows
+  const int j_end = a.over_n ? h_base + h_count : min(a.ntiles, (inner + 1) * a.chunk);
+  for (int j = (a.over_n ? h_base : inner * a.chunk) + wave; j < j_end; j += 4) {
+    const int h_first = a.over_n ? j : j * NB;
+    const int rows = a.over_n ? tabs_valid : min(NB, a.Hout - h_first);
+    // image of the run as indices into the class-token tables: -1 (padding) everywhere, then
+    // the classes of every row
+    {
+      const int4 neg = make_int4(-1, -1, -1, -1);
+      int4 *s4 = reinterpret_cast<int4 *>(stage);
+      for (int i = lane; i < (rows * C + 3) >> 2; i += PDT_WAVE) s4[i] = neg;
+    }
+    wave_sync();
+    for (int u0 = 0; u0 < rows; u0 += rows_per_pass) {
+      const int u = u0 + ur;
+      const bool live = u < rows && word < W;
+      // row (h, n) of the chunk: over_n -> (h_first, u), else (h_first + u, the utterance)
+      const int row = a.over_n ? (h_first - h_base) * tabs_valid + u : h_first - h_base + u;
+      unsigned w = live ? bm[row * W + word] : 0u;
+      const int cnt = __popc(w);
+      const int incl = wave_incl_scan_add(cnt);
+      const int before = __builtin_amdgcn_ds_bpermute((seg > 0 ? seg - 1 : 0) << 2, incl);
+      int pos = incl - cnt - (seg > 0 ? before : 0);
+      const int tab = (a.over_n ? u : 0) * R + word * 32;
+      int *srow = stage + u * C;
+      while (w) {
+        const int b = __builtin_ctz(w);
+        w &= w - 1u;
+        srow[pos++] = tab + b;
+      }
+    }
+    wave_sync();
+    int64_t *dst = a.targets + (a.over_n ? (int64_t)h_first * a.outer_stride + n_first * C
+                                         : n_first * a.outer_stride + (int64_t)h_first * C);
+    const int total = rows * C;
+    auto tok_of = [&](int id) { return id < 0 ? a.padding : ctok[id]; };
+    if (a.wide) {  // 16-byte stores, four in flight per lane (total is even here or the odd last
+                   // element goes out alone)
+      const int2 *s2 = reinterpret_cast<const int2 *>(stage);
+      longlong2 *d2 = reinterpret_cast<longlong2 *>(dst);
+      const int pairs = total >> 1;
+      int i = lane;
+      for (; i + 3 * PDT_WAVE < pairs; i += 4 * PDT_WAVE) {
+        int2 id[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) id[q] = s2[i + q * PDT_WAVE];
+        longlong2 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          v[q].x = tok_of(id[q].x);
+          v[q].y = tok_of(id[q].y);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d2[i + q * PDT_WAVE] = v[q];
+      }
+      for (; i < pairs; i += PDT_WAVE) {
+        const int2 id = s2[i];
+        longlong2 v;
+        v.x = tok_of(id.x);
+        v.y = tok_of(id.y);
+        d2[i] = v;
+      }
+      if ((total & 1) && lane == 0) dst[total - 1] = tok_of(stage[total - 1]);
+    } else {
+      for (int i = lane; i < total; i += PDT_WAVE) dst[i] = tok_of(stage[i]);
+    }
+    // (the next tile's fill may not overtake these reads of the image: the LDS serves a wave's
+    // instructions in order, so only the compiler has to be told)
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
                      int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
                      int64_t tgt_sn, hipStream_t stream) {
   const int W = (int)pdt_oc_mask_words(R);
   if (W > PDT_WAVE) return PDT_E_TOO_LONG;
+  // tiled form: rows that follow each other in memory (stride C along n or along h)
+  const bool over_n = tgt_sn == C, over_h = tgt_sh == C;
+  if ((over_n || over_h) && N < (1ll << 31)) {
+    OcTileArgs a{};
+    a.bitmask = bitmask; a.class_tokens = class_tokens; a.targets = targets;
+    a.N = N; a.padding = padding; a.R = R; a.W = W; a.Hout = Hout; a.C = C;
+    a.over_n = over_n ? 1 : 0;
+    a.outer_stride = over_n ? tgt_sh : tgt_sn;
+    while ((1 << a.lgWp) < W) ++a.lgWp;
+    // rows per tile: 4 (a run of 4 * C * 8 bytes: 31 whole lines at the bench shape; measured
+    // 0.55 ms against 0.61 with 8 rows, whose tables leave room for two workgroups per CU only),
+    // fewer while the tables + bitmask words + four images exceed 64 KiB; jobs per workgroup:
+    // 64 values of h per table load (over_n) / 16 tiles of one utterance
+    const size_t cap = 64 * 1024;
+#ifndef PDT_OC_TILE_ROWS
+#define PDT_OC_TILE_ROWS 4
+#endif
+#ifndef PDT_OC_CHUNK
+#define PDT_OC_CHUNK 64
+#endif
+    int NB = PDT_OC_TILE_ROWS;
+    int chunk = over_n ? PDT_OC_CHUNK : 16;
+    while (oc_tile_lds(R, W, C, NB, a.over_n, chunk, nullptr, nullptr) > cap && (NB > 1 || chunk > 8)) {
+      if (chunk > 16 || NB == 1) chunk >>= 1; else NB >>= 1;
+    }
+    const size_t smem = oc_tile_lds(R, W, C, NB, a.over_n, chunk, nullptr, nullptr);
+    if (smem <= 160 * 1024) {
+      a.NB = NB;
+      a.chunk = chunk;
+      const int64_t inner_len = over_n ? N : Hout;
+      a.ntiles = (int)((inner_len + NB - 1) / NB);
+      const int64_t grid = over_n ? (int64_t)a.ntiles * ((Hout + a.chunk - 1) / a.chunk)
+                                  : N * ((a.ntiles + a.chunk - 1) / a.chunk);
+      a.wide = ((a.outer_stride & 1) == 0 && (((int64_t)NB * C) & 1) == 0 &&
+                (reinterpret_cast<uintptr_t>(targets) & 15) == 0) ? 1 : 0;
+      if (grid > 0 && grid < (1ll << 31)) {
+        if (smem > cap) {
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(oc_expand_tiles_kernel),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+          if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL(oc_expand_tiles_kernel, dim3((unsigned)grid), dim3(256), smem, stream, a);
+        return (int)hipGetLastError();
+      }
+    }
+  }
   const size_t smem = (((size_t)R + (size_t)4 * W * 32) * 8 + 15) & ~(size_t)15;
   if (smem > 160 * 1024) return PDT_E_TOO_LONG;
   if (smem > 64 * 1024) {

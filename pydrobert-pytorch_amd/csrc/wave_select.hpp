@@ -37,6 +37,23 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
   return ((u64)hi << 32) | lo;
 }
 
+// lanes whose index has bit B clear: the lower lane of every pair (l, l ^ X) when B is the top
+// set bit of X
+constexpr u64 lanes_with_bit_clear(int B) {
+  u64 m = 0;
+  for (int l = 0; l < 64; ++l)
+    if ((l & B) == 0) m |= 1ull << l;
+  return m;
+}
+
+// The mask as a lane predicate, materialised where it is used by two s_mov_b32 the compiler
+// may not hoist (hoisted masks filled the scalar registers of the frame loops, and their spills
+// are v_readlane / v_writelane in a VALU-bound kernel).
+template <u64 MASK>
+__device__ __forceinline__ bool lane_predicate() {
+  return __builtin_amdgcn_inverse_ballot_w64(MASK);
+}
+
 // value of lane (lane ^ X).  One DPP move where one exists: quad_perm for X = 1, 2, 3,
 // row_half_mirror / row_mirror for X = 7 / 15, row_ror:8 for X = 8.  The others (4, 16, 31, 32,
 // 63) would take two or three VALU instructions each; the kernels that sort are VALU-issue-bound
@@ -62,29 +79,37 @@ __device__ __forceinline__ unsigned xor_shfl(unsigned v) {
     return (unsigned)__builtin_amdgcn_mov_dpp((int)v, 0x128, 0xf, 0xf, true);  // row_ror:8
   } else {
     static_assert(X == 4 || X == 16 || X == 31 || X == 32 || X == 63, "xor_shfl: unsupported pattern");
+#ifdef PDT_SORT_VALU
+    // Register-only forms (gfx950): the crossbar answers after ~70 cycles alone and ~190 with
+    // every wave of the CU using it, a dependent VALU instruction after 8-30 -- and the
+    // consumer of the CTC search is one dependency chain.
+    if constexpr (X == 4) {
+      // lanes 0-3 / 8-11 of a row read 4 lanes up, lanes 4-7 / 12-15 read 4 lanes down
+      int t = __builtin_amdgcn_update_dpp((int)v, (int)v, 0x104, 0xf, 0x5, false);  // row_shl:4, banks 0 and 2
+      t = __builtin_amdgcn_update_dpp(t, (int)v, 0x114, 0xf, 0xA, false);            // row_shr:4, banks 1 and 3
+      return (unsigned)t;
+    } else if constexpr (X == 16) {
+      // v_permlane16_swap: odd rows of the first operand <-> even rows of the second; with both
+      // = v the first becomes rows (0, 0, 2, 2) and the second rows (1, 1, 3, 3)
+      const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+      return lane_predicate<lanes_with_bit_clear(16)>() ? r[1] : r[0];
+    } else if constexpr (X == 32) {
+      // v_permlane32_swap: upper half of the first operand <-> lower half of the second
+      const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+      return lane_predicate<lanes_with_bit_clear(32)>() ? r[1] : r[0];
+    } else if constexpr (X == 31) {
+      return xor_shfl<16>(xor_shfl<15>(v));
+    } else {
+      return xor_shfl<32>(xor_shfl<16>(xor_shfl<15>(v)));
+    }
+#else
     return (unsigned)__builtin_amdgcn_ds_bpermute((int)((lane_id() ^ X) << 2), (int)v);
+#endif
   }
 }
 template <int X>
 __device__ __forceinline__ u64 xor_shfl(u64 v) {
   return ((u64)xor_shfl<X>((unsigned)(v >> 32)) << 32) | xor_shfl<X>((unsigned)v);
-}
-
-// lanes whose index has bit B clear: the lower lane of every pair (l, l ^ X) when B is the top
-// set bit of X
-constexpr u64 lanes_with_bit_clear(int B) {
-  u64 m = 0;
-  for (int l = 0; l < 64; ++l)
-    if ((l & B) == 0) m |= 1ull << l;
-  return m;
-}
-
-// The mask as a lane predicate, materialised where it is used by two s_mov_b32 the compiler
-// may not hoist (hoisted masks filled the scalar registers of the frame loops, and their spills
-// are v_readlane / v_writelane in a VALU-bound kernel).
-template <u64 MASK>
-__device__ __forceinline__ bool lane_predicate() {
-  return __builtin_amdgcn_inverse_ballot_w64(MASK);
 }
 
 // One compare-exchange stage of a DESCENDING sort: partners (l, l ^ X), the lower lane keeps the

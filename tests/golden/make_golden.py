@@ -488,3 +488,33 @@ def fill_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "fill"):
     fill_goldens()
+
+
+def c4_goldens():
+    """BASELINE config 4 at its real frame count (T=1000, F=80) for two utterances: the live
+    reference's SpecAugment application (time warp up to 80 frames, 2 + 2 masks) and its
+    sparse_image_warp of the same tensor; float16 inputs keep the fixture small and are exact
+    in float32."""
+    rng = np.random.default_rng(0x5EED000A)
+    N, T, Fq = 2, 1000, 80
+    feats = torch.from_numpy(rng.normal(size=(N, T, Fq)).astype(np.float16).astype(np.float32))
+    lens = torch.tensor([1000, 731])
+    params = (
+        torch.tensor([412.0, 250.0]), torch.tensor([63.0, -71.0]), torch.zeros(0), torch.zeros(0),
+        torch.tensor([[100, 640], [20, 500]]), torch.tensor([[37, 22], [29, 11]]),
+        torch.tensor([[3, 50], [10, 61]]), torch.tensor([[20, 9], [27, 5]]),
+    )  # fmt: skip
+    d = dict(feats=feats.numpy().astype(np.float16), lens=lens)
+    for i, p in enumerate(params):
+        d["p{}".format(i)] = p
+    out = F.spec_augment_apply_parameters(feats, params, 1, lens)
+    d["sa_o1"] = out
+    src = torch.tensor([[[300.0, 20.0], [700.0, 60.0], [500.0, 40.0]], [[100.0, 10.0], [650.0, 70.0], [400.0, 33.0]]])
+    dst = src + torch.tensor([[[2.0, -1.0], [-3.0, 0.5], [1.0, 1.0]], [[-2.0, 0.5], [1.5, -1.0], [0.0, 2.0]]])
+    d.update(siw_src=src, siw_dst=dst)
+    d["siw"] = F.sparse_image_warp(feats.unsqueeze(1), src, dst, pinned_boundary_points=1, include_flow=False)
+    save("c4_sample", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "c4"):
+    c4_goldens()
