@@ -51,7 +51,11 @@ def _beam_search_advance_op(
     log_probs_prev: torch.Tensor,
     y_prev: torch.Tensor,
     y_prev_lens: Optional[torch.Tensor],
+    grows: Optional[bool] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    # `grows`: the caller already knows whether some path is as long as the history (y_next
+    # then has one row more, reference :133-135), which saves the read-back of max(y_prev_lens);
+    # None = find out here
     if log_probs_t.dim() != 3:
         raise RuntimeError("log_probs_t must be 3 dimensional")
     N, Kp, V = log_probs_t.shape
@@ -80,7 +84,9 @@ def _beam_search_advance_op(
     lpt, lpp, yp = _f32(log_probs_t), _f32(log_probs_prev), _i64(y_prev)
     ypl = None if y_prev_lens is None else _i64(y_prev_lens)
     grow = True
-    if ypl is not None and N * Kp:
+    if grows is not None:
+        grow = grows
+    elif ypl is not None and N * Kp:
         if S:
             grow = int(ypl.max().item()) >= S  # :133-135 don't make y bigger unless we have to
         elif bool((ypl != 0).any()):
@@ -105,10 +111,12 @@ def _beam_search_advance_op(
 
 
 @_beam_search_advance_op.register_fake
-def _(log_probs_t, width, log_probs_prev, y_prev, y_prev_lens):
+def _(log_probs_t, width, log_probs_prev, y_prev, y_prev_lens, grows=None):
     N = log_probs_t.shape[0]
     S = y_prev.shape[0]
-    if y_prev_lens is not None:  # data dependent: S or S + 1 (:133-135)
+    if grows is not None:
+        S_out = S + (1 if grows else 0)
+    elif y_prev_lens is not None:  # data dependent: S or S + 1 (:133-135)
         S_out = torch.library.get_ctx().new_dynamic_size()
     else:
         S_out = S + 1
@@ -118,6 +126,32 @@ def _(log_probs_t, width, log_probs_prev, y_prev, y_prev_lens):
         log_probs_t.new_empty((N, width)),
         y_prev.new_empty((N, width), dtype=torch.long),
     )
+
+
+def _beam_search_advance_setup(ctx, inputs, output):
+    log_probs_t, _, log_probs_prev = inputs[:3]
+    y_next, y_next_lens, lp_next, next_src = output
+    # the token a new path ends in sits at its last position
+    tok = y_next.gather(0, (y_next_lens - 1).clamp(min=0).unsqueeze(0)).squeeze(0)
+    ctx.save_for_backward(next_src, tok, torch.isfinite(lp_next))
+    ctx.shape_t, ctx.dtype_t, ctx.dtype_prev = log_probs_t.shape, log_probs_t.dtype, log_probs_prev.dtype
+
+
+def _beam_search_advance_backward(ctx, g_y, g_lens, g_lp, g_src):
+    # log_probs_next[n, k] = log_probs_prev[n, src] + log_probs_t[n, src, tok] (reference
+    # _decoding.py:121-131: the top-k VALUES stay in the graph), so the gradient of an entry goes
+    # to exactly those two addends; padded (-inf) entries carry none
+    src, tok, valid = ctx.saved_tensors
+    N, Kp, V = ctx.shape_t
+    g = torch.where(valid, g_lp, torch.zeros_like(g_lp)).float()
+    g_prev = g.new_zeros((N, Kp)).scatter_add_(1, src, g)
+    g_t = g.new_zeros((N, Kp * V)).scatter_add_(1, src * V + tok.clamp(0, V - 1), g).view(N, Kp, V)
+    return g_t.to(ctx.dtype_t), None, g_prev.to(ctx.dtype_prev), None, None, None
+
+
+register_autograd(
+    "pydrobert_amd::beam_search_advance", _beam_search_advance_backward, setup_context=_beam_search_advance_setup
+)
 
 
 def beam_search_advance(
@@ -242,6 +276,75 @@ def _(ext, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_i
         i64(S + 1, N, W), i64(N, W), i64(N, W), ext.new_empty((N, W)), ext.new_empty((N, W)),
         ext.new_empty((N, W, W), dtype=torch.bool), i64(N, W), ext.new_empty((N, W), dtype=torch.bool),
     )  # fmt: skip
+
+
+def _ctc_advance_setup(ctx, inputs, output):
+    ext, nonext, blank, _, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix = inputs
+    _, o_last, _, o_nb, _, _, o_src, o_non = output
+    ctx.save_for_backward(ext, nonext, blank, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix,
+                          o_last, o_nb, o_src, o_non)  # fmt: skip
+
+
+def _ctc_advance_backward(ctx, g_y, g_last, g_lens, g_nb, g_b, g_isp, g_src, g_non):
+    """Adjoint of the masses of one CTC prefix-search step (reference _decoding.py:777-880; the
+    selection itself is piecewise constant).  A new entry i with source s = next_src[i] holds
+      extension by v:   nb' = w(s, v) * ext[s, v],  b' = 0,   w(s, v) = (nb[s] if v != last[s] else 0) + b[s]
+      non-extension:    nb' = nb[s] * nonext[last[s]] + sum over prefixes k that BECOME s when extended
+                              by need(k, s) of w(k, need) * ext[k, need],
+                        b'  = (nb[s] + b[s]) * blank
+    The dense work is (N, K', K') -- nothing of size V besides the scatter into grad ext."""
+    (ext, nonext, blank, nb, b, y_prev, last, lens, is_prefix, o_last, o_nb, src, non) = ctx.saved_tensors
+    N, Kp, V = ext.shape
+    S = y_prev.shape[0]
+    f = torch.float
+    ext_, nonext_, blank_, nb_, b_ = ext.to(f), nonext.to(f), blank.to(f), nb.to(f), b.to(f)
+    valid = torch.isfinite(o_nb)
+    zero = torch.zeros((), device=ext.device, dtype=f)
+    # absent (padded) prefixes hold -inf masses: they are the source of nothing valid
+    nb_, b_ = torch.where(torch.isfinite(nb_), nb_, zero), torch.where(torch.isfinite(b_), b_, zero)
+    gnb = torch.where(valid, g_nb.to(f), zero)
+    gb = torch.where(valid & non, g_b.to(f), zero)
+    lastc = last.clamp(0, V - 1)
+    # --- extension entries
+    is_ext = valid & ~non
+    tok = o_last.clamp(0, V - 1)
+    last_s = lastc.gather(1, src)
+    w = torch.where(tok != last_s, nb_.gather(1, src), zero) + b_.gather(1, src)
+    e = ext_.reshape(N, Kp * V).gather(1, src * V + tok)
+    ge = torch.where(is_ext, gnb, zero)
+    g_ext = ge.new_zeros((N, Kp * V)).scatter_add_(1, src * V + tok, ge * w)
+    g_nb_prev = ge.new_zeros((N, Kp)).scatter_add_(1, src, torch.where(tok != last_s, ge * e, zero))
+    g_b_prev = ge.new_zeros((N, Kp)).scatter_add_(1, src, ge * e)
+    # --- non-extension entries: gradient of stay_nb[s] / stay_b[s], summed over the entries that kept s
+    gs_nb = ge.new_zeros((N, Kp)).scatter_add_(1, src, torch.where(non, gnb, zero))
+    gs_b = ge.new_zeros((N, Kp)).scatter_add_(1, src, gb)
+    p_last = nonext_.gather(1, lastc)
+    g_nonext = ge.new_zeros((N, V)).scatter_add_(1, lastc, gs_nb * nb_)
+    g_nb_prev = g_nb_prev + gs_nb * p_last + gs_b * blank_.unsqueeze(1)
+    g_b_prev = g_b_prev + gs_b * blank_.unsqueeze(1)
+    g_blank = (gs_b * (nb_ + b_)).sum(1)
+    # merged extensions: prefix k + need(k, s) == prefix s
+    if S:
+        at = lens.clamp(max=S - 1).unsqueeze(2).expand(N, Kp, Kp).transpose(0, 1)
+        need = y_prev.gather(0, at).transpose(0, 1).clamp(0, V - 1)  # (N, k, s)
+    else:
+        need = torch.zeros((N, Kp, Kp), dtype=torch.long, device=ext.device)
+    becomes = ((lens + 1).unsqueeze(2) == lens.unsqueeze(1)) & is_prefix.bool()
+    gm = torch.where(becomes, gs_nb.unsqueeze(1).expand(N, Kp, Kp), zero)  # d stay_nb[s] / d term(k, s)
+    differs = need != lastc.unsqueeze(2)
+    wk = torch.where(differs, nb_.unsqueeze(2), zero) + b_.unsqueeze(2)
+    ek = ext_.gather(2, need)
+    k_idx = torch.arange(Kp, device=ext.device).view(1, Kp, 1)
+    g_ext.scatter_add_(1, (k_idx * V + need).reshape(N, Kp * Kp), (gm * wk).reshape(N, Kp * Kp))
+    g_nb_prev = g_nb_prev + torch.where(differs, gm * ek, zero).sum(2)
+    g_b_prev = g_b_prev + (gm * ek).sum(2)
+    return (g_ext.view(N, Kp, V).to(ext.dtype), g_nonext.to(nonext.dtype), g_blank.to(blank.dtype), None,
+            g_nb_prev.to(nb.dtype), g_b_prev.to(b.dtype), None, None, None, None)  # fmt: skip
+
+
+register_autograd(
+    "pydrobert_amd::ctc_prefix_search_advance", _ctc_advance_backward, setup_context=_ctc_advance_setup
+)
 
 
 def ctc_prefix_search_advance(
@@ -380,87 +483,94 @@ class CTCPrefixSearch(torch.nn.Module):
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         if logits.dim() != 3:
             raise RuntimeError("logits must be 3 dimensional")
+        # The one-kernel search returns probabilities that are cut off from the graph.  When the
+        # caller wants gradients with respect to the logits (the reference's probabilities are
+        # differentiable, _decoding.py:1093, :1188), the search runs frame by frame instead: every
+        # frame is one kernel whose masses carry an autograd formula.
+        wants_grad = torch.is_grad_enabled() and logits.requires_grad
+        prev: Dict[str, torch.Tensor] = dict()
+        if initial_state is not None:
+            prev = initial_state
         if self.lm is None:
+            if wants_grad:
+                return self._frame_by_frame(logits, lens, prev)
             return ctc_prefix_search(logits, self.width, lens)
         else:
-            Vp1 = logits.size(2)
-            if self.lm.vocab_size != Vp1 - 1:
+            if self.lm.vocab_size != logits.size(2) - 1:
                 raise RuntimeError(
-                    "Expected dim 2 of logits to be {}, got {}".format(self.lm.vocab_size + 1, Vp1)
+                    "Expected dim 2 of logits to be {}, got {}".format(self.lm.vocab_size + 1, logits.size(2))
                 )
-            if self.beta == 0.0:
+            if self.beta == 0.0 and not wants_grad:
                 return ctc_prefix_search(logits, self.width, lens)
-            prev: Dict[str, torch.Tensor] = dict()
-            if initial_state is not None:
-                prev = initial_state
-            return self._fused_with_lm(logits, lens, prev)
+            return self._frame_by_frame(logits, lens, prev)
 
-    def _fused_with_lm(
-        self, logits: torch.Tensor, lens: Optional[torch.Tensor], prev: Dict[str, torch.Tensor]
+    def _frame_by_frame(
+        self, logits: torch.Tensor, lens: Optional[torch.Tensor], state: Dict[str, torch.Tensor]
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-        # reference _decoding.py:1083-1202, frame loop around the user's language model
-        T, N, Vp1 = logits.size(0), logits.size(1), logits.size(2)
-        V, W = Vp1 - 1, self.width
+        """One ``ctc_prefix_search_advance`` kernel per frame, around the user's language model
+        when there is one (the semantics of reference _decoding.py:1083-1202).  Utterances whose
+        frames have run out are frozen on the device (a ``where`` per state tensor); the only
+        host read is the number of frames to run."""
+        T, N, V, W = logits.size(0), logits.size(1), logits.size(2) - 1, self.width
         device, dtype = logits.device, logits.dtype
-        if lens is None:
-            lens_ = torch.full((N,), T, device=device, dtype=torch.long)
-            len_min = len_max = T
-        else:
+        n_frames = T
+        if lens is not None:
             if lens.dim() != 1:
                 raise RuntimeError("lens must be 1 dimensional")
             if lens.size(0) != N:
                 raise RuntimeError("expected dim 0 of lens to be {}, got {}".format(N, lens.size(0)))
-            lens_ = lens
-            len_min, len_max = int(lens.min().item()), int(lens.max().item())
+            n_frames = min(T, int(lens.max().item())) if N else 0
         probs = logits.softmax(2)
-        blank_probs, nonext_probs = probs[..., V], probs[..., :V]
+        # beam state: one empty prefix per utterance, all of its mass on "ends in blank"
         nb = torch.zeros((N, 1), device=device, dtype=dtype)
         b = torch.ones((N, 1), device=device, dtype=dtype)
         y = torch.empty((0, N, 1), dtype=torch.long, device=device)
         y_lens = torch.zeros((N, 1), dtype=torch.long, device=device)
         y_last = y_lens
         is_prefix = torch.ones((N, 1, 1), device=device, dtype=torch.bool)
-        assert self.lm is not None
-        prev = self.lm.update_input(prev, y)
+        fuse = self.beta != 0.0
+        if self.lm is not None:
+            if fuse:
+                state = self.lm.update_input(state, y)
         Kp = 1
-        pad_y = torch.zeros((1, N, W), device=device, dtype=torch.long)
-        for t in range(len_max):
-            nonext_t, blank_t = nonext_probs[t], blank_probs[t]
-            lm_lp, in_next = self.lm.calc_idx_log_probs(y.flatten(1), prev, y_lens.flatten())
-            if self.valid_mixture:  # :1120-1128
-                lm_p = self.beta * lm_lp.softmax(-1).view(N, Kp, V) * (1 - blank_t.view(N, 1, 1))
-                ext_t = (1.0 - self.beta) * nonext_t.unsqueeze(1) + lm_p
-            else:  # :1130-1135
-                lm_p = (self.beta * lm_lp.log_softmax(-1)).exp().view(N, Kp, V)
-                ext_t = lm_p * nonext_t.unsqueeze(1)
-            (y_next, last_next, lens_next, probs_next, isp_next, src, is_nonext) = \
-                ctc_prefix_search_advance(
-                    (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
-                )  # fmt: skip
-            nb_next, b_next = probs_next
-            flat = (torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1) + src).flatten()
-            prev = self.lm.extract_by_src(prev, flat)  # :1154-1163
-            in_next = self.lm.extract_by_src(in_next, flat)
-            prev = self.lm.mix_by_mask(prev, in_next, is_nonext.flatten())
-            if t < len_min:
-                y_lens, nb, b = lens_next, nb_next, b_next
-            else:  # :1165-1181 freeze finished batch elements
-                valid = (t < lens_).unsqueeze(1)
-                y = torch.cat([y.expand(-1, -1, W), pad_y], 0)
-                y_next = torch.where(valid.unsqueeze(0), y_next, y)
-                y_lens = torch.where(valid, lens_next, y_lens)
-                if Kp < W:
-                    neg_inf = nb.new_full((N, W - Kp), -float("inf"))
-                    nb, b = torch.cat([nb, neg_inf], 1), torch.cat([b, neg_inf], 1)
-                nb = torch.where(valid, nb_next, nb)
-                b = torch.where(valid, b_next, b)
-            y, y_last, is_prefix, Kp = y_next, last_next, isp_next, W
-        probs_out = nb + b
-        if Kp == 1 and W != 1:  # :1190-1200
-            y = y.repeat(1, 1, W)
-            y_lens = y_lens.repeat(1, W)
-            probs_out = torch.cat([probs_out, probs_out.new_full((N, W - 1), -float("inf"))], 1)
-        return y, y_lens, probs_out
+        for t in range(n_frames):
+            nonext_t, blank_t = probs[t, :, :V], probs[t, :, V]
+            ext_t = nonext_t.unsqueeze(1).expand(N, Kp, V)
+            state_next: Dict[str, torch.Tensor] = dict()
+            if self.lm is not None:
+                if fuse:
+                    lm_lp, state_next = self.lm.calc_idx_log_probs(y.flatten(1), state, y_lens.flatten())
+                    if self.valid_mixture:  # convex combination that still sums to 1 - blank (:1120-1128)
+                        lm_p = lm_lp.softmax(-1).view(N, Kp, V) * (1 - blank_t.view(N, 1, 1))
+                        ext_t = (1.0 - self.beta) * ext_t + self.beta * lm_p
+                    else:  # shallow fusion: p_ctc * p_lm ** beta (:1130-1135)
+                        ext_t = ext_t * (self.beta * lm_lp.log_softmax(-1)).exp().view(N, Kp, V)
+            y_new, last_new, lens_new, masses, is_prefix, src, kept = ctc_prefix_search_advance(
+                (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
+            )
+            nb_new, b_new = masses
+            if self.lm is not None:
+                if fuse:
+                    rows = (src + torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1)).flatten()
+                    state = self.lm.mix_by_mask(
+                        self.lm.extract_by_src(state, rows), self.lm.extract_by_src(state_next, rows), kept.flatten()
+                    )  # :1154-1163
+            if lens is not None:
+                live = (lens > t).unsqueeze(1)  # (N, 1): utterances that still have this frame
+                if Kp < W:  # the first frame: widen the old state with absent entries
+                    absent = nb.new_full((N, W - Kp), -float("inf"))
+                    nb, b = torch.cat([nb, absent], 1), torch.cat([b, absent], 1)
+                    y, y_lens = y.expand(-1, -1, W), y_lens.expand(-1, W)
+                y_old = torch.cat([y, y.new_zeros((1, N, W))], 0)
+                y_new = torch.where(live.unsqueeze(0), y_new, y_old)
+                lens_new = torch.where(live, lens_new, y_lens)
+                nb_new, b_new = torch.where(live, nb_new, nb), torch.where(live, b_new, b)
+            y, y_last, y_lens, nb, b, Kp = y_new, last_new, lens_new, nb_new, b_new, W
+        total = nb + b
+        if Kp < W:  # no frame at all: fill the beam with absent entries (:1190-1200)
+            y, y_lens = y.repeat(1, 1, W), y_lens.repeat(1, W)
+            total = torch.cat([total, total.new_full((N, W - Kp), -float("inf"))], 1)
+        return y, y_lens, total
 
 
 class BeamSearch(torch.nn.Module):
@@ -555,39 +665,46 @@ class BeamSearch(torch.nn.Module):
             max_iters = 1073741824
         elif max_iters < 0:
             raise RuntimeError("max_iters must be non-negative, got {}".format(max_iters))
-        pad_y = torch.full((1, N, W), self.pad_value, device=device, dtype=torch.long)
+        pad_row = torch.full((1, N, W), self.pad_value, device=device, dtype=torch.long)
+        track_eos = self.eos is not None
         for t in range(max_iters):
-            t_ = torch.tensor(t, device=device)
-            if self.eos is not None and t:  # :413-427 which paths have ended; are we done?
-                last = y.permute(1, 2, 0).gather(2, (lens - 1).clamp(min=0).unsqueeze(2)).squeeze(2)
-                eos_mask = (last == self.eos) & (lens > 0)
-                done = eos_mask.all(1, keepdim=True) if self.finish_all_paths else eos_mask[..., :1]
-                if bool(done.all()):
+            step = torch.tensor(t, device=device)
+            ended = torch.zeros((N, Kp), device=device, dtype=torch.bool)
+            frozen = ended[:, :1]  # batch elements whose search is over (:413-427)
+            any_frozen = False
+            if track_eos and t:
+                tail = y.permute(1, 2, 0).gather(2, (lens - 1).clamp(min=0).unsqueeze(2)).squeeze(2)
+                ended = (tail == self.eos) & (lens > 0)
+                frozen = ended.all(1, keepdim=True) if self.finish_all_paths else ended[:, :1]
+                # the one host read of the step: (everything is over, something is over)
+                code = int((frozen.all().long() * 2 + frozen.any().long()).item())
+                any_frozen = code > 0
+                if code > 1:
                     break
-            else:
-                eos_mask = torch.zeros((N, Kp), device=device, dtype=torch.bool)
-                done = eos_mask[..., :1]
-            y_ = y.clamp(0, V - 1)
-            lp_t, in_next = self.lm.calc_idx_log_probs(y_.flatten(1), prev, t_)
+            hist = y.clamp(0, V - 1)
+            lp_t, state_next = self.lm.calc_idx_log_probs(hist.flatten(1), prev, step)
             lp_t = lp_t.reshape(N, Kp, V).log_softmax(-1)
-            log_probs, lp_t = self.update_log_probs_for_step(log_probs, lp_t, y_, lens, eos_mask)
-            if self.eos is not None:  # :448-458 ended paths may only emit eos, for free
-                lp_t = lp_t.masked_fill(eos_mask.unsqueeze(2), -float("inf"))
-                lp_t[..., self.eos] = lp_t[..., self.eos].masked_fill(eos_mask, 0.0)
-            y_next, lens_next, lp_next, src = beam_search_advance(lp_t, W, log_probs, y_, lens)
-            if self.eos is not None:  # :465-468 ended sources do not grow
-                lens_next = lens_next - eos_mask.gather(1, src).to(lens_next)
-            flat = (torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1) + src).flatten()
-            prev = self.lm.extract_by_src(in_next, flat)
-            if self.eos is not None and bool(done.any()):  # :479-486 frozen batch elements
+            log_probs, lp_t = self.update_log_probs_for_step(log_probs, lp_t, hist, lens, ended)
+            if track_eos:  # a path that has ended repeats eos at no cost and emits nothing else (:448-458)
+                only_eos = torch.full_like(lp_t, -float("inf"))
+                only_eos[..., self.eos] = 0.0
+                lp_t = torch.where(ended.unsqueeze(2), only_eos, lp_t)
+            # some path is as long as the history whenever the loop gets here (a live element has
+            # a live path of t tokens), so y grows by a row: no read-back of the lengths
+            y_new, lens_new, lp_new, src = torch.ops.pydrobert_amd.beam_search_advance(
+                lp_t, W, log_probs, hist, lens, True
+            )
+            if track_eos:  # ended sources stay as long as they were (:465-468)
+                lens_new = lens_new - ended.gather(1, src).to(lens_new)
+            rows = (src + torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1)).flatten()
+            prev = self.lm.extract_by_src(state_next, rows)
+            if any_frozen:  # finished batch elements keep what they had (:479-486)
                 y, log_probs, lens = self._to_width(y, log_probs, lens)
-                y = torch.cat([y, pad_y], 0)
-                if y.size(0) < y_next.size(0):
-                    y = torch.cat([y, pad_y.expand(y_next.size(0) - y.size(0), -1, -1)], 0)
-                y_next = torch.where(done.unsqueeze(0), y[: y_next.size(0)], y_next)
-                lp_next = torch.where(done, log_probs, lp_next)
-                lens_next = torch.where(done, lens, lens_next)
-            y, lens, log_probs, Kp = y_next, lens_next, lp_next, W
+                grown = torch.cat([y, pad_row.expand(y_new.size(0) - y.size(0), -1, -1)], 0)
+                y_new = torch.where(frozen.unsqueeze(0), grown, y_new)
+                lp_new = torch.where(frozen, log_probs, lp_new)
+                lens_new = torch.where(frozen, lens, lens_new)
+            y, lens, log_probs, Kp = y_new, lens_new, lp_new, W
         y, log_probs, lens = self._to_width(y, log_probs, lens)
         if batch_size is None:
             y, lens, log_probs = y.squeeze(1), lens.squeeze(0), log_probs.squeeze(0)

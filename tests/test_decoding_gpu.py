@@ -346,3 +346,134 @@ def test_beam_search_advance_errors(device):
         F.beam_search_advance(lpt, 2, torch.zeros(2, 3, device=device),
                               torch.zeros(0, 2, 3, dtype=torch.long, device=device),
                               torch.ones(2, 3, dtype=torch.long, device=device))  # fmt: skip
+
+
+# ---------------------------------------------------------------------------------------
+# gradients of the decoding outputs (the reference keeps them in its autograd graph)
+# ---------------------------------------------------------------------------------------
+def test_beam_search_advance_gradients(device):
+    """log_probs_next carries gradients to log_probs_prev and log_probs_t exactly like the
+    reference's graph (_decoding.py:121-131: sum, then top-k VALUES)."""
+    rng = np.random.default_rng(3)
+    for N, Kp, V, W in [(3, 4, 9, 5), (2, 1, 6, 6), (4, 7, 30, 16), (2, 3, 2, 8)]:
+        lpt = torch.from_numpy(rng.normal(size=(N, Kp, V)).astype(np.float32)).log_softmax(-1)
+        lpp = torch.from_numpy(rng.normal(size=(N, Kp)).astype(np.float32))
+        yp = torch.from_numpy(rng.integers(0, V, (2, N, Kp)))
+        g = torch.from_numpy(rng.normal(size=(N, W)).astype(np.float32))
+        a, b = lpt.clone().requires_grad_(True), lpp.clone().requires_grad_(True)
+        K = min(W, Kp * V)
+        vals = (b.unsqueeze(2) + a).flatten(1).topk(K, 1)[0]
+        (vals * g[:, :K]).sum().backward()
+        a2, b2 = lpt.to(device).requires_grad_(True), lpp.to(device).requires_grad_(True)
+        out = F.beam_search_advance(a2, W, b2, yp.to(device))
+        assert out[2].requires_grad and not out[0].requires_grad
+        torch.where(torch.isfinite(out[2]), out[2] * g.to(device), torch.zeros_like(out[2])).sum().backward()
+        assert torch.allclose(a2.grad.cpu(), a.grad, atol=1e-6) and torch.allclose(b2.grad.cpu(), b.grad, atol=1e-6)
+
+
+def test_ctc_prefix_search_advance_gradients(device):
+    """(nb, b) of the step function are differentiable w.r.t. all five probability inputs;
+    compared with autograd through the torch restatement of the reference's dense graph
+    (oracle/torch_cpu.py), teacher-forced over several frames so that merges occur."""
+    from oracle import torch_cpu as tc
+
+    rng = np.random.default_rng(5)
+    for V, W in [(4, 3), (6, 5), (3, 6), (9, 4)]:
+        N = 3
+        nb, b = torch.zeros(N, 1), torch.ones(N, 1)
+        y = torch.zeros((0, N, 1), dtype=torch.long)
+        last = lens = torch.zeros((N, 1), dtype=torch.long)
+        isp = torch.ones((N, 1, 1), dtype=torch.bool)
+        for t in range(7):
+            Kp = nb.shape[1]
+            p = torch.from_numpy(rng.random((N, V + 1)).astype(np.float32)).softmax(1)
+            lm = torch.from_numpy(rng.random((N, Kp, V)).astype(np.float32))
+            leaves = [(lm * p[:, None, :V]).contiguous(), p[:, :V].contiguous(), p[:, V].contiguous(), nb.clone(), b.clone()]
+            gn, gb = torch.from_numpy(rng.normal(size=(N, W)).astype(np.float32)), torch.from_numpy(rng.normal(size=(N, W)).astype(np.float32))
+
+            def loss(nb2, b2, gn, gb):
+                ok = torch.isfinite(nb2)
+                z = torch.zeros_like(nb2)
+                return (torch.where(ok, nb2, z) * gn).sum() + (torch.where(ok, b2, z) * gb).sum()
+
+            cpu = [x.clone().requires_grad_(True) for x in leaves]
+            exp = tc.ctc_advance(cpu[0], cpu[1], cpu[2], W, cpu[3], cpu[4], y, last, lens, isp)
+            loss(exp[3], exp[4], gn, gb).backward()
+            dev = [x.to(device).requires_grad_(True) for x in leaves]
+            act = F.ctc_prefix_search_advance(
+                (dev[0], dev[1], dev[2]), W, (dev[3], dev[4]), y.to(device), last.to(device), lens.to(device), isp.to(device)
+            )
+            loss(act[3][0], act[3][1], gn.to(device), gb.to(device)).backward()
+            assert torch.equal(act[2].cpu(), exp[2])  # same beam, so the same graph
+            for name, c, d in zip(("ext", "nonext", "blank", "nb", "b"), cpu, dev):
+                ok = torch.isfinite(c.grad)  # (-inf masses of absent prefixes make the dense graph's own gradient NaN)
+                assert torch.isfinite(d.grad).all(), (name, V, W, t)
+                assert torch.allclose(d.grad.cpu()[ok], c.grad[ok], rtol=1e-4, atol=1e-6), (name, V, W, t)
+            y, last, lens, nb, b, isp = exp[0], exp[1], exp[2], exp[3].detach(), exp[4].detach(), exp[5]
+
+
+def test_ctc_prefix_search_module_gradients(device):
+    """CTCPrefixSearch probabilities are differentiable w.r.t. the logits (reference
+    _decoding.py:1093, :1188): with requires_grad the Module runs frame by frame; same beams as the
+    one-kernel search, gradients equal to those of the dense torch graph."""
+    from oracle import torch_cpu as tc
+
+    rng = np.random.default_rng(8)
+    T, N, V, K = 12, 4, 7, 5
+    lg = torch.from_numpy(_peaky_logits(rng, T, N, V, scale=3.0))
+    w = torch.from_numpy(rng.normal(size=(N, K)).astype(np.float32))
+    a = lg.clone().requires_grad_(True)
+    ey, eyl, eyp = tc.ctc_prefix_search(a, K)
+    (eyp * w).sum().backward()
+    a2 = lg.to(device).requires_grad_(True)
+    y, yl, yp = M.CTCPrefixSearch(K)(a2)
+    assert yp.requires_grad
+    fy, fyl, fyp = F.ctc_prefix_search(lg.to(device), K)
+    assert torch.equal(yl, fyl) and torch.allclose(yp, fyp, rtol=1e-5)
+    inside = torch.arange(T, device=device).view(-1, 1, 1) < yl.unsqueeze(0)
+    assert torch.equal(y * inside, fy * inside) and torch.equal(yl.cpu(), eyl)
+    (yp * w.to(device)).sum().backward()
+    assert torch.allclose(a2.grad.cpu(), a.grad, rtol=1e-3, atol=1e-7), (a2.grad.cpu() - a.grad).abs().max()
+    # ragged lengths take the same route
+    lens = torch.tensor([12, 5, 0, 9])
+    a3 = lg.to(device).requires_grad_(True)
+    y3, yl3, yp3 = M.CTCPrefixSearch(K)(a3, lens.to(device))
+    f3 = F.ctc_prefix_search(lg.to(device), K, lens.to(device))
+    ok = torch.isfinite(f3[2])
+    assert torch.equal(yl3[ok], f3[1][ok]) and torch.allclose(yp3[ok], f3[2][ok], rtol=1e-5)
+    yp3[ok].sum().backward()
+    assert torch.isfinite(a3.grad).all() and float(a3.grad[5:, 1].abs().max()) == 0.0  # frames past the length
+
+
+def test_beam_search_trains_through_its_log_probs(device):
+    """The MER recipe of the reference (_string.py:1573-1584): an n-best list out of BeamSearch,
+    its log-probabilities into minimum_error_rate_loss, gradients into the language model."""
+    from _toy_lm import BigramLM
+
+    V, K, N = 6, 4, 3
+    torch.manual_seed(2)
+    table = torch.randn(V + 1, V).to(device).requires_grad_(True)
+
+    class TrainableBigram(BigramLM):
+        def __init__(self, t):
+            torch.nn.Module.__init__(self)
+            self.vocab_size = t.shape[1]
+            self.table = t
+
+    def run(tbl):
+        search = M.BeamSearch(TrainableBigram(tbl.log_softmax(-1)), K).to(device)
+        y, yl, lp = search(dict(), N, 5)
+        return y, lp
+
+    y, lp = run(table)
+    assert lp.requires_grad
+    ref = torch.randint(0, V, (5, N), device=device)
+    loss = F.minimum_error_rate_loss(lp, ref, y, warn=False)
+    (g,) = torch.autograd.grad(loss, table)
+    assert torch.isfinite(g).all() and float(g.abs().max()) > 0
+    # a directional finite difference of the loss with the beams held fixed by a tiny step
+    d = torch.randn_like(table)
+    eps = 1e-3
+    lp_p, lp_m = run(table.detach() + eps * d)[1], run(table.detach() - eps * d)[1]
+    fd = (F.minimum_error_rate_loss(lp_p, ref, y, warn=False) - F.minimum_error_rate_loss(lp_m, ref, y, warn=False)) / (2 * eps)
+    assert abs(float(fd) - float((g * d).sum())) < 5e-2 * max(1.0, abs(float(fd))), (float(fd), float((g * d).sum()))
