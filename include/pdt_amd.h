@@ -222,9 +222,14 @@ int pdt_sequence_log_probs_backward(const float *logits, const int64_t *hyp, int
  * contiguous unless strides are given.
  *
  * pdt_polyharmonic_spline: polyharmonic_spline (_img.py:59-150).  train_points (N,T,I),
- *   train_values (N,T,O), query_points (N,Q,I) -> out (N,Q,O); T + I + 1 <= 100.  The bordered
- *   system is solved exactly (float64, partial pivoting), which covers both of the reference's
- *   `full_matrix` evaluation orders.  workspace: pdt_spline_workspace_bytes(N,T,I,O) bytes.
+ *   train_values (N,T,O), query_points (N,Q,I) -> out (N,Q,O).  The bordered system is solved
+ *   exactly (float64, partial pivoting; in LDS up to ~140 unknowns, in the workspace beyond),
+ *   which covers both of the reference's `full_matrix` evaluation orders.
+ *   workspace: pdt_spline_workspace_bytes(N,T,I,O) bytes.
+ * pdt_spline_solve: the solve alone, with an optional right-hand-side tail: solution (N, T+I+1, O)
+ *   float64 of [[phi(|c_i - c_j|) + reg I, [c 1]], [[c 1]^T, 0]] X = [train_values; tail]
+ *   (tail (N, I+1, O) or NULL = zeros).  The spline's weights (_img.py:79-130), and -- the matrix
+ *   being symmetric -- the adjoint system of its backward pass.
  * pdt_warp_1d_grid: warp_1d_grid (_img.py:268-303): src, flow, lengths (N,) -> grid (N,T).
  * pdt_spec_augment_apply: spec_augment_apply_parameters (_img.py:1142-1211).  feats (N,T,F)
  *   through element strides; time_grid (N,T) / freq_grid (N,F) normalised sampling grids or
@@ -246,6 +251,10 @@ int pdt_sequence_log_probs_backward(const float *logits, const int64_t *hyp, int
  *   hardware float atomic, so sums are not bit-reproducible from run to run.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_spline_workspace_bytes(int64_t N, int64_t T, int64_t I, int64_t O);
+
+int pdt_spline_solve(const float *train_points, const float *train_values, const float *tail,
+                     int64_t N, int64_t T, int64_t I, int64_t O, int order,
+                     float regularization_weight, double *solution, void *workspace, void *stream);
 
 int pdt_polyharmonic_spline(const float *train_points, const float *train_values,
                             const float *query_points, int64_t N, int64_t T, int64_t I, int64_t O,

@@ -19,7 +19,9 @@
 
 namespace pdt {
 
-constexpr int kMaxSplineSys = 100;  // T + I + 1
+// T + I + 1 up to which the augmented system of one batch element fits the 160 KB of LDS (with
+// O <= 4 right-hand sides); larger systems are eliminated in a global-memory workspace
+constexpr size_t kSplineLdsCap = 160 * 1024 - 64;
 
 __device__ __forceinline__ double phi_d(double r, int order) {
   // _img.py:59-64; eps = float32 epsilon (train/query points are cast to float, :142-143)
@@ -98,15 +100,20 @@ __device__ void solve_in_lds(double *a, int S, int O, int *piv_row) {
   __syncthreads();
 }
 
-// train points c (N,T,I), values f (N,T,O) -> wv (N, T+I+1, O) doubles
+// train points c (N,T,I), values f (N,T,O) -> wv (N, T+I+1, O) doubles.  `tail` (N, I+1, O) or
+// null: the last I + 1 rows of the right-hand side (zeros for the interpolation problem itself;
+// the adjoint system of the backward pass has them).  `gmat` non-null: the augmented matrix of
+// batch element n lives at gmat + n * S * (S + O) in global memory instead of LDS (systems too
+// large for LDS; a workgroup's own global writes are visible to it after __syncthreads()).
 __global__ void __launch_bounds__(256)
-spline_solve_kernel(const float *__restrict__ c, const float *__restrict__ f, int T, int I, int O,
-                    int order, float reg, double *__restrict__ wv) {
+spline_solve_kernel(const float *__restrict__ c, const float *__restrict__ f,
+                    const float *__restrict__ tail, int T, int I, int O, int order, float reg,
+                    double *__restrict__ wv, double *gmat) {
   extern __shared__ __align__(16) unsigned char smem[];
-  double *a = reinterpret_cast<double *>(smem);
   const int S = T + I + 1, ld = S + O;
-  int *piv = reinterpret_cast<int *>(a + (size_t)S * ld);
   const int64_t n = blockIdx.x;
+  double *a = gmat ? gmat + n * (int64_t)S * ld : reinterpret_cast<double *>(smem);
+  int *piv = gmat ? reinterpret_cast<int *>(smem) : reinterpret_cast<int *>(a + (size_t)S * ld);
   const float *cn = c + n * (int64_t)T * I;
   const float *fn = f + n * (int64_t)T * O;
   for (int i = (int)threadIdx.x; i < S * ld; i += (int)blockDim.x) {
@@ -126,6 +133,8 @@ spline_solve_kernel(const float *__restrict__ c, const float *__restrict__ f, in
       v = (r - T) < I ? (double)cn[col * I + (r - T)] : 1.0;
     } else if (r < T && col >= S) {
       v = (double)fn[r * O + (col - S)];
+    } else if (r >= T && col >= S && tail) {
+      v = (double)tail[(n * (I + 1) + (r - T)) * O + (col - S)];
     }
     a[i] = v;
   }
@@ -663,23 +672,49 @@ extern "C" {
 
 int64_t pdt_spline_workspace_bytes(int64_t N, int64_t T, int64_t I, int64_t O) {
   if (N < 0 || T < 0 || I < 0 || O < 0) return 0;
-  return N * (T + I + 1) * O * (int64_t)(sizeof(double) + sizeof(float)) + 64;
+  const int64_t S = T + I + 1;
+  int64_t bytes = N * S * O * (int64_t)(sizeof(double) + sizeof(float)) + 64;
+  // systems beyond the LDS are eliminated in global memory, after the solutions
+  if ((size_t)S * (S + O) * sizeof(double) + 16 > pdt::kSplineLdsCap) bytes += N * S * (S + O) * (int64_t)sizeof(double);
+  return bytes;
 }
 
-static int spline_solve(const float *c, const float *f, int64_t N, int64_t T, int64_t I, int64_t O,
-                        int order, float reg, double *wv, hipStream_t stream) {
+static int spline_solve(const float *c, const float *f, const float *tail, int64_t N, int64_t T,
+                        int64_t I, int64_t O, int order, float reg, double *wv, hipStream_t stream) {
   using namespace pdt;
   const int64_t S = T + I + 1;
-  if (S > kMaxSplineSys) return PDT_E_TOO_LONG;
-  const size_t smem = (size_t)S * (S + O) * sizeof(double) + 16;
+  if (S > 4096 || O > 64) return PDT_E_TOO_LONG;
+  size_t smem = (size_t)S * (S + O) * sizeof(double) + 16;
+  double *gmat = nullptr;
+  if (smem > kSplineLdsCap) {  // the matrix follows the (N, S, O) doubles + floats of the solutions
+    gmat = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(wv) +
+                                      (((size_t)N * S * O * (sizeof(double) + sizeof(float)) + 63) & ~(size_t)63));
+    smem = 16;
+  }
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(spline_solve_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(spline_solve_kernel, dim3((unsigned)N), dim3(256), smem, stream, c, f, (int)T,
-                     (int)I, (int)O, order, reg, wv);
+  hipLaunchKernelGGL(spline_solve_kernel, dim3((unsigned)N), dim3(256), smem, stream, c, f, tail,
+                     (int)T, (int)I, (int)O, order, reg, wv, gmat);
   return (int)hipGetLastError();
+}
+
+int pdt_spline_solve(const float *train_points, const float *train_values, const float *tail,
+                     int64_t N, int64_t T, int64_t I, int64_t O, int order,
+                     float regularization_weight, double *solution, void *workspace, void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 1 || I < 1 || O < 1 || order < 1) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!train_points || !train_values || !solution || !workspace) return PDT_E_ARG;
+  if (N > 65535) return PDT_E_TOO_LONG;
+  double *wv = reinterpret_cast<double *>(workspace);
+  int rc = spline_solve(train_points, train_values, tail, N, T, I, O, order, regularization_weight, wv,
+                        (hipStream_t)stream);
+  if (rc != PDT_OK) return rc;
+  return (int)hipMemcpyAsync(solution, wv, (size_t)N * (T + I + 1) * O * sizeof(double),
+                             hipMemcpyDeviceToDevice, (hipStream_t)stream);
 }
 
 int pdt_polyharmonic_spline(const float *train_points, const float *train_values,
@@ -692,7 +727,7 @@ int pdt_polyharmonic_spline(const float *train_points, const float *train_values
   if (!train_points || !train_values || !query_points || !out || !workspace) return PDT_E_ARG;
   if (N > 65535) return PDT_E_TOO_LONG;
   double *wv = reinterpret_cast<double *>(workspace);
-  int rc = spline_solve(train_points, train_values, N, T, I, O, order, regularization_weight, wv,
+  int rc = spline_solve(train_points, train_values, nullptr, N, T, I, O, order, regularization_weight, wv,
                         (hipStream_t)stream);
   if (rc != PDT_OK) return rc;
   const size_t smem = (size_t)(T + I + 1) * O * sizeof(double) + (size_t)T * I * sizeof(float);
@@ -830,7 +865,7 @@ static int sparse_warp_launch(const float *image, const float *train_points,
     return PDT_E_ARG;
   if (H * W >= (1ll << 31) || N > 65535) return PDT_E_TOO_LONG;
   double *wv = reinterpret_cast<double *>(workspace);
-  int rc = spline_solve(train_points, train_values, N, M, 2, 2, order, regularization_weight, wv,
+  int rc = spline_solve(train_points, train_values, nullptr, N, M, 2, 2, order, regularization_weight, wv,
                         (hipStream_t)stream);
   if (rc != PDT_OK) return rc;
   const int64_t total = N * (M + 3) * 2;

@@ -66,6 +66,7 @@ SIGNATURES = {
         _INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _I64, _P, _P, _P],
     ),
     "pdt_spline_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),
+    "pdt_spline_solve": (_INT, [_P, _P, _P, _I64, _I64, _I64, _I64, _INT, _F, _P, _P, _P]),
     "pdt_polyharmonic_spline": (
         _INT, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _P, _P, _P],
     ),

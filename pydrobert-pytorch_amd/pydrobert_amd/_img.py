@@ -63,8 +63,6 @@ def _polyharmonic_spline_op(
     if train_values.shape[:2] != (N, T) or query_points.shape[0] != N or query_points.shape[2] != I:
         raise RuntimeError("train_points, train_values and query_points have inconsistent shapes")
     device = _cabi.require_hip(train_points, train_values, query_points)
-    if T + I + 1 > 100:
-        raise RuntimeError("polyharmonic_spline: more than {} control points".format(100 - I - 1))
     c, f, x = _f32c(train_points), _f32c(train_values), _f32c(query_points)
     L = _cabi.lib()
     with torch.cuda.device(device):
@@ -83,6 +81,109 @@ def _(train_points, train_values, query_points, order, regularization_weight):
     return train_values.new_empty(
         (train_points.shape[0], query_points.shape[1], train_values.shape[2])
     )
+
+
+def _spline_solve(c: torch.Tensor, f: torch.Tensor, tail: Optional[torch.Tensor], order: int, reg: float):
+    """(N, T+I+1, O) float64 solution of the spline's bordered system for right-hand side
+    [f; tail] (include/pdt_amd.h: pdt_spline_solve)."""
+    N, T, I = c.shape
+    O = f.shape[2]
+    device = c.device
+    L = _cabi.lib()
+    with torch.cuda.device(device):
+        sol = torch.empty((N, T + I + 1, O), device=device, dtype=torch.double)
+        ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, T, I, O)),), device=device, dtype=torch.uint8)
+        rc = L.pdt_spline_solve(
+            _cabi.ptr(c), _cabi.ptr(f), _cabi.ptr(tail), N, T, I, O, int(order), float(reg),
+            _cabi.ptr(sol), _cabi.ptr(ws), _cabi.stream_ptr(device),
+        )  # fmt: skip
+    _cabi.check(rc, "pdt_spline_solve")
+    return sol
+
+
+@custom_op("pydrobert_amd::polyharmonic_spline_backward", mutates_args=())
+def _polyharmonic_spline_backward_op(
+    grad_out: torch.Tensor,
+    train_points: torch.Tensor,
+    train_values: torch.Tensor,
+    query_points: torch.Tensor,
+    order: int,
+    regularization_weight: float,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Gradients of the spline with respect to (train_points, train_values, query_points).
+
+    With M the symmetric bordered matrix, [w; v] = M^-1 [f; 0] and out = Phi(x, c) w + [x 1] v:
+    the adjoint system M lam = [Phi^T G; [x 1]^T G] is solved by the same kernel (float64), the
+    rest are the chain rules of phi(|x - c|) and phi(|c_i - c_j|) -- elementwise / matmul device
+    ops over (N, Q, T) and (N, T, T)."""
+    device = _cabi.require_hip(grad_out, train_points, train_values, query_points)
+    c, f, x = _f32c(train_points), _f32c(train_values), _f32c(query_points)
+    N, T, I = c.shape
+    d = torch.double
+    G = grad_out.detach().to(d)
+    cd, xd = c.to(d), x.to(d)
+    eps = float(torch.finfo(torch.float).eps)
+
+    def phi_and_slope(r):
+        """phi(r) and phi'(r) / r (zero where r = 0: the direction vector vanishes there)."""
+        pos = r > 0
+        safe = torch.where(pos, r, torch.ones_like(r))
+        if order % 2:
+            phi = r**order
+            slope = order * safe ** (order - 2)
+        else:
+            lg = torch.log(safe.clamp(min=eps))
+            phi = r**order * lg
+            inner = torch.where(safe > eps, order * lg + 1.0, torch.full_like(lg, order * math.log(eps)))
+            slope = safe ** (order - 2) * inner
+        return phi, torch.where(pos, slope, torch.zeros_like(slope))
+
+    sol = _spline_solve(c, f, None, order, regularization_weight)  # (N, T+I+1, O)
+    w, v = sol[:, :T], sol[:, T:]
+    dxc = xd.unsqueeze(2) - cd.unsqueeze(1)  # (N, Q, T, I)
+    r_xc = dxc.norm(dim=3)
+    phi_xc, slope_xc = phi_and_slope(r_xc)
+    x1 = torch.cat([xd, torch.ones_like(xd[..., :1])], 2)
+    g_sol = torch.cat([phi_xc.transpose(1, 2) @ G, x1.transpose(1, 2) @ G], 1)  # (N, T+I+1, O)
+    lam = _spline_solve(c, g_sol[:, :T].float().contiguous(), g_sol[:, T:].float().contiguous(), order,
+                        regularization_weight)  # fmt: skip
+    lam_w, lam_v = lam[:, :T], lam[:, T:]
+    g_f = lam_w
+    # through the evaluation: out = Phi(x, c) w + [x 1] v
+    g_phi = (G @ w.transpose(1, 2)) * slope_xc  # (N, Q, T): dL/dPhi * phi'/r
+    g_x = (g_phi.unsqueeze(3) * dxc).sum(2) + G @ v[:, :I].transpose(1, 2)
+    g_c = -(g_phi.unsqueeze(3) * dxc).sum(1)
+    # through the system: dL/dM = -lam sol^T
+    dcc = cd.unsqueeze(2) - cd.unsqueeze(1)  # (N, T, T, I)
+    _, slope_cc = phi_and_slope(dcc.norm(dim=3))
+    g_A = -(lam_w @ w.transpose(1, 2))
+    g_A = (g_A + g_A.transpose(1, 2)) * slope_cc
+    g_c = g_c + (g_A.unsqueeze(3) * dcc).sum(2)
+    g_B = -(lam_w @ v.transpose(1, 2) + w @ lam_v.transpose(1, 2))  # (N, T, I+1)
+    g_c = g_c + g_B[..., :I]
+    return g_c.to(train_points.dtype), g_f.to(train_values.dtype), g_x.to(query_points.dtype)
+
+
+@_polyharmonic_spline_backward_op.register_fake
+def _(grad_out, train_points, train_values, query_points, order, regularization_weight):
+    return (torch.empty_like(train_points), torch.empty_like(train_values), torch.empty_like(query_points))
+
+
+def _spline_setup_context(ctx, inputs, output):
+    train_points, train_values, query_points, order, reg = inputs
+    ctx.save_for_backward(train_points, train_values, query_points)
+    ctx.cfg = (order, reg)
+
+
+def _spline_backward(ctx, grad_out):
+    c, f, x = ctx.saved_tensors
+    g_c, g_f, g_x = torch.ops.pydrobert_amd.polyharmonic_spline_backward(grad_out, c, f, x, ctx.cfg[0], ctx.cfg[1])
+    return g_c, g_f, g_x, None, None
+
+
+register_autograd(
+    "pydrobert_amd::polyharmonic_spline", _spline_backward, setup_context=_spline_setup_context
+)
 
 
 def polyharmonic_spline(
@@ -132,6 +233,40 @@ def _warp_1d_grid_op(
 def _(src, flow, lengths, max_length, interpolation_order):
     T = torch.library.get_ctx().new_dynamic_size() if max_length is None else max_length
     return src.new_empty((src.shape[0], T), dtype=torch.float)
+
+
+def _warp_1d_grid_setup(ctx, inputs, output):
+    src, flow, lengths, _, order = inputs
+    ctx.save_for_backward(src, flow, lengths)
+    ctx.T, ctx.order = output.shape[1], order
+
+
+def _warp_1d_grid_backward(ctx, grad):
+    """The grid is a three-knot spline whose knots are affine (clamped) in src and flow
+    (_img.py:284-302): chain the knots' torch formulas into the spline's own backward."""
+    src, flow, lengths = ctx.saved_tensors
+    T, N = ctx.T, src.shape[0]
+    if T == 0 or N == 0:
+        return torch.zeros_like(src), torch.zeros_like(flow), None, None, None
+    with torch.enable_grad():
+        s0, f0 = src.detach().float().requires_grad_(True), flow.detach().float().requires_grad_(True)
+        ln = lengths.detach().float()
+        eps = float(torch.finfo(torch.float).eps)
+        s = torch.min(s0, ln - 1).clamp_min(0)
+        d = torch.min(s + f0, ln - 1).clamp_min(0)
+        s, d = (2.0 * s + 1.0) / T - 1.0, (2.0 * d + 1.0) / T - 1.0
+        lo = torch.full_like(ln, 1.0 / T - 1.0 - eps)
+        up = (2.0 * ln - 1.0) / T - 1.0 + eps
+        t = ((2.0 * torch.arange(T, device=src.device) + 1.0) / T - 1.0).expand(N, T)
+        grid = torch.ops.pydrobert_amd.polyharmonic_spline(
+            torch.stack([lo, d, up], 1).unsqueeze(-1), torch.stack([lo, s, up], 1).unsqueeze(-1),
+            t.unsqueeze(-1), ctx.order, 0.0,
+        ).squeeze(-1)  # fmt: skip
+        g_s, g_f = torch.autograd.grad(grid, [s0, f0], grad.float())
+    return g_s.to(src.dtype), g_f.to(flow.dtype), None, None, None
+
+
+register_autograd("pydrobert_amd::warp_1d_grid", _warp_1d_grid_backward, setup_context=_warp_1d_grid_setup)
 
 
 def warp_1d_grid(
@@ -197,17 +332,49 @@ def _(grad_out, flow, indexing, mode, padding_mode):
     return grad_out.new_empty(grad_out.shape)
 
 
+def _sampling_grid_from_flow(flow: torch.Tensor, indexing: str, H: int, W: int) -> torch.Tensor:
+    """grid_sample's normalised (x, y) grid for ``output[h, w] = image[h - flow_h, w - flow_w]``
+    (the algebra of reference _img.py:400-433)."""
+    hh, ww = torch.meshgrid(
+        torch.arange(H, dtype=torch.float, device=flow.device),
+        torch.arange(W, dtype=torch.float, device=flow.device), indexing="ij",
+    )  # fmt: skip
+    xy = torch.stack((ww, hh), 2).unsqueeze(0)
+    fl = flow.flip(-1) if indexing == "hw" else flow
+    size = torch.tensor([W, H], dtype=torch.float, device=flow.device)
+    return (2 * xy - 2 * fl + 1.0) / size - 1.0
+
+
 def _dense_setup_context(ctx, inputs, output):
-    _, flow, indexing, mode, padding_mode = inputs
-    ctx.save_for_backward(flow)
+    image, flow, indexing, mode, padding_mode = inputs
+    ctx.needs_flow = flow.requires_grad
+    if ctx.needs_flow:
+        ctx.save_for_backward(flow, image)
+    else:
+        ctx.save_for_backward(flow)
     ctx.cfg = (indexing, mode, padding_mode)
 
 
 def _dense_backward(ctx, grad_out):
-    (flow,) = ctx.saved_tensors
+    flow = ctx.saved_tensors[0]
     indexing, mode, padding_mode = ctx.cfg
-    g = torch.ops.pydrobert_amd.dense_image_warp_backward(grad_out, flow, indexing, mode, padding_mode)
-    return g, None, None, None, None
+    g = None
+    if ctx.needs_input_grad[0]:
+        g = torch.ops.pydrobert_amd.dense_image_warp_backward(grad_out, flow, indexing, mode, padding_mode)
+    g_flow = None
+    if ctx.needs_flow and ctx.needs_input_grad[1]:
+        # the derivative of the bilinear taps with respect to the sampling position: torch's own
+        # grid_sample adjoint on the device, the graph the reference differentiates (:436)
+        image = ctx.saved_tensors[1]
+        with torch.enable_grad():
+            fl = flow.detach().float().requires_grad_(True)
+            grid = _sampling_grid_from_flow(fl, indexing, image.shape[2], image.shape[3])
+            out = torch.nn.functional.grid_sample(
+                image.detach().float(), grid, mode=mode, padding_mode=padding_mode, align_corners=False
+            )
+            (g_flow,) = torch.autograd.grad(out, fl, grad_out.float())
+        g_flow = g_flow.to(flow.dtype)
+    return g, g_flow, None, None, None
 
 
 register_autograd(
@@ -263,8 +430,6 @@ def _sparse_prepare(image, source_points, dest_points, indexing, pinned_boundary
         pp = _pinned_points(pinned_boundary_points, W, H, N, device)
         src, dst = torch.cat([src, pp], 1), torch.cat([dst, pp], 1)
     Mp = src.shape[1]
-    if Mp + 3 > 100:
-        raise RuntimeError("sparse_image_warp: more than 97 control points")
     if include_flow:
         vals = dst - src  # :561-562
     else:
@@ -356,16 +521,63 @@ def _(grad_out, source_points, dest_points, indexing, field_interpolation_order,
 
 
 def _sparse_setup_context(ctx, inputs, output):
-    ctx.save_for_backward(inputs[1], inputs[2])
+    ctx.points_need_grad = inputs[1].requires_grad or inputs[2].requires_grad
+    if ctx.points_need_grad:
+        ctx.save_for_backward(inputs[1], inputs[2], inputs[0])
+    else:
+        ctx.save_for_backward(inputs[1], inputs[2])
     ctx.cfg = tuple(inputs[3:])
 
 
-def _sparse_backward(ctx, grad_warped, _grad_flow):
-    source_points, dest_points = ctx.saved_tensors
-    g = torch.ops.pydrobert_amd.sparse_image_warp_backward(
-        grad_warped, source_points, dest_points, *ctx.cfg
-    )
-    return (g,) + (None,) * 9
+def _sparse_backward(ctx, grad_warped, grad_flow):
+    source_points, dest_points = ctx.saved_tensors[:2]
+    g = None
+    if ctx.needs_input_grad[0]:
+        g = torch.ops.pydrobert_amd.sparse_image_warp_backward(
+            grad_warped, source_points, dest_points, *ctx.cfg
+        )
+    g_src = g_dst = None
+    if ctx.points_need_grad:
+        # control points: the spline (its own backward kernel path) chained into the gather's
+        # position derivative, as the reference's graph does (_img.py:561-585, :633-655)
+        image = ctx.saved_tensors[2]
+        indexing, order, reg, pinned, mode, padding, include_flow = ctx.cfg
+        N, C, H, W = image.shape
+        if source_points.shape[1]:
+            with torch.enable_grad():
+                s0 = source_points.detach().float().requires_grad_(True)
+                d0 = dest_points.detach().float().requires_grad_(True)
+                src, dst = (s0.flip(-1), d0.flip(-1)) if indexing == "hw" else (s0, d0)
+                if pinned > 0:
+                    pp = _pinned_points(pinned, W, H, N, image.device)
+                    src, dst = torch.cat([src, pp], 1), torch.cat([dst, pp], 1)
+                hh, ww = torch.meshgrid(
+                    torch.arange(H, dtype=torch.float, device=image.device),
+                    torch.arange(W, dtype=torch.float, device=image.device), indexing="ij",
+                )  # fmt: skip
+                query = torch.stack([ww.flatten(), hh.flatten()], 1).unsqueeze(0).expand(N, H * W, 2)
+                size = torch.tensor([W, H], dtype=torch.float, device=image.device)
+                outs, grads = [], []
+                if include_flow:
+                    flow = torch.ops.pydrobert_amd.polyharmonic_spline(dst, dst - src, query, order, reg)
+                    flow = flow.view(N, H, W, 2)
+                    grid = _sampling_grid_from_flow(flow, "wh", H, W)
+                    if grad_flow is not None:
+                        outs.append(flow.flip(-1) if indexing == "hw" else flow)
+                        grads.append(grad_flow.float())
+                else:
+                    grid = torch.ops.pydrobert_amd.polyharmonic_spline(
+                        dst, (2.0 * src + 1.0) / size - 1.0, query, order, reg
+                    ).view(N, H, W, 2)
+                warped = torch.nn.functional.grid_sample(
+                    image.detach().float(), grid, mode=mode, padding_mode=padding, align_corners=False
+                )
+                outs.append(warped)
+                grads.append(grad_warped.float())
+                g_src, g_dst = torch.autograd.grad(outs, [s0, d0], grads, allow_unused=True)
+            g_src = None if g_src is None else g_src.to(source_points.dtype)
+            g_dst = None if g_dst is None else g_dst.to(dest_points.dtype)
+    return (g, g_src, g_dst) + (None,) * 7
 
 
 register_autograd(

@@ -315,3 +315,128 @@ def test_spec_augment_rows_backward_any_grid(device, monotone):
     # deterministic: the same call twice gives the same bits
     (again,) = torch.autograd.grad(torch.ops.pydrobert_amd.spec_augment_apply(x, tgrid, None, t_0, t, f_0, f), x, g)
     assert torch.equal(act, again)
+
+
+# ---------------------------------------------------------------------------------------
+# gradients with respect to points / values / flow (the reference's ops are plain torch graphs)
+# ---------------------------------------------------------------------------------------
+def _torch_phi(r, k):
+    eps = float(torch.finfo(torch.float).eps)
+    return r**k if k % 2 else r**k * torch.log(r.clamp(min=eps))
+
+
+def _torch_spline(c, f, x, k, reg=0.0):
+    """The reference's spline as a float64 torch graph (_img.py:67-130), for autograd."""
+    N, T, I = c.shape
+    cdist = lambda a, b: torch.cdist(a, b, compute_mode="donot_use_mm_for_euclid_dist")  # noqa: E731 (exact differences)
+    A = _torch_phi(cdist(c, c), k) + reg * torch.eye(T, dtype=c.dtype)
+    B = torch.cat([c, torch.ones_like(c[..., :1])], 2)
+    M_ = torch.cat([torch.cat([A, B], 2), torch.cat([B.transpose(1, 2), c.new_zeros(N, I + 1, I + 1)], 2)], 1)
+    sol = torch.linalg.solve(M_, torch.cat([f, f.new_zeros(N, I + 1, f.shape[2])], 1))
+    return _torch_phi(cdist(x, c), k) @ sol[:, :T] + torch.cat([x, torch.ones_like(x[..., :1])], 2) @ sol[:, T:]
+
+
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_polyharmonic_spline_gradients(device, order):
+    rng = np.random.default_rng(40 + order)
+    for reg in (0.0, 0.05):
+        N, T, I, O, Q = 2, 7, 2, 3, 11
+        c = (rng.uniform(size=(N, T, I)) * 4).astype(np.float32)
+        f = rng.normal(size=(N, T, O)).astype(np.float32)
+        x = (rng.uniform(size=(N, Q, I)) * 4).astype(np.float32)
+        G = rng.normal(size=(N, Q, O)).astype(np.float32)
+        ref = [torch.from_numpy(a).double().requires_grad_(True) for a in (c, f, x)]
+        (_torch_spline(*ref, order, reg) * torch.from_numpy(G).double()).sum().backward()
+        dev = [_t(a, device).requires_grad_(True) for a in (c, f, x)]
+        out = F.polyharmonic_spline(*dev, order, reg)
+        (out * _t(G, device)).sum().backward()
+        for name, a, b in zip("cfx", dev, ref):
+            err = (a.grad.cpu().double() - b.grad).abs().max() / b.grad.abs().max()
+            assert err < 1e-3, (name, order, reg, float(err))
+
+
+def test_polyharmonic_spline_many_points(device):
+    """Systems beyond the LDS (more than ~140 unknowns) are eliminated in the workspace."""
+    rng = np.random.default_rng(9)
+    N, T, I, O, Q = 2, 180, 2, 2, 40
+    c = rng.uniform(-3, 3, (N, T, I)).astype(np.float32)
+    f = rng.normal(size=(N, T, O)).astype(np.float32)
+    x = rng.uniform(-3, 3, (N, Q, I)).astype(np.float32)
+    for order in (1, 3):
+        exp = oracle.polyharmonic_spline(c, f, x, order)
+        act = F.polyharmonic_spline(_t(c, device), _t(f, device), _t(x, device), order).cpu().numpy()
+        assert np.allclose(exp, act, atol=2e-3 * max(1.0, np.abs(exp).max())), np.abs(exp - act).max()
+        back = F.polyharmonic_spline(_t(c, device), _t(f, device), _t(c, device), order).cpu().numpy()
+        assert np.allclose(back, f, atol=5e-3)
+
+
+def test_warp_1d_grid_gradients(device):
+    # (knots kept off the integer frames: with order 1 the spline has a kink wherever a query
+    # point meets a knot, and every implementation picks its own subgradient there)
+    src = torch.tensor([10.3, 12.7, 15.2, 3.4])
+    flow = torch.tensor([2.1, -3.3, 1.5, 1.2])
+    lens = torch.tensor([20.0, 25.0, 30.0, 7.0])
+    T = 30
+    for order in (1, 2):
+        s, f = src.double().requires_grad_(True), flow.double().requires_grad_(True)
+        eps = float(torch.finfo(torch.float).eps)
+        ss = torch.min(s, lens.double() - 1).clamp_min(0)
+        dd = torch.min(ss + f, lens.double() - 1).clamp_min(0)
+        ss, dd = (2 * ss + 1) / T - 1, (2 * dd + 1) / T - 1
+        lo = torch.full_like(ss, 1 / T - 1 - eps)
+        up = (2 * lens.double() - 1) / T - 1 + eps
+        t = ((2.0 * torch.arange(T) + 1) / T - 1).double().expand(4, T)
+        grid = _torch_spline(torch.stack([lo, dd, up], 1).unsqueeze(-1), torch.stack([lo, ss, up], 1).unsqueeze(-1),
+                             t.unsqueeze(-1), order).squeeze(-1)  # fmt: skip
+        w = torch.randn(4, T, dtype=torch.double)
+        (grid * w).sum().backward()
+        s2, f2 = src.to(device).requires_grad_(True), flow.to(device).requires_grad_(True)
+        g2 = F.warp_1d_grid(s2, f2, lens.to(device), T, order)
+        (g2 * w.float().to(device)).sum().backward()
+        assert torch.allclose(s2.grad.cpu().double(), s.grad, rtol=2e-3, atol=1e-5), order
+        assert torch.allclose(f2.grad.cpu().double(), f.grad, rtol=2e-3, atol=1e-5), order
+
+
+@pytest.mark.parametrize("include_flow", [True, False])
+def test_warps_gradients_wrt_flow_and_points(device, include_flow):
+    """dense_image_warp w.r.t. the flow and sparse_image_warp w.r.t. both point sets, against the
+    reference's formulation as a float64 torch graph (spline -> grid -> grid_sample)."""
+    rng = np.random.default_rng(21)
+    N, C, H, W, Mp = 2, 2, 9, 7, 4
+    img = torch.from_numpy(rng.uniform(size=(N, C, H, W)))
+    flow = torch.from_numpy(rng.normal(size=(N, H, W, 2)) * 0.7)
+    w = torch.from_numpy(rng.normal(size=(N, C, H, W)))
+    hh, ww = torch.meshgrid(torch.arange(H, dtype=torch.double), torch.arange(W, dtype=torch.double), indexing="ij")
+    xy = torch.stack((ww, hh), 2).unsqueeze(0)
+    size = torch.tensor([W, H], dtype=torch.double)
+
+    fl = flow.clone().requires_grad_(True)
+    out = torch.nn.functional.grid_sample(img, (2 * xy - 2 * fl.flip(-1) + 1) / size - 1, mode="bilinear",
+                                          padding_mode="border", align_corners=False)  # fmt: skip
+    (out * w).sum().backward()
+    fl2 = flow.float().to(device).requires_grad_(True)
+    im2 = img.float().to(device).requires_grad_(True)
+    out2 = F.dense_image_warp(im2, fl2)
+    (out2 * w.float().to(device)).sum().backward()
+    assert torch.allclose(fl2.grad.cpu().double(), fl.grad, rtol=1e-3, atol=1e-5)
+    assert im2.grad is not None
+
+    src = torch.from_numpy(rng.uniform(size=(N, Mp, 2)) * [H - 1, W - 1])
+    dst = src + torch.from_numpy(rng.normal(size=(N, Mp, 2)) * 0.5)
+    s, d = src.clone().requires_grad_(True), dst.clone().requires_grad_(True)
+    sx, dx = s.flip(-1), d.flip(-1)
+    query = torch.stack([ww.flatten(), hh.flatten()], 1).unsqueeze(0).expand(N, H * W, 2)
+    if include_flow:
+        fxy = _torch_spline(dx, dx - sx, query, 2).view(N, H, W, 2)
+        grid = (2 * xy - 2 * fxy + 1) / size - 1
+    else:
+        grid = _torch_spline(dx, (2 * sx + 1) / size - 1, query, 2).view(N, H, W, 2)
+    out = torch.nn.functional.grid_sample(img, grid, mode="bilinear", padding_mode="border", align_corners=False)
+    (out * w).sum().backward()
+    s2, d2 = src.float().to(device).requires_grad_(True), dst.float().to(device).requires_grad_(True)
+    res = F.sparse_image_warp(img.float().to(device), s2, d2, include_flow=include_flow)
+    warped = res[0] if include_flow else res
+    (warped * w.float().to(device)).sum().backward()
+    for name, a, b in (("source", s2, s), ("dest", d2, d)):
+        err = (a.grad.cpu().double() - b.grad).abs().max() / b.grad.abs().max()
+        assert err < 5e-3, (name, include_flow, float(err))
