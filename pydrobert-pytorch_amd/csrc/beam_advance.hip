@@ -156,9 +156,13 @@ __global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) 
   int *toks = srcs + W;
   int *plens = toks + W;
 
-  // per-prefix sorted lists of the best tokens
+  // per-prefix lists of the best tokens, ranked by the candidate value itself -- the float32 sum
+  // log_probs_prev[k] + log_probs_t[k, v] (:122) -- so that candidates whose SUMS are equal come
+  // out lowest token first although their log_probs_t differ: with "lowest lane first" in the
+  // merge below an exact tie goes to the lowest flat index k * V + v, the oracle's order
   for (int k = 0; k < Kp; ++k) {
-    const u64 tk = wave_top_sorted_strided(a.lpt + n * a.lt_sn + k * a.lt_sk, a.lt_sv, V, M, surv);
+    const u64 tk = wave_top_sorted_strided<false, false, true>(
+        a.lpt + n * a.lt_sn + k * a.lt_sk, a.lt_sv, V, M, surv, nullptr, nullptr, 1, a.lpp[n * a.lp_sn + k * a.lp_sk]);
     if (lane < M) tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
     wave_sync();
   }

@@ -466,6 +466,30 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     if (rr == R - 2) { key2 = (kvalid && o1) ? fkey_nonneg(m1_k) : 0u; tk2 = lastc_k; }
     if (rr == R - 1) { key2 = (kvalid && o2) ? fkey_nonneg(m2_k) : 0u; tk2 = lastc_k; }
   }
+  // Exact ties (rare; the reference's torch.topk leaves them unspecified): equal masses go to the
+  // lowest flat candidate index of the reference's layout -- extension (k, v) at k * V + v, the
+  // non-extension of k at K' * V + k.  Rank of a resident candidate among equals: (prefix, list
+  // position) for extensions -- the list is (value, token) ordered; the last-token stream ranks
+  // just before the entry at its own position -- and every non-extension after every extension.
+  // Only evaluated when a tie has been seen.
+  auto tie_rank = [&](const int slot, const int tk) -> unsigned {
+    const int e = rr + R * slot;
+    if (e == n_main + 1) return (unsigned)(32 + kb) * 128u;
+    int j = 63;  // (a bound, or a last token outside the list: after every entry)
+    if (e == n_main) {
+      const int jl_k = shfl_i(jl, ksrc);
+      j = jl_k >= 0 ? jl_k : 63;
+    } else if (tk >= 0 && e < n_main) {
+      if (DENSE) {
+        const int *lt = L.tl_tok + ksrc * PDT_WAVE;
+        for (int q = 0; q < M; ++q) j = lt[q] == tk ? q : j;
+      } else {
+        const int q = L.pos[tk];
+        j = q == 0xFF ? 63 : q;
+      }
+    }
+    return (unsigned)kb * 128u + (unsigned)(2 * j + (e == n_main ? 0 : 1));
+  };
   // Fast path: the K winners all at once.  A lane holding a winner has a local maximum >= the
   // K-th best candidate, and at most K lanes do, so tau = K-th largest local maximum bounds
   // the winners from below; the (>= K, usually ~K) resident candidates >= tau are compacted
@@ -489,29 +513,44 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       auto below = [&](u64 b) {
         return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
       };
-      sel[lane] = (u64)fresh_zero();
-      wave_sync();
-      if (p0) sel[below(b0)] = pack_key(key0, (unsigned)(lane * 4 + 0));
-      if (p1) sel[c0 + below(b1)] = pack_key(key1, (unsigned)(lane * 4 + 1));
-      if (p2) sel[c0 + c1 + below(b2)] = pack_key(key2, (unsigned)(lane * 4 + 2));
-      wave_sync();
-      // rank by counting: the packed keys are distinct, so the number of larger survivors is
-      // a survivor's position in the sorted order (2 VALU per survivor instead of a 21-stage
-      // bitonic network; the LDS reads are same-address broadcasts)
-      const u64 mine = sel[lane];
-      int rank = 0;
-      for (int j = 0; j < count; j += 4) {
-        const u64 o0 = sel[j], o1 = sel[j + 1], o2 = sel[j + 2], o3 = sel[j + 3];
-        rank += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
+      // low word of a packed key: [tie rank <<] (lane, slot) locator.  Ranking runs on the bare
+      // locators; only if two of the first K + 1 survivors have EQUAL masses is it repeated with
+      // tie ranks (see tie_rank: lowest flat candidate index first, as the oracle orders them)
+      auto rank_survivors = [&](const bool with_ties) -> u64 {
+        sel[lane] = (u64)fresh_zero();
+        wave_sync();
+        const unsigned r0 = with_ties ? tie_rank(0, tk0) << 8 : 0u, r1 = with_ties ? tie_rank(1, tk1) << 8 : 0u,
+                       r2 = with_ties ? tie_rank(2, tk2) << 8 : 0u;
+        if (p0) sel[below(b0)] = pack_key(key0, r0 | (unsigned)(lane * 4 + 0));
+        if (p1) sel[c0 + below(b1)] = pack_key(key1, r1 | (unsigned)(lane * 4 + 1));
+        if (p2) sel[c0 + c1 + below(b2)] = pack_key(key2, r2 | (unsigned)(lane * 4 + 2));
+        wave_sync();
+        // rank by counting: the packed keys are distinct, so the number of larger survivors is
+        // a survivor's position in the sorted order (2 VALU per survivor instead of a 21-stage
+        // bitonic network; the LDS reads are same-address broadcasts)
+        const u64 mine = sel[lane];
+        int rank = 0;
+        for (int j = 0; j < count; j += 4) {
+          const u64 o0 = sel[j], o1 = sel[j + 1], o2 = sel[j + 2], o3 = sel[j + 3];
+          rank += (o0 > mine) + (o1 > mine) + (o2 > mine) + (o3 > mine);
+        }
+        wave_sync();
+        if (lane < count && rank <= K) sel[rank] = mine;  // (one more than the winners: the tie check)
+        wave_sync();
+        const u64 top = (lane <= K && lane < count) ? sel[lane] : 0ull;
+        wave_sync();  // sel is nxt_new: the is-prefix update below writes it
+        return top;
+      };
+      u64 s = rank_survivors(false);
+      {
+        const unsigned k_next = (unsigned)__builtin_amdgcn_mov_dpp((int)key_of(s), 0x130, 0xf, 0xf, true);  // wave_shl:1
+        // (masses that have underflowed to 0 all tie: nothing meaningful is left to order there)
+        if (__ballot(lane < K && key_of(s) > 1u && key_of(s) == k_next) != 0ull) s = rank_survivors(true);
       }
-      wave_sync();
-      if (lane < count && rank < K) sel[rank] = mine;
-      wave_sync();
-      const u64 s = (lane < K && lane < count) ? sel[lane] : 0ull;
-      wave_sync();  // sel is nxt_new: the is-prefix update below writes it
+      if (lane >= K) s = 0ull;
       const unsigned wkey = key_of(s);
       const bool isw = lane < K && wkey != 0u;
-      const int id = isw ? (int)idx_of(s) : 0;
+      const int id = isw ? (int)(idx_of(s) & 255u) : 0;
       const int wl = id >> 2, sw = id & 3;
       const int e = (wl >> GS) + R * sw;
       if (__ballot(isw && e == n_main - 1) == 0ull) {
@@ -536,9 +575,14 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     const unsigned lk = max(max(key0, key1), key2);
     const unsigned mx = wave_max_u32(lk);
     if (mx == 0u) break;  // fewer valid candidates than K: the rest stay invalid (:902-924)
-    const int win = (int)__builtin_ctzll(__ballot(lk == mx));
     const int sw_l = key0 == mx ? 0 : (key1 == mx ? 1 : 2);
     const int tw_l = key0 == mx ? tk0 : (key1 == mx ? tk1 : tk2);
+    const u64 at_max = __ballot(lk == mx);
+    int win = (int)__builtin_ctzll(at_max);
+    if ((at_max & (at_max - 1ull)) && mx > 1u) {  // several lanes hold the (non-zero) maximum: lowest flat index first
+      const unsigned inv = lk == mx ? ~((tie_rank(sw_l, tw_l) << 6) | (unsigned)lane) : 0u;
+      win = (int)(~wave_max_u32(inv) & 63u);
+    }
     const int sw = __builtin_amdgcn_readlane(sw_l, win);
     const int wtok = __builtin_amdgcn_readlane(tw_l, win);
     if (wtok < 0) {  // a bound: the short list is not enough for this frame

@@ -255,15 +255,18 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // the values in registers), so the first pass over x is skipped.
 // probe / probe_rank: if given (and V > 64), *probe receives the probe_rank-th largest per-lane
 // maximum (as a key) -- a by-product callers use to guess the next row's threshold.
-template <bool LONG = false, bool NONNEG = false>
+// BIAS: the ranked values are bias + x[v] (one float32 add, as the caller's own arithmetic forms
+// them): elements whose sums round to the same float tie and come out lowest index first, even
+// when their x differ.
+template <bool LONG = false, bool NONNEG = false, bool BIAS = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
                                                        int M, u64 *surv,
                                                        const unsigned *lmax_in = nullptr,
                                                        unsigned *probe = nullptr,
-                                                       int probe_rank = 1) {
+                                                       int probe_rank = 1, float bias = 0.0f) {
   int lane = lane_id();
   asm volatile("" : "+v"(lane));  // nothing lane-derived is hoisted out of the caller's frame loop
-  auto X = [&](int v) { return xb[(int64_t)v * sx]; };
+  auto X = [&](int v) { return BIAS ? bias + xb[(int64_t)v * sx] : xb[(int64_t)v * sx]; };
   auto fkey = [](float f) { return NONNEG ? fkey_nonneg(f) : pdt::fkey(f); };
   if (V <= PDT_WAVE) {
     const u64 k = lane < V ? pack_key(fkey(X(lane)), (unsigned)lane) : 0ull;

@@ -477,3 +477,48 @@ def test_beam_search_trains_through_its_log_probs(device):
     lp_p, lp_m = run(table.detach() + eps * d)[1], run(table.detach() - eps * d)[1]
     fd = (F.minimum_error_rate_loss(lp_p, ref, y, warn=False) - F.minimum_error_rate_loss(lp_m, ref, y, warn=False)) / (2 * eps)
     assert abs(float(fd) - float((g * d).sum())) < 5e-2 * max(1.0, abs(float(fd))), (float(fd), float((g * d).sum()))
+
+
+# ---------------------------------------------------------------------------------------
+# exact ties: the lowest flat candidate index wins, in the kernels and in the oracle alike
+# ---------------------------------------------------------------------------------------
+def test_beam_search_advance_exact_ties(device):
+    """Candidates whose float32 SUMS are equal although their log_probs_t differ (the rounding of
+    log_probs_prev + log_probs_t merges them), equal log_probs_t inside one beam, and equal sums
+    across beams: flat index k * V + v decides."""
+    # (a) one beam, prev = 2^20: the ulp there is 1/8, so 0.01, 0.02 and 0.03 all round away
+    lpt = torch.tensor([[[0.03, 0.01, -5.0, 0.02, -9.0, 0.03]]])
+    lpp = torch.tensor([[1048576.0]])
+    assert len({float(lpp[0, 0] + x) for x in lpt[0, 0, [0, 1, 3, 5]]}) == 1  # the sums do tie
+    y = torch.zeros((0, 1, 1), dtype=torch.long)
+    exp = oracle.beam_search_advance(lpt.numpy(), 4, lpp.numpy(), y.numpy())
+    act = F.beam_search_advance(lpt.to(device), 4, lpp.to(device), y.to(device))
+    assert act[0][0, 0].tolist() == exp[0][0, 0].tolist() == [0, 1, 3, 5]
+    # (b) random cases built from few distinct values: ties everywhere, inside and across beams
+    rng = np.random.default_rng(12)
+    for it in range(200):
+        N, Kp, V = int(rng.integers(1, 4)), int(rng.integers(1, 6)), int(rng.integers(2, 40))
+        W = int(rng.integers(1, 12))
+        lpt = rng.choice(np.array([-1.0, -1.5, -2.0, -3.0], np.float32), (N, Kp, V))
+        lpp = rng.choice(np.array([0.0, -0.5, -1.0, 1e6], np.float32), (N, Kp))
+        yp = rng.integers(0, V, (2, N, Kp))
+        exp = oracle.beam_search_advance(lpt, W, lpp, yp)
+        act = [x.cpu().numpy() for x in F.beam_search_advance(*(torch.from_numpy(a).to(device) for a in (lpt,)), W,
+                                                               torch.from_numpy(lpp).to(device), torch.from_numpy(yp).to(device))]  # fmt: skip
+        K = min(W, Kp * V)
+        assert np.array_equal(act[3], exp[3]) and np.array_equal(act[2], exp[2]), it
+        assert np.array_equal(act[0][..., :K], exp[0][..., :K]), it
+
+
+def test_ctc_prefix_search_exact_ties(device):
+    """Tokens with IDENTICAL logits give extensions of one prefix identical masses; the list is
+    ordered (value, then token), so the lower token wins -- the oracle's flat index order.  The
+    keys of such candidates collide in the lean tier's rounded 32-bit sort, which must hand the
+    frame to the exact tiers instead of guessing."""
+    rng = np.random.default_rng(4)
+    for V, K, T in [(6, 4, 1), (20, 8, 1), (70, 16, 1), (300, 16, 1), (12, 5, 2)]:
+        lg = rng.normal(size=(T, 3, V + 1)).astype(np.float32)
+        lg[0, :, 1::2] = lg[0, :, : V + 1 : 2][:, : lg[0, :, 1::2].shape[1]]  # pairs (2i, 2i + 1) share a logit
+        exp = oracle.ctc_prefix_search(lg[:1], K)
+        act = F.ctc_prefix_search(torch.from_numpy(lg[:1]).to(device), K)
+        _check_search(act, exp, ("ties", V, K))
