@@ -13,6 +13,8 @@ rm -rf $out && mkdir -p $out
 MB=profiles/microbench/microbench
 $MB issue > $out/valu_issue.json
 $MB traffic > $out/traffic_rates.json
+$MB stores > $out/store_patterns.json
+$MB tiles > $out/store_tiles.json
 rocprofv3 --kernel-trace --stats -d $out/stats -o bench --output-format csv -- \
   python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $out/bench_line.json 2> $out/bench.err
 rocprofv3 --kernel-trace --stats -d $out/opstats -o ops --output-format csv -- python3 profiles/prof_ops.py > $out/ops.log 2>&1
