@@ -132,18 +132,18 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *   y      (S, N, width) int64 contiguous; every element is written (rows beyond a prefix's
  *          length are 0; the reference leaves them undefined);
  *   y_lens (N, width) int64, y_probs (N, width) float32 (probabilities, not logs).
- *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, width) bytes of scratch
- *          (the prefix trie: one (parent, token) record per frame and beam entry, and the
- *          checkpoints of the output walk).
+ *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, V, width) bytes of scratch
+ *          (the prefix trie: one (parent, token) record per frame and beam entry, the
+ *          checkpoints of the output walk and, for rows beyond the LDS, the rows of the ring).
  *   width <= 32.  S must be at least min(T, max lens): frames beyond S are not decoded.
- *   Rows of up to about 16 000 tokens fit (one row of probabilities per ring slot in the
- *   160 KB of LDS); longer ones return PDT_E_TOO_LONG.
+ *   Rows of up to about 16 000 tokens live in LDS (one row of probabilities per ring slot);
+ *   longer ones stay in the workspace (L2-resident), any V below 2^30.
  * pdt_ctc_prefix_search_plan (host only, no device work): the launch configuration the library
  *   picks for rows of V tokens and this width -- plan4 = {producer waves per utterance, ring
- *   slots, utterances per workgroup, 1 if a row is held in the producer's registers} -- or
- *   PDT_E_TOO_LONG.  Lets callers and tests see where the configurations change.
+ *   slots, utterances per workgroup, where a row is held: 1 the producer's registers, 0 LDS,
+ *   2 the workspace}.  Lets callers and tests see where the configurations change.
  * ------------------------------------------------------------------------------------- */
-int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t width);
+int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t V, int64_t width);
 
 int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4);
 

@@ -45,6 +45,7 @@ struct CtcArgs {
   // (node, length | origin << 24) -- origin = the entry of the previous checkpoint it descends
   // from -- so the prefixes are read off the trie in parallel segments, not one 'T-hop chain.
   int2 *ckpt;           // (N, ckpt_count, W)
+  unsigned char *grow;  // rows of the ring for vocabularies beyond the LDS (ctc_search.hip: RingLayout)
   int ckpt_shift, ckpt_count;
   int lds_per_wave, waves_per_wg;
 };

@@ -94,14 +94,22 @@ struct RingLayout {
   int utt_bytes;    // ring + consumer scratch + producer scratch + flags
   int utt_per_wg;
   int producers;    // producer waves per utterance
+  // rows too long for any LDS ring: the row of probabilities and the token -> list-position table
+  // of every slot live in the HBM workspace instead (g_slot_bytes per slot, L2-resident); the LDS
+  // slot keeps the list and the header
+  int row_global, g_slot_bytes;
 };
 
 __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int utt_per_wg,
-                                                  int producers) {
+                                                  int producers, bool row_global = false) {
   RingLayout r;
   r.row_floats = (V + 1 + 3) & ~3;
   r.pos_bytes = (V + 15) & ~15;
-  r.slot_bytes = r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
+  r.row_global = row_global ? 1 : 0;
+  r.g_slot_bytes = row_global ? r.row_floats * 4 + r.pos_bytes : 0;
+  // (8 KiB per slot at least in that form: the freed ring holds the checkpoint table of the
+  // output walk)
+  r.slot_bytes = row_global ? 8192 : r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
   r.nstage = nstage;
   const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
   r.utt_bytes = (r.slot_bytes * nstage + consumer + producers * PDT_SURV_CAP * 8 + 32 + 15) & ~15;
@@ -124,10 +132,12 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 // INREG (P = 1 only): the whole row, V + 1 <= 512 elements, sits in the eight prefetch registers
 // of the producer's lanes.  P = 1 without it is the last resort for rows so long that only a
 // two-slot ring of one producer fits in LDS: the generic LDS-staged row pass of the P > 1 forms.
-template <int P, int NT = -1, bool INREG = (P == 1)>
+// GROW (P = 1, generic row pass): rows no LDS ring can hold -- see RingLayout::row_global.
+template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
 __global__ void __launch_bounds__(256, INREG ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
+  static_assert(!GROW || (P == 1 && !INREG), "rows in the workspace are a form of the generic one-producer pass");
   static_assert(NT < 0 || INREG, "compile-time chunk counts belong to the register-resident row pass");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -153,11 +163,23 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
   int *ready = consumed + 1;                                          // [nstage] frame + 1 held by a slot
   int *want_full = ready + 4;  // consumer -> producers: the lean tier keeps failing, send complete lists
-  auto slot_row = [&](int sl) { return reinterpret_cast<float *>(ring + (size_t)sl * rl.slot_bytes); };
-  auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(slot_row(sl) + rl.row_floats); };
+  // slot: [row of probabilities | list tokens | list probabilities | token -> position | header];
+  // GROW keeps the first and the fourth in the workspace
+  unsigned char *gring = GROW ? a.grow + (size_t)n * rl.nstage * rl.g_slot_bytes : nullptr;
+  auto slot_row = [&](int sl) {
+    return reinterpret_cast<float *>(GROW ? gring + (size_t)sl * rl.g_slot_bytes : ring + (size_t)sl * rl.slot_bytes);
+  };
+  auto slot_tok = [&](int sl) {
+    return reinterpret_cast<int *>(ring + (size_t)sl * rl.slot_bytes + (GROW ? 0 : (size_t)rl.row_floats * 4));
+  };
   auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
-  auto slot_pos = [&](int sl) { return reinterpret_cast<unsigned char *>(slot_p(sl) + PDT_WAVE); };
-  auto slot_hdr = [&](int sl) { return reinterpret_cast<float *>(slot_pos(sl) + rl.pos_bytes); };
+  auto slot_pos = [&](int sl) {
+    return GROW ? reinterpret_cast<unsigned char *>(slot_row(sl) + rl.row_floats)
+                : reinterpret_cast<unsigned char *>(slot_p(sl) + PDT_WAVE);
+  };
+  auto slot_hdr = [&](int sl) {
+    return GROW ? slot_p(sl) + PDT_WAVE : reinterpret_cast<float *>(slot_pos(sl) + rl.pos_bytes);
+  };
   // frames of this utterance; never more than the S rows of y the caller allocated
   const int Tn = min(a.S, a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T);
   const int NS = rl.nstage;
@@ -575,16 +597,16 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #endif
 }
 
-template <int P, int NT = -1, bool INREG = (P == 1)>
+template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
 static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG, GROW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
+  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG, GROW>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
                      stream, a, rl);
   return (int)hipGetLastError();
 }
@@ -592,7 +614,8 @@ static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream
 // checkpoint spacing: 32 frames, doubled until the (C + 1) x W table of the output walk fits in
 // the smallest ring any launch configuration uses (2 slots)
 __host__ inline int ckpt_shift_for(int T, int V, int W) {
-  const size_t ring2 = (size_t)ring_layout(V, W, 2, 1, 1).slot_bytes * 2;
+  size_t ring2 = (size_t)ring_layout(V, W, 2, 1, 1).slot_bytes * 2;
+  if (ring2 > 160 * 1024) ring2 = (size_t)ring_layout(V, W, 2, 1, 1, true).slot_bytes * 2;  // rows in the workspace
   int sh = 5;
   while (((size_t)(T >> sh) + 1) * W * sizeof(int2) > ring2) ++sh;
   return sh;
@@ -617,7 +640,9 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
     // the longest rows LDS can hold at all
     *rl = ring_layout(V, W, 2, 1, 1);
     if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{1, 2, 1, 0}, PDT_OK;
-    return PDT_E_TOO_LONG;
+    // beyond: the rows stay in the HBM workspace
+    *rl = ring_layout(V, W, 4, 1, 1, true);
+    return *plan = CtcPlan{1, 4, 1, 2}, PDT_OK;
   }
   // ring depth and utterances per workgroup from the LDS budget
   int nstage = PDT_RING_STAGES, upw = PDT_UTT_PER_WG;
@@ -637,6 +662,7 @@ int launch_ctc_search(CtcArgs a, hipStream_t stream) {
   if (rc != PDT_OK) return rc;
   if (plan.producers == 3) return launch_ctc_search_p<3>(a, rl, stream);
   if (plan.producers == 2) return launch_ctc_search_p<2>(a, rl, stream);
+  if (plan.inreg == 2) return launch_ctc_search_p<1, -1, false, true>(a, rl, stream);
   if (!plan.inreg) return launch_ctc_search_p<1, -1, false>(a, rl, stream);
   if (a.V / PDT_WAVE == 4) return launch_ctc_search_p<1, 4>(a, rl, stream);
   return launch_ctc_search_p<1>(a, rl, stream);
@@ -646,10 +672,20 @@ int launch_ctc_search(CtcArgs a, hipStream_t stream) {
 
 extern "C" {
 
-int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t width) {
-  if (T < 0 || N < 0 || width < 0) return 0;
+static int64_t ctc_trie_bytes(int64_t T, int64_t N, int64_t width) {
   // trie records + checkpoints (at most one per 32 frames)
-  return (T + T / 32 + 1) * N * width * (int64_t)sizeof(int2) + 16;
+  return ((T + T / 32 + 1) * N * width * (int64_t)sizeof(int2) + 255) & ~(int64_t)255;
+}
+
+int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t V, int64_t width) {
+  if (T < 0 || N < 0 || V < 1 || width < 1 || V >= (1 << 30)) return 0;
+  int64_t bytes = ctc_trie_bytes(T, N, width) + 16;
+  pdt::CtcPlan plan;
+  pdt::RingLayout rl;
+  if (pdt::plan_ctc_search((int)V, (int)(width > pdt::kMaxWidth ? pdt::kMaxWidth : width), &plan, &rl) == PDT_OK &&
+      rl.row_global)
+    bytes += N * (int64_t)rl.nstage * rl.g_slot_bytes;  // the rows of the ring
+  return bytes;
 }
 
 int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4) {
@@ -680,6 +716,7 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   a.y = y; a.y_lens = y_lens; a.y_probs = y_probs;
   a.trie = reinterpret_cast<int2 *>(workspace);
   a.ckpt = a.trie + T * N * width;
+  a.grow = reinterpret_cast<unsigned char *>(workspace) + ctc_trie_bytes(T, N, width);
   a.ckpt_shift = pdt::ckpt_shift_for((int)T, (int)V, (int)width);
   a.ckpt_count = (int)(T >> a.ckpt_shift) + 1;
   return launch_ctc_search(a, (hipStream_t)stream);

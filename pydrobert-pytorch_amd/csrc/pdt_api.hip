@@ -54,7 +54,7 @@ static int fill_common(LevArgs &a, const int64_t *ref, int64_t R, int64_t ref_st
 
 extern "C" {
 
-int pdt_amd_abi_version(void) { return 1; }
+int pdt_amd_abi_version(void) { return 2; }  // 2: pdt_ctc_prefix_search_workspace_bytes takes V
 
 int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
             int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,

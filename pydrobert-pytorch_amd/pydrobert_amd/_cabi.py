@@ -98,7 +98,7 @@ SIGNATURES = {
     ),
     "pdt_pad_variable": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _INT, _P, _I64, _P, _P]),
     "pdt_pad_variable_backward": (_INT, [_P, _I64, _I64, _I64, _P, _P, _INT, _I64, _P, _P]),
-    "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64]),
+    "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),
     "pdt_ctc_prefix_search_plan": (_INT, [_I64, _I64, _P]),
     "pdt_ctc_prefix_search": (
         _INT,

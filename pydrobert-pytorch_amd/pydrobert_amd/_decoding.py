@@ -404,7 +404,7 @@ def _ctc_prefix_search_op(
         y_lens = torch.empty((N, width), device=device, dtype=torch.long)
         y_probs = torch.empty((N, width), device=device, dtype=torch.float)
         ws = torch.empty(
-            (int(L.pdt_ctc_prefix_search_workspace_bytes(T, N, width)),),
+            (int(L.pdt_ctc_prefix_search_workspace_bytes(T, N, V, width)),),
             device=device, dtype=torch.uint8,
         )  # fmt: skip
         rc = L.pdt_ctc_prefix_search(

@@ -61,7 +61,7 @@ def test_abi_version_and_arg_validation_without_gpu(lib):
 
     assert lib.pdt_amd_abi_version() >= 1
     assert lib.pdt_oc_mask_words(512) == 16 and lib.pdt_oc_mask_words(513) == 17
-    assert lib.pdt_ctc_prefix_search_workspace_bytes(10, 4, 16) >= 10 * 4 * 16 * 8
+    assert lib.pdt_ctc_prefix_search_workspace_bytes(10, 4, 30, 16) >= 10 * 4 * 16 * 8
     assert lib.pdt_spline_workspace_bytes(2, 3, 1, 1) > 0
     z = [0] * 32
     # N == 0: OK, nothing to do

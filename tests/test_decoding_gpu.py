@@ -81,21 +81,19 @@ def _plan_boundaries(K, hi=17000):
 
 
 def _long_row_cases():
-    cases = [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4), (11000, 16), (15000, 8)]
+    cases = [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4), (11000, 16), (15000, 8), (40000, 16)]
     for K in (16, 32):
-        for edge in _plan_boundaries(K):
-            if _ctc_plan(edge, K)[0] == 0:
-                cases += [(edge - 1, K), (edge, K)]  # one V on each side of every change
-            else:
-                cases += [(edge - 1, K)]  # the longest row that still fits
+        for edge in _plan_boundaries(K, hi=20000):
+            cases += [(edge - 1, K), (edge, K)]  # one V on each side of every change
     return sorted(set(cases))
 
 
 @pytest.mark.parametrize("V,K", _long_row_cases())
 def test_ctc_prefix_search_long_rows(device, V, K):
     """Vocabularies beyond 511: several producer waves share an utterance's frames (three, then
-    two as the ring grows), finally one producer with a two-slot ring; one V on each side of
-    every change of configuration, ragged lens shorter than the number of producers included."""
+    two as the ring grows), then one producer with a two-slot ring, finally rows that stay in the
+    HBM workspace because no LDS ring holds them; one V on each side of every change of
+    configuration, ragged lens shorter than the number of producers included."""
     rng = np.random.default_rng(7000 + V)
     for it, (T, N) in enumerate([(2, 3), (25, 5), (61, 2)] if V < 10000 else [(2, 3), (23, 3)]):
         lg = _peaky_logits(rng, T, N, V, scale=11.0 if V < 10000 else 13.0)
@@ -106,12 +104,12 @@ def test_ctc_prefix_search_long_rows(device, V, K):
         _check_search(act, exp, (V, K, T, N, _ctc_plan(V, K)))
 
 
-def test_ctc_prefix_search_rows_too_long(device):
-    """Rows that no ring holds raise (the reference has no limit)."""
-    edge = _plan_boundaries(16)[-1]
-    assert _ctc_plan(edge, 16)[0] != 0 and _ctc_plan(edge - 1, 16)[0] == 0
-    with pytest.raises(RuntimeError, match="too long"):
-        F.ctc_prefix_search(torch.zeros(2, 1, edge + 1, device=device), 16)
+def test_ctc_plan_covers_every_vocabulary():
+    """Every row length has a configuration (rows beyond the LDS: plan[3] == 2, the workspace)."""
+    for V in (1, 64, 65, 511, 512, 5000, 16000, 16200, 100000, 1 << 20):
+        rc, plan = _ctc_plan(V, 16)
+        assert rc == 0 and plan[0] >= 1, (V, rc, plan)
+    assert _ctc_plan(1 << 20, 16)[1][3] == 2 and _ctc_plan(256, 16)[1][3] == 1 and _ctc_plan(5000, 16)[1][3] == 0
 
 
 def test_ctc_prefix_search_golden_shape(device):
