@@ -434,9 +434,13 @@ def ctc_prefix_search(
 
     Reference: ``CTCPrefixSearch.forward`` (_decoding.py:1064-1202) with ``lm=None``.
     Returns ``(y (S, N, width) int64, y_lens (N, width) int64, y_probs (N, width))``; rows of
-    ``y`` beyond ``y_lens`` are zero (the reference leaves them undefined).
+    ``y`` beyond ``y_lens`` are zero (the reference leaves them undefined).  The fused kernel's
+    probabilities are cut off from the graph; logits that require grad take the frame-by-frame
+    route of :class:`CTCPrefixSearch` instead (same beams, differentiable probabilities).
     """
-    return torch.ops.pydrobert_amd.ctc_prefix_search(logits, width, lens)
+    if torch.jit.is_scripting() or not (torch.is_grad_enabled() and logits.requires_grad):
+        return torch.ops.pydrobert_amd.ctc_prefix_search(logits, width, lens)
+    return CTCPrefixSearch(width)(logits, lens)
 
 
 class CTCPrefixSearch(torch.nn.Module):
@@ -764,6 +768,35 @@ def _(logits, in_lens, blank_idx, batch_first, is_probs):
     )
 
 
+def _ctc_greedy_setup(ctx, inputs, output):
+    logits, in_lens, _, batch_first, is_probs = inputs
+    ctx.save_for_backward(logits, in_lens)
+    ctx.cfg = (batch_first, is_probs)
+
+
+def _ctc_greedy_backward(ctx, g_max, g_paths, g_lens):
+    """``max_`` is the sum (product) over the valid frames of the best class's log-probability
+    (probability): differentiable in the reference (_decoding.py:526-553).  The frames' maxima
+    are recomputed with device ops and differentiated by autograd."""
+    logits, in_lens = ctx.saved_tensors
+    batch_first, is_probs = ctx.cfg
+    with torch.enable_grad():
+        x = logits.detach().requires_grad_(True)
+        y = x if is_probs else x.log_softmax(2)
+        if not batch_first:
+            y = y.transpose(0, 1)
+        best = y.max(2)[0]  # (N, T)
+        if in_lens is not None:
+            valid = torch.arange(best.size(1), device=best.device).unsqueeze(0) < in_lens.unsqueeze(1)
+            best = best.masked_fill(~valid, 1.0 if is_probs else 0.0)
+        total = best.prod(1) if is_probs else best.sum(1)
+        (g,) = torch.autograd.grad(total, x, g_max.to(total.dtype))
+    return g, None, None, None, None
+
+
+register_autograd("pydrobert_amd::ctc_greedy_search", _ctc_greedy_backward, setup_context=_ctc_greedy_setup)
+
+
 def ctc_greedy_search(
     logits: torch.Tensor,
     in_lens: Optional[torch.Tensor] = None,
@@ -772,7 +805,7 @@ def ctc_greedy_search(
     is_probs: bool = False,
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """Functional version of :class:`CTCGreedySearch` (reference _decoding.py:507-558):
-    returns ``(max_, paths, out_lens)``.  One pass over the logits; ``max_`` carries no gradient."""
+    returns ``(max_, paths, out_lens)``.  One pass over the logits."""
     return torch.ops.pydrobert_amd.ctc_greedy_search(logits, in_lens, blank_idx, batch_first, is_probs)
 
 

@@ -110,3 +110,30 @@ def test_random_walk_statistics(device):
     y2, lp2 = F.random_walk_advance(table[:1].expand(8, V), torch.zeros(8, device=device),
                                     torch.zeros((0, 8), dtype=torch.long, device=device))  # fmt: skip
     assert y2.shape == (1, 8) and lp2.shape == (8,)
+
+
+@pytest.mark.parametrize("is_probs", [False, True])
+@pytest.mark.parametrize("batch_first", [False, True])
+def test_ctc_greedy_search_max_gradient(device, is_probs, batch_first):
+    """``max_`` stays in the graph as in the reference (_decoding.py:526-553)."""
+    rng = np.random.default_rng(2 + is_probs)
+    T, N, V = 9, 4, 6
+    x = rng.normal(size=(T, N, V)).astype(np.float32)
+    if is_probs:
+        x = np.exp(x) / np.exp(x).sum(2, keepdims=True)
+    if batch_first:
+        x = np.ascontiguousarray(x.transpose(1, 0, 2))
+    lens = torch.tensor([9, 4, 0, 7])
+    w = torch.from_numpy(rng.normal(size=(N,)).astype(np.float32))
+    a = torch.from_numpy(x).clone().requires_grad_(True)
+    y = a if is_probs else a.log_softmax(2)
+    y = y if batch_first else y.transpose(0, 1)
+    best = y.max(2)[0]
+    valid = torch.arange(T).unsqueeze(0) < lens.unsqueeze(1)
+    best = best.masked_fill(~valid, 1.0 if is_probs else 0.0)
+    ((best.prod(1) if is_probs else best.sum(1)) * w).sum().backward()
+    b = torch.from_numpy(x).to(device).requires_grad_(True)
+    mx, paths, out_lens = F.ctc_greedy_search(b, lens.to(device), -1, batch_first, is_probs)
+    assert mx.requires_grad
+    (mx * w.to(device)).sum().backward()
+    assert torch.allclose(b.grad.cpu(), a.grad, rtol=1e-4, atol=1e-6)
