@@ -322,8 +322,9 @@ def ctc_kernel_name(V, W):
     plan = (ctypes.c_int32 * 4)()
     if _cabi.lib().pdt_ctc_prefix_search_plan(V, W, plan) != 0:
         return "pdt::ctc_search_kernel"
-    nt = V // 64 if (plan[3] and V // 64 == 4) else -1
-    return "pdt::ctc_search_kernel<{}, {}, {}>".format(plan[0], nt, "true" if plan[3] else "false")
+    nt = V // 64 if (plan[3] == 1 and V // 64 == 4) else -1
+    return "pdt::ctc_search_kernel<{}, {}, {}, {}>".format(
+        plan[0], nt, "true" if plan[3] == 1 else "false", "true" if plan[3] == 2 else "false")
 
 
 def rendezvous_only(args, world, rank):
@@ -508,7 +509,7 @@ def run_rank(args):
                     "wave_insts_per_launch": insts,
                     "issue_cycles_per_wave_inst": cyc,
                     "pipe_busy_frac": None if cyc is None else insts * cyc / (1024 * 2.4e9 * op_ms[dom] * 1e-3),
-                    "source": "profiles/r02_ctc_sq_counters.csv (SQ_INSTS_VALU), profiles/r02_valu_issue.json "
+                    "source": "profiles/r02_kernels.json (SQ_INSTS_VALU), profiles/r02_valu_issue.json "
                               "(measured issue cycles per wave64 VALU instruction at 8 waves/SIMD)",
                 }
 

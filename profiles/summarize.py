@@ -92,9 +92,9 @@ shapes = {
                                              per_unit="utterance (tokens in, class bitmasks out)", cells=512 * 512),
     "oc_expand_tiles_kernel": dict(what="optimal_completion expansion", units=4096, alg=8 * 513 * (C_oc or 0),
                                    per_unit="utterance ((H+1) x C int64 out)"),
-    "ctc_search_kernel<1, 4, true>": dict(what="fused CTC search N=4096 T=512 V=256 K=16 (+12 and +6 logits)", units=4096,
+    "ctc_search_kernel<1, 4, true": dict(what="fused CTC search N=4096 T=512 V=256 K=16 (+12 and +6 logits)", units=4096,
                                           alg=4 * 512 * 257 + 8 * 512 * 16 + 12 * 16, per_unit="utterance", frames=512),
-    "ctc_search_kernel<3, -1, false>": dict(what="fused CTC search C3: N=1024 T=1000 V=1000 K=16", units=1024,
+    "ctc_search_kernel<3, -1, false": dict(what="fused CTC search C3: N=1024 T=1000 V=1000 K=16", units=1024,
                                             alg=4 * 1000 * 1001 + 8 * 1000 * 16 + 12 * 16, per_unit="utterance", frames=1000),
     "spec_augment_rows_kernel": dict(what="spec_augment_apply C4: 2048 x 1000 x 80", units=2048, alg=640000, per_unit="utterance"),
     "image_warp_kernel<false>": dict(what="sparse_image_warp C4: (2048,1,1000,80)", units=2048, alg=640000, per_unit="image"),
@@ -144,9 +144,9 @@ for key, meta in shapes.items():
 json.dump({"valu_issue_ns_per_wave_inst_per_simd": ns_per_inst, "kernels": records},
           open(os.path.join(here, "r02_kernels.json"), "w"), indent=1)
 
-ctc = records["ctc_search_kernel<1, 4, true>"]
+ctc = records["ctc_search_kernel<1, 4, true"]
 json.dump({
-    "kernel": "pdt::" + "ctc_search_kernel<1, 4, true>",
+    "kernel": ctc["kernel"],
     "config": {"N": 4096, "T": 512, "V": 256, "beam": 16},
     "hbm_bytes_per_launch": ctc["hbm_bytes_per_launch"],
     "raw": {"FETCH_SIZE_KB": ctc["FETCH_SIZE_KB_raw"], "WRITE_SIZE_KB": ctc["WRITE_SIZE_KB_raw"]},
