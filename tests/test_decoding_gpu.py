@@ -520,3 +520,33 @@ def test_ctc_prefix_search_exact_ties(device):
         exp = oracle.ctc_prefix_search(lg[:1], K)
         act = F.ctc_prefix_search(torch.from_numpy(lg[:1]).to(device), K)
         _check_search(act, exp, ("ties", V, K))
+
+
+def test_ctc_prefix_search_near_ties_are_the_only_disagreements(device):
+    """Probabilities are p * (1 / sum) with a guard-free exp: within an ulp or two of the
+    reference's quotient.  That can swap two beam entries whose masses agree to ~1e-6 (measured by
+    the fuzz scripts: ~4 utterances in 100 000).  Bound it: wherever the beams of kernel and oracle
+    differ, they hold the same prefixes up to entries whose probabilities are within 1e-5 of a
+    neighbour's, and the sorted probabilities agree to 1e-5 everywhere."""
+    rng = np.random.default_rng(123)
+    T, N, V, K = 120, 2048, 40, 8
+    lg = _peaky_logits(rng, T, N, V, scale=5.0)
+    y, yl, yp = (x.cpu().numpy() for x in F.ctc_prefix_search(torch.from_numpy(lg).to(device), K))
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(i):
+        return oracle.ctc_prefix_search(np.ascontiguousarray(lg[:, i : i + 64]), K)
+
+    with ThreadPoolExecutor(16) as ex:
+        parts = list(ex.map(one, range(0, N, 64)))
+    ey = np.concatenate([p[0] for p in parts], 1)
+    eyl, eyp = np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
+    assert np.allclose(yp, eyp, rtol=1e-5, atol=0.0)  # sorted masses agree whatever the order of near-equal entries
+    bad = [n for n in range(N) if not (np.array_equal(yl[n], eyl[n]) and np.array_equal(y[:, n], ey[:, n]))]
+    assert len(bad) <= 4, len(bad)  # a handful in 2048 at most
+    for n in bad:
+        mine = {tuple(y[: yl[n, k], n, k].tolist()) for k in range(K)}
+        theirs = {tuple(ey[: eyl[n, k], n, k].tolist()) for k in range(K)}
+        gap = np.abs(eyp[n, 1:] / eyp[n, :-1] - 1.0).min()
+        # same prefixes in another order, or the K-th / (K+1)-th candidates were near-equal
+        assert mine == theirs or gap < 1e-5, (n, gap)

@@ -331,3 +331,19 @@ def test_fill_after_eos(device):
     (gv,) = torch.autograd.grad(out.sum(), v)
     kept = torch.from_numpy(oracle.fill_after_eos(tk, 1, 0, 0.0, np.ones((33, 9), np.float32))).to(device)
     assert torch.equal(gv, kept)
+
+
+def test_optimal_completion_shape_sweep(device):
+    """The tiled expansion over odd shapes: batches that do not fill a tile, one-word and
+    many-word bitmasks, odd set widths C, both layouts, exclude_last, ragged lengths."""
+    rng = np.random.default_rng(77)
+    shapes = [(1, 1, 1, 2), (3, 5, 4, 3), (5, 33, 20, 4), (7, 64, 70, 9), (9, 65, 33, 40), (2, 130, 17, 3),
+              (6, 600, 40, 25), (13, 31, 129, 2), (4, 200, 200, 200)]
+    for (N, R, H, V) in shapes:
+        ref = rng.integers(0, V, (R, N))
+        hyp = rng.integers(0, V, (H, N))
+        for kw in (dict(), dict(eos=V - 1, include_eos=False), dict(eos=0, exclude_last=True), dict(batch_first=True)):
+            a, b = (ref.T.copy(), hyp.T.copy()) if kw.get("batch_first") else (ref, hyp)
+            exp = oracle.optimal_completion(a, b, faithful=False, **kw)
+            act = F.optimal_completion(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), warn=False, **kw)
+            assert act.shape == exp.shape and np.array_equal(act.cpu().numpy(), exp), (N, R, H, V, kw)
