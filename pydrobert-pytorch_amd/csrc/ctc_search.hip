@@ -509,7 +509,13 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
 #ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
-    const bool enough = ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+    // Every mass has underflowed to 0 (the beam is ordered, so entry 0 holds the largest): every
+    // candidate of this and all later frames has mass 0 too, the reference's top-k over them is
+    // a tie artefact, and nothing is left to decide -- the beam stays as it is.  (float32
+    // probability-space masses get there after a few hundred frames of p_max ~ 0.5, or ~1000 of
+    // p_max ~ 0.9; without this exit each such frame runs the full tiers on a beam of zeros.)
+    const bool dead = readlane_f(bm.nb + bm.b, 0) == 0.0f;
+    const bool enough = dead || ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
     // feedback to the producers: a complete selection costs the producer about what two list
     // completions cost this wave, so the balance is at one completed list in two frames: +1
     // per frame this wave had to complete a short list, -1 per frame it did not (0 .. 32);
@@ -523,10 +529,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #else
     ns = nt = nk = 0; (void)s;
 #endif
-    int *tmp = L.nxt_old;
-    L.nxt_old = L.nxt_new;
-    L.nxt_new = tmp;
-    Kp = W;
+    if (!dead) {  // (a skipped frame leaves the next-token tables where they are)
+      int *tmp = L.nxt_old;
+      L.nxt_old = L.nxt_new;
+      L.nxt_new = tmp;
+      Kp = W;
+    }
     if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
       const int c = ((t + 1) >> a.ckpt_shift) - 1;
