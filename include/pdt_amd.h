@@ -54,13 +54,20 @@ int pdt_amd_abi_version(void);
  *   return_mistakes: 1 = error-count semantics (error_rate / prefix_error_rates),
  *                    0 = cost semantics (edit_distance / prefix_edit_distances).
  *   ref_lens_out / hyp_lens_out (optional, (N,) int64) receive the sequence lengths.
+ *   workspace (optional): pdt_lev_workspace_bytes(R, H, N) bytes of device memory, 256-byte
+ *   aligned, contents irrelevant.  With it, unit (i.e. uniform) costs run on the bit-parallel
+ *   kernels of lev_bitpar.hip; without it (NULL / too small), or when that function returns 0
+ *   (a hypothesis longer than 1024 tokens), on the cell-by-cell kernels.  Same results.
  * ------------------------------------------------------------------------------------- */
+int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N);
+
 int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
             const int64_t *hyp, int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N,
             int has_eos, int64_t eos, int include_eos, float ins_cost, float del_cost,
             float sub_cost, int norm, int mode, int exclude_last, float padding,
             int return_mistakes, float *out, int64_t out_sh, int64_t out_sn,
-            int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status, void *stream);
+            int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status, void *workspace,
+            int64_t workspace_bytes, void *stream);
 
 /* ---------------------------------------------------------------------------------------
  * fill_after_eos (_string.py:30-42): out = value, except that every position strictly after

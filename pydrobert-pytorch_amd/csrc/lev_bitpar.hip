@@ -1,0 +1,528 @@
+// Bit-parallel Levenshtein for unit costs (ins = del = sub = 1, what every uniform-cost call
+// becomes after the rescaling of reference _string.py:168-174) on gfx950.
+//
+// The cell recurrence of _string_matching (reference _string.py:286-346) moves by -1 / 0 / +1
+// between neighbouring cells, so a whole DP column is two bit-vectors of vertical deltas
+// (Pv: +1, Mv: -1) and one column update costs ~20 word operations per 32 cells (Myers 1999;
+// the block form with carried horizontal deltas is Hyyro 2003) instead of ~5 per cell in
+// lev_skewed.hip.  Values are small integers either way: results are identical.
+//
+// Two kernels, fed from a caller-provided workspace (pdt_lev_workspace_bytes):
+//   lev_classify_kernel  one wave per utterance: sequence lengths, the distinct tokens of the
+//                        bit-vector sequence X (= hyp) in ascending order (bitonic sort in
+//                        registers), and the match masks Eq[class][block] in compressed rows --
+//                        per class a 32-bit block-presence word + an offset into a packed array of
+//                        mask words (one word per (class, block) pair that has a match: at most
+//                        |X| words).  Every position of the consumed sequence Y (= ref) gets its
+//                        class's (presence, offset) pair, so the DP loop never sees a token.
+//   lev_bitpar_kernel    L = 2^k >= |X| / 32 lanes per utterance, 64 / L utterances per wave.
+//                        Lane b owns block b (rows 32 b + 1 .. 32 b + 32) and runs one column
+//                        behind lane b - 1, which hands it the horizontal delta of its last row
+//                        through one DPP shift -- an anti-diagonal pipeline over blocks.  After
+//                        the last reference token the vectors hold D[ref_len][h] - D[ref_len][h-1]
+//                        for every h: all prefix distances come out of one final prefix sum.
+// (With X = hyp the transposed table is computed; unit costs make it the same table.)
+//
+// Optimal completion stays on lev_rowsync.hip: a form of this pipeline that dumped every column's
+// (Pv, Mv) words and searched them for the arg-min rows (nibble-table block minima, bounds from
+// popcounts, one lane per column) measured 0.48 ms against 0.51 -- its cost is the arg-min sets
+// (13 rows per column at the bench shape, each a class look-up), not the recurrence.
+#include <type_traits>
+
+#include "lev_common.hpp"
+#include "wave_select.hpp"
+
+namespace pdt {
+
+struct BitparArgs {
+  const int64_t *ref, *hyp;
+  int64_t ref_st, ref_sn, hyp_st, hyp_sn;
+  int R, H, N;
+  int has_eos, include_eos;
+  int64_t eos;
+  int exclude_last, norm, mode;
+  float mult, padding;
+  float *out;
+  int64_t out_sh, out_sn;
+  int64_t *ref_lens_out, *hyp_lens_out;
+  int32_t *status;
+  int X, Y;      // capacities of the bit-vector sequence and of the consumed sequence
+  int lgL, upw;  // lanes per utterance = 1 << lgL; utterances per wave (<= 64 >> lgL)
+  int P;         // sort capacity: power of two >= X
+  int32_t *lens;   // [N][2]     ref_len, hyp_len
+  uint2 *yh;       // [N][Y]     (block presence, offset) of the class of Y[j]; (0, 0) = no match
+  uint32_t *msk;   // [N][X + 1] packed match-mask words
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// X: length of the bit-vector sequence, Y: of the consumed one.  Blocks are 32 rows and the
+// presence word has 32 bits: X <= 1024.
+BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N) {
+  BitparPlan p{};
+  if (X > 1024 || Y > (1 << 20) || N <= 0) return p;
+  int lgL = 0;
+  while ((32 << lgL) < X) ++lgL;
+  p.lgL = lgL;
+  int P = 2;
+  while (P < X) P <<= 1;
+  p.P = P;
+  const size_t Xs = (size_t)(X > 0 ? X : 1), Ys = (size_t)(Y > 0 ? Y : 1);
+  // classify: [(presence, offset) per class X * 8] [tokens (X + 1) * 8 (later: the mask words)]
+  //           [classes of Y, 2 bytes each]
+  p.lds_classify = align_up(Xs * 8 + (Xs + 1) * 8 + Ys * 2, 16);
+  // DP: [yh Y * 8] [mask words (X + 1) * 4] [distances (X + 1) * 4]
+  p.lds_sub = align_up(Ys * 8 + (Xs + 1) * 4 + (Xs + 1) * 4, 16);
+  int upw = 64 >> lgL;
+  while (upw > 1 && p.lds_sub * upw > 40 * 1024) upw >>= 1;  // (four waves per CU)
+  if (p.lds_sub * upw > 150 * 1024 || p.lds_classify * 4 > 160 * 1024) return p;
+  p.upw = upw;
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    const size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  p.off_lens = take((size_t)N * 8);
+  p.off_yh = take((size_t)N * Ys * 8);
+  p.off_msk = take((size_t)N * (Xs + 1) * 4);
+  p.total = off;
+  p.ok = 1;
+  return p;
+}
+
+// Classes (ranks in the sorted table of U distinct tokens, -1 = absent) of NQ tokens per lane:
+// NQ branch-free binary searches of lgP steps advance together, so their LDS reads overlap.
+template <int NQ>
+__device__ __forceinline__ void classes_of(const int64_t *tab, const int U, const int lgP,
+                                           const int64_t (&v)[NQ], int (&cls)[NQ]) {
+  int pos[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) pos[q] = 0;
+  if (U > 0) {
+    for (int st = 1 << (lgP - 1); st >= 1; st >>= 1) {
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int k = pos[q] + st - 1;
+        const int64_t t = tab[min(k, U - 1)];
+        if (k < U && t < v[q]) pos[q] += st;
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) cls[q] = (pos[q] < U && tab[pos[q]] == v[q]) ? pos[q] : -1;
+}
+
+// Sorts NR * 64 keys held as k[r] of lane l = element r * 64 + l, DESCENDING in that order
+// (wave_select.hpp sorts the 64 keys of one register; registers are then merged pairwise: the
+// lower run against the lane- and register-reversed upper run gives two bitonic halves, cleaned by
+// register-to-register exchanges and one 6-stage merge inside every register).
+template <int NR>
+__device__ __forceinline__ void sort_regs_desc(u64 (&k)[NR]) {
+#pragma unroll
+  for (int r = 0; r < NR; ++r) k[r] = wave_sort_desc<u64>(k[r]);
+#pragma unroll
+  for (int m = 1; m < NR; m <<= 1) {  // runs of m registers -> runs of 2 m
+#pragma unroll
+    for (int base = 0; base < NR; base += 2 * m) {
+#pragma unroll
+      for (int i = 0; i < m; ++i) {
+        const int lo = base + i, hi = base + 2 * m - 1 - i;
+        const u64 rev = xor_shfl<63>(k[hi]);
+        const u64 big = k[lo] > rev ? k[lo] : rev, small = k[lo] > rev ? rev : k[lo];
+        k[lo] = big;
+        k[hi] = small;  // (each half is bitonic now; the order inside k[hi] does not matter yet)
+      }
+#pragma unroll
+      for (int d = m >> 1; d >= 1; d >>= 1) {  // half-cleaners between registers
+#pragma unroll
+        for (int i = 0; i < 2 * m; ++i) {
+          if ((i & d) == 0) {
+            const u64 x = k[base + i], y = k[base + i + d];
+            k[base + i] = x > y ? x : y;
+            k[base + i + d] = x > y ? y : x;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) k[r] = bitonic_merge<32>(k[r]);
+  }
+}
+
+// tokens t0 + lane + 64 q, q < 8, of one sequence (all eight loads in flight); `fill` past T
+__device__ __forceinline__ void load_tokens(const int64_t *tok, const int T, const int64_t st,
+                                            const int64_t off, const int t0, const int64_t fill,
+                                            int64_t (&v)[8]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int t = t0 + lane + q * PDT_WAVE;
+    v[q] = t < T ? tok[(int64_t)t * st + off] : fill;
+  }
+}
+
+// first position of `eos` in tok[0..T) (T when absent): _lens_from_eos, _string.py:137-143
+__device__ __forceinline__ int first_eos(const int64_t *tok, const int T, const int64_t st,
+                                         const int64_t off, const int64_t eos) {
+  const int lane = lane_id();
+  for (int t0 = 0; t0 < T; t0 += 8 * PDT_WAVE) {
+    int64_t v[8];
+    load_tokens(tok, T, st, off, t0, 0, v);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const unsigned long long hit = __ballot(t0 + lane + q * PDT_WAVE < T && v[q] == eos);
+      if (hit) return t0 + q * PDT_WAVE + (int)__builtin_ctzll(hit);
+    }
+  }
+  return T;
+}
+
+// ---- kernel 1: lengths, classes, compressed match masks -------------------------------------
+// (Time-major inputs cost this kernel ~15 us at the bench shape -- a wave's tokens sit in 512
+// different 32-byte sectors; reading (T, 4) strips with the whole workgroup and exchanging them
+// through LDS measured no better.)
+template <int NR>
+__global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, const int lds_per_wave) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  if (n >= a.N) return;  // waves never synchronise with each other
+  unsigned char *base = smem + (size_t)wave * lds_per_wave;
+  const int X = a.X > 0 ? a.X : 1, Y = a.Y > 0 ? a.Y : 1;
+  // [(presence, offset) per class: X * 8] [distinct tokens (X + 1) * 8; later the packed mask
+  // words] [classes of Y, 2 bytes each]
+  uint2 *po = reinterpret_cast<uint2 *>(base);
+  int64_t *ctok = reinterpret_cast<int64_t *>(base + (size_t)X * 8);
+  unsigned *msk = reinterpret_cast<unsigned *>(ctok);
+  short *yc = reinterpret_cast<short *>(ctok + X + 1);
+
+  // ---- lengths (_string.py:195-228) -----------------------------------------------------
+  int ref_len = a.R, hyp_len = a.H;
+  bool rmiss = false, hmiss = false;
+  const int64_t roff = n * a.ref_sn, hoff = n * a.hyp_sn;
+  if (a.has_eos) {
+    ref_len = first_eos(a.ref, a.R, a.ref_st, roff, a.eos);
+    hyp_len = first_eos(a.hyp, a.H, a.hyp_st, hoff, a.eos);
+    if (a.include_eos) {
+      if (ref_len == a.R) rmiss = true; else ref_len += 1;
+      if (hyp_len == a.H) hmiss = true; else hyp_len += 1;
+    }
+  }
+  int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;  // rows that are updated (:286-288)
+  if (Heff < 0) Heff = 0;
+  // bit-vectors along the hypothesis (only its first Heff tokens matter), reference consumed
+  const int64_t *x = a.hyp, *y = a.ref;
+  const int64_t x_st = a.hyp_st, y_st = a.ref_st, xoff = hoff, yoff = roff;
+  const int x_len = Heff, y_len = ref_len;
+
+  // ---- distinct tokens of X in ascending order ---------------------------------------------
+  // X <= 64 NR tokens: they stay in registers, are sorted there (key = ~(token with its sign bit
+  // flipped): a descending sort of the keys is an ascending sort of the tokens, padding last) and
+  // the first element of every run of equal keys is compacted into the LDS table.
+  int64_t xt[NR];
+  {
+    int64_t part[8];
+#pragma unroll
+    for (int c = 0; c < NR / 8; ++c) {
+      load_tokens(x, x_len, x_st, xoff, c * 8 * PDT_WAVE, INT64_MAX, part);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xt[c * 8 + q] = part[q];
+    }
+  }
+  constexpr u64 kSign = 0x8000000000000000ull;
+  int U = 0;
+  {
+    u64 key[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) key[q] = lane + q * PDT_WAVE < x_len ? ~((u64)xt[q] ^ kSign) : 0ull;
+    sort_regs_desc<NR>(key);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int idx = q * PDT_WAVE + lane;
+      // key of element idx - 1: the lane below, or lane 63 of the register below
+      unsigned plo = 0u, phi = 0u;
+      if (q > 0) {
+        plo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)key[q - 1], 63);
+        phi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(key[q - 1] >> 32), 63);
+      }
+      const unsigned lo = (unsigned)shr1((int)(unsigned)key[q], (int)plo);
+      const unsigned hi = (unsigned)shr1((int)(unsigned)(key[q] >> 32), (int)phi);
+      const u64 prev = ((u64)hi << 32) | lo;
+      const bool first = idx < x_len && (idx == 0 || key[q] != prev);
+      const unsigned long long firsts = __ballot(first);
+      if (first) ctok[U + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(firsts >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)firsts, 0u))] =
+          (int64_t)(~key[q] ^ kSign);
+      U += (int)__popcll(firsts);
+    }
+  }
+  wave_sync();
+  for (int k = lane; k < U; k += PDT_WAVE) po[k] = make_uint2(0u, 0u);
+  int lgP = 1;
+  while ((1 << lgP) < U) ++lgP;  // (search steps 2^(lgP-1) .. 1 reach every index below U)
+  int xc[NR];  // classes of X[lane + 64 q]
+  classes_of<NR>(ctok, U, lgP, xt, xc);
+  for (int j0 = 0; j0 < y_len; j0 += 8 * PDT_WAVE) {
+    int64_t yt[8];
+    int c[8];
+    load_tokens(y, y_len, y_st, yoff, j0, 0, yt);
+    classes_of<8>(ctok, U, lgP, yt, c);
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (j0 + lane + q * PDT_WAVE < y_len) yc[j0 + lane + q * PDT_WAVE] = (short)c[q];
+  }
+  wave_sync();  // the token table is dead from here on: the mask words take it over
+  for (int i = lane; i <= x_len; i += PDT_WAVE) msk[i] = 0u;
+  auto for_x = [&](auto &&f) {  // f(position, class) over this lane's positions of X
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      if (lane + q * PDT_WAVE < x_len) f(lane + q * PDT_WAVE, xc[q]);
+  };
+  for_x([&](const int i, const int c) {
+    atomicOr(&po[c].x, 1u << (i >> 5));  // blocks that hold the class
+  });
+  wave_sync();
+  {  // offsets = exclusive scan of the presence popcounts
+    const int B = (U + PDT_WAVE - 1) / PDT_WAVE;
+    const int i0 = lane * B;
+    int sum = 0;
+    for (int q = 0; q < B; ++q)
+      if (i0 + q < U) sum += __popc(po[i0 + q].x);
+    const int incl = wave_incl_scan_add(sum);
+    int pos = incl - sum;
+    for (int q = 0; q < B; ++q)
+      if (i0 + q < U) {
+        po[i0 + q].y = (unsigned)pos;
+        pos += __popc(po[i0 + q].x);
+      }
+  }
+  wave_sync();
+  for_x([&](const int i, const int c) {
+    const uint2 e = po[c];
+    atomicOr(&msk[e.y + (unsigned)__popc(e.x & ((1u << (i >> 5)) - 1u))], 1u << (i & 31));
+  });
+  wave_sync();
+  for (int j = lane; j < y_len; j += PDT_WAVE) {
+    const int c = yc[j];
+    a.yh[n * (int64_t)Y + j] = c >= 0 ? po[c] : make_uint2(0u, 0u);
+  }
+  for (int i = lane; i <= x_len; i += PDT_WAVE) a.msk[n * (int64_t)(X + 1) + i] = msk[i];
+  if (lane == 0) {
+    a.lens[2 * n] = ref_len;
+    a.lens[2 * n + 1] = hyp_len;
+    int flags = 0;
+    if (rmiss) flags |= PDT_WARN_REF_NO_EOS;
+    if (hmiss) flags |= PDT_WARN_HYP_NO_EOS;
+    if (a.norm && ref_len == 0) flags |= PDT_WARN_EMPTY_REF;
+    if (flags && a.status) atomicOr(a.status, flags);
+    if (a.ref_lens_out) a.ref_lens_out[n] = ref_len;
+    if (a.hyp_lens_out) a.hyp_lens_out[n] = hyp_len;
+  }
+}
+
+// ---- kernel 2: the column recurrence ----------------------------------------------------------
+__global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, const int lds_per_sub) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int L = 1 << a.lgL;
+  const int sub = lane >> a.lgL, b = lane & (L - 1);
+  const int64_t n_raw = (int64_t)blockIdx.x * a.upw + sub;
+  const bool valid = sub < a.upw && n_raw < a.N;
+  const int64_t n = valid ? n_raw : (int64_t)blockIdx.x * a.upw;  // (a safe utterance to address)
+  const int X = a.X > 0 ? a.X : 1, Y = a.Y > 0 ? a.Y : 1;
+  unsigned char *base = smem + (size_t)(valid ? sub : 0) * lds_per_sub;
+  uint2 *yh_l = reinterpret_cast<uint2 *>(base);
+  unsigned *msk_l = reinterpret_cast<unsigned *>(yh_l + Y);
+  float *bnd = reinterpret_cast<float *>(msk_l + X + 1);
+
+  const int ref_len = a.lens[2 * n], hyp_len = a.lens[2 * n + 1];
+  int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;
+  if (Heff < 0) Heff = 0;
+  const int x_len = valid ? Heff : 0, y_len = valid ? ref_len : 0;
+
+  // ---- stage this utterance's lookups in LDS (eight loads in flight per lane) --------------
+  {
+    const uint2 *src = a.yh + n * (int64_t)Y;
+    for (int j0 = b; j0 < y_len; j0 += 8 * L) {
+      uint2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = j0 + q * L < y_len ? src[j0 + q * L] : make_uint2(0u, 0u);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (j0 + q * L < y_len) yh_l[j0 + q * L] = v[q];
+    }
+    if (valid && y_len == 0 && b == 0) yh_l[0] = make_uint2(0u, 0u);
+    const unsigned *msrc = a.msk + n * (int64_t)(X + 1);
+    for (int i0 = b; i0 <= x_len && valid; i0 += 8 * L) {
+      unsigned v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = i0 + q * L <= x_len ? msrc[i0 + q * L] : 0u;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (i0 + q * L <= x_len) msk_l[i0 + q * L] = v[q];
+    }
+  }
+  wave_sync();
+  int ymax = y_len;
+#pragma unroll
+  for (int t = 1; t < PDT_WAVE; t <<= 1) ymax = max(ymax, __shfl_xor(ymax, t));
+  ymax = __builtin_amdgcn_readfirstlane(ymax);
+  const int nsteps = ymax > 0 ? ymax + L - 1 : 0;
+
+  // ---- the pipeline: lane b handles Y[s - b] at step s ---------------------------------------
+  // A lone wave issues a dependent instruction every ~8.5 cycles and nothing else runs on its SIMD
+  // (four utterances per SIMD at the bench shape, all in this wave), so the loop is as long as its
+  // instruction count: the match masks of kChunk steps are looked up first (independent LDS reads,
+  // batched), then kChunk recurrence steps run out of registers.
+  //
+  // Steps need no guard while every lane is either working or still waiting for its first column:
+  // a waiting lane sees Eq = 0 (its lookups are forced to 0) and the horizontal delta 0 its waiting
+  // neighbour emits, which leaves the column-0 state (Pv = ~0, Mv = 0) as it is and emits 0 again.
+  // Only the last steps (the first utterance of the wave to finish, onwards) are guarded.
+  constexpr int kChunk = 16;
+  unsigned Pv = 0xffffffffu, Mv = 0u;  // column 0: D[i][0] = i
+  unsigned hop = 0u, hon = 0u;         // horizontal delta of this block's last row: +1 / -1 flags
+  const unsigned lowmask = (1u << b) - 1u, bbit = 1u << b;
+  const int jcap = y_len > 0 ? y_len - 1 : 0;
+  int ymin = (sub < a.upw && n_raw < a.N) ? y_len : (1 << 30);
+#pragma unroll
+  for (int t = 1; t < PDT_WAVE; t <<= 1) ymin = min(ymin, __shfl_xor(ymin, t));
+  ymin = __builtin_amdgcn_readfirstlane(ymin);
+  const int nfree = (ymin / kChunk) * kChunk;  // steps [0, nfree): no lane has run out of columns
+  const bool row16 = a.lgL == 4;               // a DPP row is one utterance: row_shr:1 feeds +1 into b = 0
+  auto lookups = [&](int s0, unsigned (&eq)[kChunk]) {
+    uint2 hq[kChunk];
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) hq[q] = yh_l[min(max(s0 + q - b, 0), jcap)];
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) eq[q] = msk_l[hq[q].y + (unsigned)__popc(hq[q].x & lowmask)];
+#pragma unroll
+    for (int q = 0; q < kChunk; ++q) eq[q] = ((hq[q].x & bbit) && s0 + q >= b) ? eq[q] : 0u;
+  };
+  auto step = [&](const unsigned eq0, const unsigned hp, const unsigned hn) {
+    const unsigned Xv = eq0 | Mv;
+    const unsigned Eq = eq0 | hn;
+    const unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    unsigned Ph = Mv | ~(Xh | Pv);
+    unsigned Mh = Pv & Xh;
+    hop = Ph >> 31;
+    hon = Mh >> 31;
+    Ph = (Ph << 1) | hp;
+    Mh = (Mh << 1) | hn;
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+  };
+  auto sweep = [&](auto row16_tag, auto guarded_tag, const int s_begin, const int s_end) {
+    constexpr bool ROW16 = decltype(row16_tag)::value, GUARDED = decltype(guarded_tag)::value;
+    for (int s0 = s_begin; s0 < s_end; s0 += kChunk) {
+      unsigned eq[kChunk];
+      lookups(s0, eq);
+#pragma unroll
+      for (int q = 0; q < kChunk; ++q) {
+        unsigned hp, hn;
+        if (ROW16) {
+          hp = (unsigned)__builtin_amdgcn_update_dpp(1, (int)hop, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
+          hn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hon, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
+        } else {
+          hp = (unsigned)shr1((int)hop, 0);
+          hn = (unsigned)shr1((int)hon, 0);
+          if (b == 0) {  // D[0][j] = j
+            hp = 1u;
+            hn = 0u;
+          }
+        }
+        const int j = s0 + q - b;
+        if (!GUARDED || (unsigned)j < (unsigned)y_len) {
+          step(eq[q], hp, hn);
+        }
+      }
+    }
+  };
+  using T = std::true_type;
+  using F = std::false_type;
+  if (row16) {
+    sweep(T{}, F{}, 0, nfree);
+    sweep(T{}, T{}, nfree, nsteps);
+  } else {
+    sweep(F{}, F{}, 0, nfree);
+    sweep(F{}, T{}, nfree, nsteps);
+  }
+
+  // ---- distances: D[ref_len][h] = ref_len + sum_{k <= h} (Pv_k - Mv_k) (_string.py:357-405) --
+  const int nvalid = min(max(x_len - 32 * b, 0), 32);
+  const unsigned vm = nvalid == 32 ? 0xffffffffu : (1u << nvalid) - 1u;
+  const int bs = __popc(Pv & vm) - __popc(Mv & vm);
+  const int incl = wave_incl_scan_add(bs);
+  const int seg = lane & ~(L - 1);
+  const int before = __builtin_amdgcn_ds_bpermute((seg > 0 ? seg - 1 : 0) << 2, incl);
+  int run = ref_len + incl - bs - (seg > 0 ? before : 0);
+  if (valid) {
+    if (b == 0) bnd[0] = (float)ref_len;
+    for (int k = 0; k < nvalid; ++k) {
+      run += (int)((Pv >> k) & 1u) - (int)((Mv >> k) & 1u);
+      bnd[32 * b + k + 1] = (float)run;
+    }
+  }
+  wave_sync();
+  if (!valid) return;
+  if (a.mode == PDT_MODE_FINAL) {
+    if (b == 0)
+      a.out[n * a.out_sn] = lev_finish(bnd[Heff], a.mult, a.norm, ref_len, hyp_len > 0 ? 1.0f : 0.0f);
+  } else {
+    const int Hout = a.H + (a.exclude_last ? 0 : 1);
+    const int pad_from = hyp_len + (a.exclude_last ? 0 : 1);  // :379-386
+    for (int h = b; h < Hout; h += L) {
+      float v;
+      if (h >= pad_from)
+        v = a.padding;
+      else
+        v = lev_finish(bnd[h], a.mult, a.norm, ref_len, h > 0 ? 1.0f : 0.0f);
+      a.out[(int64_t)h * a.out_sh + n * a.out_sn] = v;
+    }
+  }
+}
+
+// host side -------------------------------------------------------------------------------
+static int set_lds(const void *kern, size_t smem) {
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// LevArgs -> the three launches.  `ws` must hold plan.total bytes.
+int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream) {
+  BitparArgs a{};
+  a.ref = la.ref; a.hyp = la.hyp;
+  a.ref_st = la.ref_st; a.ref_sn = la.ref_sn; a.hyp_st = la.hyp_st; a.hyp_sn = la.hyp_sn;
+  a.R = la.R; a.H = la.H; a.N = la.N;
+  a.has_eos = la.has_eos; a.include_eos = la.include_eos; a.eos = la.eos;
+  a.exclude_last = la.exclude_last; a.norm = la.norm; a.mode = la.mode;
+  a.mult = la.mult; a.padding = la.padding;
+  a.out = la.out; a.out_sh = la.out_sh; a.out_sn = la.out_sn;
+  a.ref_lens_out = la.ref_lens_out; a.hyp_lens_out = la.hyp_lens_out; a.status = la.status;
+  a.X = la.H;
+  a.Y = la.R;
+  a.lgL = p.lgL; a.upw = p.upw; a.P = p.P;
+  unsigned char *w = reinterpret_cast<unsigned char *>(ws);
+  a.lens = reinterpret_cast<int32_t *>(w + p.off_lens);
+  a.yh = reinterpret_cast<uint2 *>(w + p.off_yh);
+  a.msk = reinterpret_cast<uint32_t *>(w + p.off_msk);
+
+  auto ck = a.X <= 8 * PDT_WAVE ? lev_classify_kernel<8> : lev_classify_kernel<16>;
+  int rc = set_lds(reinterpret_cast<const void *>(ck), p.lds_classify * 4);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ck, dim3((unsigned)((a.N + 3) / 4)), dim3(256), p.lds_classify * 4,
+                     stream, a, (int)p.lds_classify);
+  const size_t smem = p.lds_sub * p.upw;
+  const unsigned grid = (unsigned)((a.N + p.upw - 1) / p.upw);
+  auto kern = lev_bitpar_kernel;
+  rc = set_lds(reinterpret_cast<const void *>(kern), smem);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), smem, stream, a, (int)p.lds_sub);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pdt

@@ -26,6 +26,16 @@ struct LevArgs {
   int W;
 };
 
+// Geometry of the bit-parallel kernels (lev_bitpar.hip) for one call: lanes per utterance,
+// utterances per wave, LDS slices and the offsets of the workspace pieces.  ok = 0: the shape is
+// not served (bit-vector sequence longer than 1024 tokens, or lookups that do not fit the LDS).
+struct BitparPlan {
+  int ok, lgL, upw, P;
+  size_t lds_classify, lds_sub;  // bytes: per wave / per utterance
+  size_t off_lens, off_yh, off_msk, total;  // workspace
+};
+BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N);
+
 // Stage one utterance's tokens tok[t*st + off], t < T, into LDS as int32 and return the
 // sequence length (reference _lens_from_eos, _string.py:137-143, plus the include_eos
 // fix-up of :198-218).  `fits` tells whether every staged token survives the int64->int32

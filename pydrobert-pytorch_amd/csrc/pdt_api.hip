@@ -2,12 +2,14 @@
 // the host-side part of _string_matching's preamble (uniform-cost shortcut,
 // reference _string.py:168-174) and kernel selection.  No allocation, no synchronisation.
 #include <cmath>
+#include <cstdlib>
 
 #include "lev_common.hpp"
 
 namespace pdt {
 int launch_lev_skewed(LevArgs a, hipStream_t stream);
 int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream);
+int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream);
 int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
                      int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
                      int64_t tgt_sn, hipStream_t stream);
@@ -36,6 +38,16 @@ static bool costs_exact_in_f32(float ins, float del, float sub, int64_t R, int64
   return false;
 }
 
+// The bit-parallel kernels (lev_bitpar.hip) serve unit costs when the caller passed the workspace
+// their plan asks for; PDT_LEV_BITPAR=0 keeps the cell-by-cell kernels (for comparisons).
+static bool bitpar_enabled() {
+  static const bool on = [] {
+    const char *e = std::getenv("PDT_LEV_BITPAR");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static int fill_common(LevArgs &a, const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
                        const int64_t *hyp, int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N,
                        int has_eos, int64_t eos, int include_eos, float ins, float del, float sub) {
@@ -54,14 +66,21 @@ static int fill_common(LevArgs &a, const int64_t *ref, int64_t R, int64_t ref_st
 
 extern "C" {
 
-int pdt_amd_abi_version(void) { return 2; }  // 2: pdt_ctc_prefix_search_workspace_bytes takes V
+// 2: pdt_ctc_prefix_search_workspace_bytes takes V; 3: pdt_lev takes a workspace
+int pdt_amd_abi_version(void) { return 3; }
+
+int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {
+  if (R < 0 || H < 0 || N <= 0 || !pdt::bitpar_enabled()) return 0;
+  const pdt::BitparPlan p = pdt::plan_bitpar(H, R, N);
+  return p.ok ? (int64_t)p.total : 0;
+}
 
 int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
             int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,
             int include_eos, float ins_cost, float del_cost, float sub_cost, int norm, int mode,
             int exclude_last, float padding, int return_mistakes, float *out, int64_t out_sh,
             int64_t out_sn, int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status,
-            void *stream) {
+            void *workspace, int64_t workspace_bytes, void *stream) {
   using namespace pdt;
   if (mode != PDT_MODE_FINAL && mode != PDT_MODE_PREFIX) return PDT_E_ARG;
   if (exclude_last && mode != PDT_MODE_PREFIX) return PDT_E_ARG;  // _string.py:165
@@ -87,6 +106,12 @@ int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const
   a.ref_lens_out = ref_lens_out; a.hyp_lens_out = hyp_lens_out; a.status = status;
   if (!return_mistakes && !costs_exact_in_f32(ins_cost, del_cost, sub_cost, R, H))
     return launch_lev_rowsync(a, /*exact=*/true, (hipStream_t)stream);
+  if (!return_mistakes && ins_cost == 1.0f && del_cost == 1.0f && sub_cost == 1.0f && workspace &&
+      bitpar_enabled()) {
+    const BitparPlan p = plan_bitpar(H, R, N);
+    if (p.ok && (int64_t)p.total <= workspace_bytes)
+      return launch_lev_bitpar(a, p, workspace, (hipStream_t)stream);
+  }
   return launch_lev_skewed(a, (hipStream_t)stream);
 }
 

@@ -31,8 +31,9 @@ SIGNATURES = {
     "pdt_lev": (
         _INT,
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
-        + [_INT, _INT, _INT, _F, _INT, _P, _I64, _I64, _P, _P, _P, _P],
+        + [_INT, _INT, _INT, _F, _INT, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
     ),
+    "pdt_lev_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_fill_after_eos": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P]),
     "pdt_oc_mask_words": (_I64, [_I64]),
     "pdt_oc_mask": (

@@ -162,6 +162,16 @@ def _emit_warnings(flags: int, eos, prefix: bool):
             )
 
 
+def _lev_workspace(R: int, H: int, N: int, device):
+    """Scratch memory of the bit-parallel kernels (``pdt_lev_workspace_bytes``; ``None`` when
+    the shape is served by the cell-by-cell kernels).  torch's caching allocator hands the same
+    block back call after call."""
+    nbytes = int(_cabi.lib().pdt_lev_workspace_bytes(R, H, N))
+    if nbytes <= 0:
+        return None, 0
+    return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
+
+
 @custom_op("pydrobert_amd::string_matching", mutates_args=())
 def _string_matching_op(
     ref: torch.Tensor,
@@ -201,12 +211,13 @@ def _string_matching_op(
         mode = _cabi.MODE_FINAL
     with torch.cuda.device(device):
         status = torch.zeros(1, device=device, dtype=torch.int32) if warn else None
+        ws, ws_bytes = _lev_workspace(R, H, N, device)
         rc = _cabi.lib().pdt_lev(
             _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
             int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
             float(ins_cost), float(del_cost), float(sub_cost), int(norm), mode,
             int(exclude_last), float(padding), int(return_mistakes),
-            _cabi.ptr(out), out_sh, out_sn, 0, 0, _cabi.ptr(status),
+            _cabi.ptr(out), out_sh, out_sn, 0, 0, _cabi.ptr(status), _cabi.ptr(ws), ws_bytes,
             _cabi.stream_ptr(device),
         )  # fmt: skip
     _cabi.check(rc, "pdt_lev")

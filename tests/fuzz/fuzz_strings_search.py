@@ -48,10 +48,14 @@ while time.time() < t_end:
         # small vocabularies mostly; the short-list producers (64 < V < 512, K <= 16) and the
         # compile-time-chunk instantiation (V = 256..319) regularly; long rows now and then
         u = rng.random()
-        V = int(rng.integers(1, 80)) if u < 0.5 else (int(rng.integers(65, 340)) if u < 0.9 else int(rng.integers(513, 640)))
+        # ... and, one draw in twenty, a row from each launch configuration of plan_ctc_search
+        # (3 / 2 / 1 producer waves with the row in the LDS, then the row in the HBM workspace)
+        V = int(rng.integers(1, 80)) if u < 0.5 else (int(rng.integers(65, 340)) if u < 0.85 else int(rng.integers(513, 640)) if u < 0.95
+             else int(rng.choice([5000, 9000, 11000, 13000, 15000, 17000, 40000])) + int(rng.integers(0, 64)))
         K = int(rng.integers(1, min(V + 1, 32) + 1))
         if V > 64 and rng.random() < 0.7: K = int(rng.integers(1, 17))
         Tn, N = int(rng.integers(0, 70)), int(rng.integers(1, 7))
+        if V > 1000: Tn, N = int(rng.integers(1, 12)), int(rng.integers(1, 4))
         lg = rng.normal(size=(Tn, N, V + 1)).astype(np.float32)
         if Tn:
             pk = rng.integers(0, V + 1, (Tn, N))

@@ -63,14 +63,17 @@ def test_abi_version_and_arg_validation_without_gpu(lib):
     assert lib.pdt_oc_mask_words(512) == 16 and lib.pdt_oc_mask_words(513) == 17
     assert lib.pdt_ctc_prefix_search_workspace_bytes(10, 4, 30, 16) >= 10 * 4 * 16 * 8
     assert lib.pdt_spline_workspace_bytes(2, 3, 1, 1) > 0
+    # the bit-parallel Levenshtein kernels: hypotheses of at most 1024 tokens, any reference
+    assert lib.pdt_lev_workspace_bytes(512, 512, 4096) > 0 and lib.pdt_lev_workspace_bytes(9, 1025, 4) == 0
+    assert lib.pdt_lev_workspace_bytes(512, 512, 8192) > lib.pdt_lev_workspace_bytes(512, 512, 4096)
     z = [0] * 32
     # N == 0: OK, nothing to do
-    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_OK
+    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0) == _cabi.PDT_OK
     # bad mode / negative sizes
-    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 7, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_E_ARG
-    assert lib.pdt_lev(0, -1, 1, 1, 0, 5, 1, 1, 4, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_E_ARG
+    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 0, 0, 0, 0, 1.0, 1.0, 1.0, 0, 7, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0) == _cabi.PDT_E_ARG
+    assert lib.pdt_lev(0, -1, 1, 1, 0, 5, 1, 1, 4, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0) == _cabi.PDT_E_ARG
     # null pointers with a non-empty batch
-    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 4, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0) == _cabi.PDT_E_ARG
+    assert lib.pdt_lev(0, 5, 1, 1, 0, 5, 1, 1, 4, 0, 0, 0, 1.0, 1.0, 1.0, 0, 0, 0, 0.0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0) == _cabi.PDT_E_ARG
     assert lib.pdt_ctc_prefix_search(0, 5, 2, 3, 1, 1, 1, 0, 64, 5, 0, 0, 0, 0, 0) != _cabi.PDT_OK
     assert lib.pdt_ctc_prefix_search(0, 5, 0, 3, 1, 1, 1, 0, 4, 5, 0, 0, 0, 0, 0) == _cabi.PDT_OK
     assert lib.pdt_spec_augment_apply(0, 0, 5, 5, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == _cabi.PDT_OK

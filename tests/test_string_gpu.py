@@ -347,3 +347,91 @@ def test_optimal_completion_shape_sweep(device):
             exp = oracle.optimal_completion(a, b, faithful=False, **kw)
             act = F.optimal_completion(torch.from_numpy(a).to(device), torch.from_numpy(b).to(device), warn=False, **kw)
             assert act.shape == exp.shape and np.array_equal(act.cpu().numpy(), exp), (N, R, H, V, kw)
+
+
+# ---- bit-parallel unit-cost kernels (csrc/lev_bitpar.hip) ------------------------------------
+_BITPAR_OPS = ["error_rate", "edit_distance", "prefix_error_rates", "prefix_edit_distances"]
+
+
+@pytest.mark.parametrize("H", [1, 31, 32, 33, 64, 65, 129, 256, 257, 511, 513, 1000, 1024])
+def test_bitpar_block_count_sweep(device, H):
+    """Uniform costs run on the bit-parallel kernels whenever the hypothesis has at most 1024
+    tokens: one case per number of lanes an utterance takes (1, 2, 4, ..., 32), ragged lengths on
+    both sides, batch sizes that leave lanes of the last wave without an utterance."""
+    rng = np.random.default_rng(H)
+    for it, R in enumerate((max(1, H - 3), H + 70 if H < 600 else 300, 1300 if H <= 65 else 40)):
+        N = int(rng.integers(1, 12))
+        V = int(rng.choice([2, 3, 40]))
+        ref = rng.integers(0, V, (R, N))
+        hyp = rng.integers(0, V, (H, N))
+        eos = None
+        if it != 1:
+            eos = V
+            for n in range(N):
+                if rng.random() < 0.8:
+                    ref[int(rng.integers(0, R)), n] = eos
+                if rng.random() < 0.8:
+                    hyp[int(rng.integers(0, H)), n] = eos
+            if N > 1:
+                ref[0, 0] = eos  # an empty reference
+                hyp[0, N - 1] = eos  # an empty hypothesis
+        c = [1.0, 2.5][it % 2]
+        for name in _BITPAR_OPS:
+            kw = dict(eos=eos, include_eos=bool(it & 1), ins_cost=c, del_cost=c, sub_cost=c,
+                      norm=bool(rng.integers(0, 2)))  # fmt: skip
+            if name.startswith("prefix"):
+                kw["exclude_last"] = bool(rng.integers(0, 2))
+                kw["padding"] = -3
+            exp = getattr(oracle, name)(ref, hyp, faithful=False, **kw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                act = getattr(F, name)(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device),
+                                       warn=False, **kw).cpu().numpy()  # fmt: skip
+            _assert_same(exp, act, (name, H, R, N, V, kw))
+
+
+def test_bitpar_extreme_token_values(device):
+    """The class table is built from a sort of keys derived from the int64 tokens: the extremes of
+    the range, negatives and neighbours that differ in the top or bottom bit only."""
+    rng = np.random.default_rng(3)
+    base = np.array([np.iinfo(np.int64).min, np.iinfo(np.int64).min + 1, -(2**40), -1, 0, 1, 2**31,
+                     2**32, 2**62, np.iinfo(np.int64).max - 1, np.iinfo(np.int64).max], dtype=np.int64)  # fmt: skip
+    N, R, H = 9, 200, 190
+    ref = base[rng.integers(0, len(base), (R, N))]
+    hyp = base[rng.integers(0, len(base), (H, N))]
+    for name in _BITPAR_OPS:
+        exp, act = _call_both(name, ref, hyp, device, eos=0)
+        _assert_same(exp, act, name)
+
+
+def test_lev_workspace_is_optional(device):
+    """pdt_lev gives the same bits with and without its workspace (bit-parallel kernels against the
+    cell-by-cell ones), and reports no workspace for hypotheses beyond 1024 tokens."""
+    from pydrobert_amd import _cabi
+
+    L = _cabi.lib()
+    assert L.pdt_lev_workspace_bytes(100, 1025, 8) == 0
+    assert L.pdt_lev_workspace_bytes(5000, 1024, 8) > 0
+    rng = np.random.default_rng(5)
+    N, R, H, V = 37, 300, 280, 7
+    ref = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
+    hyp = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
+    outs = []
+    for use_ws in (True, False):
+        nbytes = int(L.pdt_lev_workspace_bytes(R, H, N))
+        assert nbytes > 0
+        ws = torch.empty(nbytes, device=device, dtype=torch.uint8) if use_ws else None
+        for mode, shape in ((_cabi.MODE_FINAL, (N,)), (_cabi.MODE_PREFIX, (H + 1, N))):
+            out = torch.empty(shape, device=device, dtype=torch.float)
+            rc = L.pdt_lev(
+                _cabi.ptr(ref), R, ref.stride(0), ref.stride(1), _cabi.ptr(hyp), H, hyp.stride(0),
+                hyp.stride(1), N, 1, 3, 1, 1.0, 1.0, 1.0, 1, mode, 0, -1.0, 1,
+                _cabi.ptr(out), out.stride(0) if mode == _cabi.MODE_PREFIX else 0,
+                out.stride(-1), 0, 0, 0, _cabi.ptr(ws), nbytes if use_ws else 0,
+                _cabi.stream_ptr(device),
+            )  # fmt: skip
+            assert rc == 0
+            outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
+    exp = oracle.error_rate(ref.cpu().numpy(), hyp.cpu().numpy(), eos=3, include_eos=True, norm=True)
+    assert np.array_equal(exp, outs[0].numpy())
