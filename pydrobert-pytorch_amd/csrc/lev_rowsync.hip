@@ -15,7 +15,7 @@
 // by an in-LDS bitonic sort), so equality tests are int32 whatever the int64 token values,
 // and optimal-completion sets come out as class bitmasks whose set bits are already in the
 // ascending token order the reference produces with sort + masked_scatter (:503-514).
-#include "lev_common.hpp"
+#include "lev_classes.hpp"
 
 namespace pdt {
 
@@ -56,11 +56,17 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
   const int cbase = lane * CPL + 1;
   int rid[CPL], rnext[CPL];
   float prev[CPL], cdel[CPL], cdel_back[CPL];
+  {  // classes of this lane's columns: all loads in flight, then CPL searches side by side
+    int64_t rt[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      rt[j] = cbase + j <= ref_len ? a.ref[(int64_t)(cbase + j - 1) * a.ref_st + n * a.ref_sn] : 0;
+    classes_of<CPL>(ctok, U, search_depth(U), rt, rid);
+  }
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     const int c = cbase + j;
-    rid[j] = -2;
-    if (c <= ref_len) rid[j] = class_of(ctok, U, a.ref[(int64_t)(c - 1) * a.ref_st + n * a.ref_sn]);
+    if (c > ref_len) rid[j] = -2;
     cdel[j] = (float)c * del;
     // added back after the scan: +inf beyond ref_len, which IS the masked_fill(inf) of :332
     // (the scan's operands stay finite there, so no select per column and row is needed)
@@ -229,22 +235,8 @@ __global__ void __launch_bounds__(256) lev_rowsync_kernel(const LevArgs a, const
   bool rmiss = false, hmiss = false;
   const int64_t roff = n * a.ref_sn, hoff = n * a.hyp_sn;
   if (a.has_eos) {
-    for (int t0 = 0; t0 < a.R; t0 += PDT_WAVE) {
-      const int t = t0 + lane;
-      const unsigned long long b = __ballot(t < a.R && a.ref[(int64_t)t * a.ref_st + roff] == a.eos);
-      if (b) {
-        ref_len = t0 + (int)__builtin_ctzll(b);
-        break;
-      }
-    }
-    for (int t0 = 0; t0 < a.H; t0 += PDT_WAVE) {
-      const int t = t0 + lane;
-      const unsigned long long b = __ballot(t < a.H && a.hyp[(int64_t)t * a.hyp_st + hoff] == a.eos);
-      if (b) {
-        hyp_len = t0 + (int)__builtin_ctzll(b);
-        break;
-      }
-    }
+    ref_len = first_eos(a.ref, a.R, a.ref_st, roff, a.eos);
+    hyp_len = first_eos(a.hyp, a.H, a.hyp_st, hoff, a.eos);
     if (a.include_eos) {
       if (ref_len == a.R) rmiss = true; else ref_len += 1;
       if (hyp_len == a.H) hmiss = true; else hyp_len += 1;
@@ -253,29 +245,32 @@ __global__ void __launch_bounds__(256) lev_rowsync_kernel(const LevArgs a, const
   int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;
   if (Heff < 0) Heff = 0;
 
-  // ---- distinct reference tokens in ascending order: bitonic sort in LDS ---------------
-  const int P = L.P;
-  for (int i = lane; i < P; i += PDT_WAVE)
-    srt[i] = i < ref_len ? a.ref[(int64_t)i * a.ref_st + roff] : INT64_MAX;
-  wave_sync();
-  for (int k = 2; k <= P; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = lane; t < (P >> 1); t += PDT_WAVE) {
-        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int l = i | j;
-        const int64_t x = srt[i], y = srt[l];
-        const bool up = (i & k) == 0;
-        if ((x > y) == up) {
-          srt[i] = y;
-          srt[l] = x;
-        }
-      }
-      wave_sync();
-    }
-  }
-  // unique-compact the first ref_len sorted entries -> ctok[0..U) (blocked per lane)
+  // ---- distinct reference tokens in ascending order -> ctok[0..U) ------------------------
   int U = 0;
-  {
+  if (!BIG) {  // R <= 512: sorted in registers (lev_classes.hpp)
+    int64_t xt[8];
+    U = distinct_sorted<8>(a.ref, ref_len, a.ref_st, roff, xt, ctok);
+  } else {  // bitonic sort in LDS
+    const int P = L.P;
+    for (int i = lane; i < P; i += PDT_WAVE)
+      srt[i] = i < ref_len ? a.ref[(int64_t)i * a.ref_st + roff] : INT64_MAX;
+    wave_sync();
+    for (int k = 2; k <= P; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = lane; t < (P >> 1); t += PDT_WAVE) {
+          const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int l = i | j;
+          const int64_t x = srt[i], y = srt[l];
+          const bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            srt[i] = y;
+            srt[l] = x;
+          }
+        }
+        wave_sync();
+      }
+    }
+    // unique-compact the first ref_len sorted entries -> ctok[0..U) (blocked per lane)
     const int B = (P + PDT_WAVE - 1) / PDT_WAVE;
     const int i0 = lane * B;
     int nfirst = 0;
@@ -291,13 +286,23 @@ __global__ void __launch_bounds__(256) lev_rowsync_kernel(const LevArgs a, const
       if (i < ref_len && (i == 0 || srt[i] != srt[i - 1])) ctok[pos++] = srt[i];
     }
   }
-  wave_sync();  // ctok complete; the sort buffer is dead from here on (hyp_l etc. alias it)
+  wave_sync();  // ctok complete; a sort buffer is dead from here on (hyp_l etc. alias it)
   if (a.class_tokens)
     for (int k = lane; k < U; k += PDT_WAVE) a.class_tokens[n * (int64_t)a.R + k] = ctok[k];
 
-  // hypothesis tokens -> class ranks (-1: token does not occur in ref)
-  for (int t = lane; t < hyp_len && t < a.H; t += PDT_WAVE)
-    hyp_l[t] = class_of(ctok, U, a.hyp[(int64_t)t * a.hyp_st + hoff]);
+  // hypothesis tokens -> class ranks (-1: token does not occur in ref), eight look-ups side by side
+  {
+    const int lg = search_depth(U), hl = hyp_len < a.H ? hyp_len : a.H;
+    for (int t0 = 0; t0 < hl; t0 += 8 * PDT_WAVE) {
+      int64_t ht[8];
+      int c[8];
+      load_tokens(a.hyp, hl, a.hyp_st, hoff, t0, 0, ht);
+      classes_of<8>(ctok, U, lg, ht, c);
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (t0 + lane + q * PDT_WAVE < hl) hyp_l[t0 + lane + q * PDT_WAVE] = c[q];
+    }
+  }
   if (lane < a.W && a.bitmask) bm[lane] = 0u;
   wave_sync();
 
@@ -353,7 +358,8 @@ int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream) {
   L.off_row0 = take(exact ? (size_t)(a.R + 1) * 4 : 4);
   L.off_bnd = take(!mask_mode ? (size_t)(a.H + 1) * 4 : 4);
   L.off_bm = take(mask_mode ? (size_t)a.W * 4 : 4);
-  if (off < (size_t)P * 8) off = (size_t)P * 8;
+  const bool big = a.R > 64 * 8;
+  if (big && off < (size_t)P * 8) off = (size_t)P * 8;  // (R <= 512 sorts in registers)
   L.off_ctok = take((size_t)a.R * 8 + 8);
   const size_t per_wave = off;
   const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
@@ -365,7 +371,6 @@ int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream) {
   a.lds_per_wave = (int)per_wave;
   const size_t smem = per_wave * wpw;
   const unsigned grid = (unsigned)((a.N + wpw - 1) / wpw);
-  const bool big = a.R > 64 * 8;
   auto kern = exact ? (big ? lev_rowsync_kernel<true, true> : lev_rowsync_kernel<true, false>)
                     : (big ? lev_rowsync_kernel<false, true> : lev_rowsync_kernel<false, false>);
   if (smem > soft_cap) {
