@@ -2,7 +2,8 @@
 BASELINE shape (one process, so each PMC pass sees the same launches).
 
     python3 profiles/prof_ops.py [names...]     default: all
-      string   error_rate / prefix_error_rates / optimal_completion at C2 (lev_skewed, lev_rowsync, oc_expand)
+      string   error_rate / prefix_error_rates / optimal_completion at C2 (lev_classify + lev_bitpar,
+               lev_rowsync, oc_expand) and edit_distance with costs 1/2/3 (lev_skewed, the cell-by-cell kernel)
       ctc      fused search at the bench shape (N=4096, T=512, V=256, K=16)
       ctc_flat the same with +6 instead of +12 on the peak class (the unkind input)
       ctc_long fused search at C3 (N=1024, T=1000, V=1000): the three-producer instantiation
@@ -42,6 +43,7 @@ if "string" in want:
     for _ in range(REPS):
         F.error_rate(ref, hyp, warn=False)
         F.prefix_error_rates(ref, hyp, warn=False)
+        F.edit_distance(ref, hyp, ins_cost=1.0, del_cost=2.0, sub_cost=3.0, warn=False)
         oc = F.optimal_completion(ref, hyp, warn=False)
     print("optimal_completion C =", oc.shape[-1])
     del ref, hyp, oc

@@ -86,8 +86,13 @@ for l in open(os.path.join(src, "ops.log")):
     if l.startswith("optimal_completion C ="):
         C_oc = int(l.split("=")[1])
 shapes = {
-    "lev_skewed_kernel<false>": dict(what="error_rate / prefix_error_rates, N=4096 T=512", units=4096, alg=(8196 + 10248) / 2,
-                                     per_unit="utterance (mean of the two calls)", cells=512 * 512),
+    "lev_classify_kernel<8>": dict(what="error_rate / prefix_error_rates, N=4096 T=512: token classes + match masks", units=4096,
+                                   alg=8192 + 512 * 8 + 513 * 4, per_unit="utterance (tokens in, look-up tables out)"),
+    "lev_bitpar_kernel": dict(what="error_rate / prefix_error_rates, N=4096 T=512: bit-parallel recurrence", units=4096,
+                              alg=512 * 8 + 513 * 4 + (4 + 2052) / 2, per_unit="utterance (tables in; mean of the two calls out)",
+                              cells=512 * 512),
+    "lev_skewed_kernel<false>": dict(what="edit_distance with costs 1/2/3 (cell-by-cell), N=4096 T=512", units=4096, alg=8196,
+                                     per_unit="utterance", cells=512 * 512),
     "lev_rowsync_kernel<false, false>": dict(what="optimal_completion masks, N=4096 T=512", units=4096, alg=8192 + 513 * 64,
                                              per_unit="utterance (tokens in, class bitmasks out)", cells=512 * 512),
     "oc_expand_tiles_kernel": dict(what="optimal_completion expansion", units=4096, alg=8 * 513 * (C_oc or 0),

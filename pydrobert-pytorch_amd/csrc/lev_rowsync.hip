@@ -163,7 +163,9 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
           atomicOr(&bm[rnext[j] >> 5], 1u << (rnext[j] & 31));
       }
       if (lane == 0 && col0 == m && ref_len > 0) atomicOr(&bm[rank0 >> 5], 1u << (rank0 & 31));
-      wave_sync();
+      // (no wait here or below: the LDS serves one wave's instructions in order -- the read sees
+      // the ds_or of every lane, the next row's ds_or see the zeros; only the compiler is told)
+      __builtin_amdgcn_wave_barrier();
       int cnt = 0;
       if (lane < W) {
         const unsigned w = bm[lane];
@@ -173,7 +175,7 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
       }
       cnt = W <= 16 ? row0_sum(cnt) : wave_sum(cnt);  // (only lanes < W hold words)
       max_cnt = cnt > max_cnt ? cnt : max_cnt;
-      wave_sync();
+      __builtin_amdgcn_wave_barrier();
     } else if (a.mode == PDT_MODE_PREFIX) {
       float v = col0;
 #pragma unroll
