@@ -202,7 +202,10 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   if (producer) {
     // elements of the NEXT row of this wave held in registers while the current one is processed
     constexpr int kPrefetch = 8;
-    constexpr int kBatch = 8;  // long rows: loads in flight beyond the prefetched part
+#ifndef PDT_LONG_BATCH
+#define PDT_LONG_BATCH 32
+#endif
+    constexpr int kBatch = PDT_LONG_BATCH;  // long rows: loads in flight beyond the prefetched part
     float pre[kPrefetch];
     // Short lists (P == 1, K <= 16).  94 % of the frames are decided by each prefix's first one or
     // two list entries (lean tier, ctc_frame.hpp), so the producer normally hands over only the
@@ -358,7 +361,10 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
         {
           const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
           int v = lane + kPrefetch * PDT_WAVE;
-          if constexpr (!INREG) {  // long rows: kBatch loads in flight
+          if constexpr (!INREG) {
+            // long rows: kBatch loads in flight, then the rest in guarded groups of 8 (a load that
+            // waits for the one before it is a round trip to HBM: V = 5000 took nine per frame
+            // with batches of 8 and a one-by-one tail)
             for (; v + (kBatch - 1) * PDT_WAVE <= V; v += kBatch * PDT_WAVE) {
               float x[kBatch];
 #pragma unroll
@@ -366,6 +372,17 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #pragma unroll
               for (int i = 0; i < kBatch; ++i) {
                 p[v + i * PDT_WAVE] = x[i];
+                mx = fmaxf(mx, x[i]);
+              }
+            }
+            for (; v <= V; v += 8 * PDT_WAVE) {
+              float x[8];
+#pragma unroll
+              for (int i = 0; i < 8; ++i)
+                x[i] = v + i * PDT_WAVE <= V ? row[(int64_t)(v + i * PDT_WAVE) * a.lg_sv] : -PDT_INF;
+#pragma unroll
+              for (int i = 0; i < 8; ++i) {
+                if (v + i * PDT_WAVE <= V) p[v + i * PDT_WAVE] = x[i];
                 mx = fmaxf(mx, x[i]);
               }
             }
@@ -639,13 +656,21 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
   const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
   // Long rows: one producer wave per frame is the bottleneck and LDS (not registers) bounds
   // the occupancy, so three producers share the frames of an utterance (one utterance per
-  // workgroup); fall back to two, then to one producer with a two-slot ring.
+  // workgroup); beyond what three slots of such a ring hold, one producer with a two-slot ring.
   if (V + 1 > 8 * PDT_WAVE) {
+    // Four ring slots while four workgroups still fit a CU (rows up to ~1.7 K tokens), three
+    // beyond: with long rows the occupancy is worth more than the fourth slot (measured, N = 4096,
+    // three producers: V = 1500 3.73 ms with four slots / 3.92 with three; V = 2000 5.64 / 4.94;
+    // V = 3000 8.14 / 6.93; two producers on three slots, the round-1 choice beyond ~3.9 K
+    // tokens: V = 5000 32.4 ms against 24.5).
     *rl = ring_layout(V, W, 4, 1, 3);
-    if ((size_t)rl->utt_bytes * 2 <= hard_cap) return *plan = CtcPlan{3, 4, 1, 0}, PDT_OK;
-    *rl = ring_layout(V, W, 3, 1, 2);
-    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{2, 3, 1, 0}, PDT_OK;
-    // the longest rows LDS can hold at all
+    if ((size_t)rl->utt_bytes * 4 <= hard_cap) return *plan = CtcPlan{3, 4, 1, 0}, PDT_OK;
+    *rl = ring_layout(V, W, 3, 1, 3);
+    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{3, 3, 1, 0}, PDT_OK;
+    // the longest rows LDS can hold at all: two slots, a producer each (V = 12 000: 8.2 ms against
+    // 14.8 with one producer), then one producer (its scratch is a little smaller)
+    *rl = ring_layout(V, W, 2, 1, 2);
+    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{2, 2, 1, 0}, PDT_OK;
     *rl = ring_layout(V, W, 2, 1, 1);
     if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{1, 2, 1, 0}, PDT_OK;
     // beyond: the rows stay in the HBM workspace
