@@ -130,14 +130,13 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 // constant -- the row pass then has no chunk predicates to evaluate (instantiated for the
 // byte-sized vocabularies V = 256..319; NT = -1: any V).
 // INREG (P = 1 only): the whole row, V + 1 <= 512 elements, sits in the eight prefetch registers
-// of the producer's lanes.  P = 1 without it is the last resort for rows so long that only a
-// two-slot ring of one producer fits in LDS: the generic LDS-staged row pass of the P > 1 forms.
-// GROW (P = 1, generic row pass): rows no LDS ring can hold -- see RingLayout::row_global.
+// of the producer's lanes; longer rows take the generic LDS-staged row pass of the P > 1 forms.
+// GROW (generic row pass): rows no LDS ring can hold -- see RingLayout::row_global.
 template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
 __global__ void __launch_bounds__(256, INREG ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
-  static_assert(!GROW || (P == 1 && !INREG), "rows in the workspace are a form of the generic one-producer pass");
+  static_assert(!GROW || !INREG, "rows in the workspace are a form of the generic row pass");
   static_assert(NT < 0 || INREG, "compile-time chunk counts belong to the register-resident row pass");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -656,7 +655,7 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
   const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
   // Long rows: one producer wave per frame is the bottleneck and LDS (not registers) bounds
   // the occupancy, so three producers share the frames of an utterance (one utterance per
-  // workgroup); beyond what three slots of such a ring hold, one producer with a two-slot ring.
+  // workgroup).
   if (V + 1 > 8 * PDT_WAVE) {
     // Four ring slots while four workgroups still fit a CU (rows up to ~1.7 K tokens), three
     // beyond: with long rows the occupancy is worth more than the fourth slot (measured, N = 4096,
@@ -665,17 +664,14 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
     // tokens: V = 5000 32.4 ms against 24.5).
     *rl = ring_layout(V, W, 4, 1, 3);
     if ((size_t)rl->utt_bytes * 4 <= hard_cap) return *plan = CtcPlan{3, 4, 1, 0}, PDT_OK;
+
     *rl = ring_layout(V, W, 3, 1, 3);
     if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{3, 3, 1, 0}, PDT_OK;
-    // the longest rows LDS can hold at all: two slots, a producer each (V = 12 000: 8.2 ms against
-    // 14.8 with one producer), then one producer (its scratch is a little smaller)
-    *rl = ring_layout(V, W, 2, 1, 2);
-    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{2, 2, 1, 0}, PDT_OK;
-    *rl = ring_layout(V, W, 2, 1, 1);
-    if ((size_t)rl->utt_bytes <= hard_cap) return *plan = CtcPlan{1, 2, 1, 0}, PDT_OK;
-    // beyond: the rows stay in the HBM workspace
-    *rl = ring_layout(V, W, 4, 1, 1, true);
-    return *plan = CtcPlan{1, 4, 1, 2}, PDT_OK;
+    // beyond: the rows stay in the HBM workspace, still three producers (two producers on a
+    // two-slot LDS ring: V = 12 000 8.3 ms against 6.9 this way; below ~10 K tokens the LDS ring
+    // wins: V = 8000 16.7 against 19.1, V = 5000 24.6 against 49.6)
+    *rl = ring_layout(V, W, 4, 1, 3, true);
+    return *plan = CtcPlan{3, 4, 1, 2}, PDT_OK;
   }
   // ring depth and utterances per workgroup from the LDS budget
   int nstage = PDT_RING_STAGES, upw = PDT_UTT_PER_WG;
@@ -693,10 +689,8 @@ int launch_ctc_search(CtcArgs a, hipStream_t stream) {
   RingLayout rl;
   const int rc = plan_ctc_search(a.V, a.W, &plan, &rl);
   if (rc != PDT_OK) return rc;
+  if (plan.inreg == 2) return launch_ctc_search_p<3, -1, false, true>(a, rl, stream);
   if (plan.producers == 3) return launch_ctc_search_p<3>(a, rl, stream);
-  if (plan.producers == 2) return launch_ctc_search_p<2>(a, rl, stream);
-  if (plan.inreg == 2) return launch_ctc_search_p<1, -1, false, true>(a, rl, stream);
-  if (!plan.inreg) return launch_ctc_search_p<1, -1, false>(a, rl, stream);
   if (a.V / PDT_WAVE == 4) return launch_ctc_search_p<1, 4>(a, rl, stream);
   return launch_ctc_search_p<1>(a, rl, stream);
 }
