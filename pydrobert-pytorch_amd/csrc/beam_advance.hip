@@ -30,33 +30,34 @@ struct CtcAdvArgs {
   int lds_per_wave, waves_per_wg;
 };
 
-__global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
+// One WORKGROUP per batch element (a.waves_per_wg waves).  The Kp per-prefix selections over the
+// dense extension probabilities are independent and each is a chain of round trips to HBM for a
+// lone wave: the waves take prefixes k = w, w + NW, ... in turn (every wave with its own survivor
+// scratch), wave 0 runs the frame on the finished lists, all waves copy the histories.
+__global__ void __launch_bounds__(512) ctc_advance_kernel(const CtcAdvArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  const int64_t n = (int64_t)blockIdx.x * a.waves_per_wg + wave;
-  if (n >= a.N) return;
+  const int wave = (int)(threadIdx.x >> 6), NW = a.waves_per_wg;
+  const int64_t n = blockIdx.x;
   const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
-  unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
-  float *p = reinterpret_cast<float *>(base);
+  float *p = reinterpret_cast<float *>(smem);
   FrameLds L;
-  L.carve(base + (size_t)((V + 1 + 3) & ~3) * 4, V, W, Kp, true);
+  L.carve(smem + (size_t)((V + 1 + 3) & ~3) * 4, V, W, Kp, true);
   int *srcs = reinterpret_cast<int *>(L.surv);  // reused after the frame
+  u64 *my_surv = reinterpret_cast<u64 *>(smem + a.lds_per_wave) + (size_t)wave * PDT_SURV_CAP;
 
-  for (int v = lane; v < V; v += PDT_WAVE) p[v] = a.nonext[n * a.ne_sn + v * a.ne_sv];
-  if (lane == 0) p[V] = a.blank[n * a.bl_sn];
-  Beam bm;
-  bm.nb = lane < Kp ? a.nb_prev[n * a.pb_sn + lane * a.pb_sk] : -PDT_INF;
-  bm.b = lane < Kp ? a.b_prev[n * a.pbb_sn + lane * a.pbb_sk] : -PDT_INF;
-  bm.last = lane < Kp ? (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)-1), (int64_t)V) : 0;
-  bm.len = lane < Kp ? (int)a.lens[n * a.le_sn + lane * a.le_sk] : 0;
-  bm.node = -1;
-  unsigned m = 0u;
-  if (lane < Kp)
-    for (int b = 0; b < Kp; ++b)
-      if (a.isp[n * a.ip_sn + lane * a.ip_sa + b * a.ip_sb]) m |= 1u << b;
-  bm.isp = m;
-  wave_sync();
+  const int M = ctc_list_len(V, W, Kp);
+  for (int k = wave; k < Kp; k += NW) {
+    const u64 tk = wave_top_sorted_strided<true>(a.ext + n * a.ext_sn + k * a.ext_sk, a.ext_sv, V, M, my_surv);
+    if (lane < M) {
+      L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
+      L.tl_p[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));
+    }
+    wave_sync();
+  }
+  for (int v = (int)threadIdx.x; v < V; v += NW * PDT_WAVE) p[v] = a.nonext[n * a.ne_sn + v * a.ne_sv];
+  if (threadIdx.x == 0) p[V] = a.blank[n * a.bl_sn];
+  __syncthreads();
 
   DenseCtx dc;
   dc.ext = a.ext + n * a.ext_sn;
@@ -66,35 +67,47 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
   dc.yp_ss = a.yp_ss;
   dc.yp_sk = a.yp_sk;
   dc.S = S;
-  CtcArgs dummy{};
-  dummy.N = a.N;
-  int new_src, new_tok, new_kind;
-  const int old_len = bm.len;
-  (void)old_len;
-  #ifdef PDT_STAMPS
-  unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
+  dc.lists_ready = 1;
+  if (wave == 0) {
+    Beam bm;
+    bm.nb = lane < Kp ? a.nb_prev[n * a.pb_sn + lane * a.pb_sk] : -PDT_INF;
+    bm.b = lane < Kp ? a.b_prev[n * a.pbb_sn + lane * a.pbb_sk] : -PDT_INF;
+    bm.last = lane < Kp ? (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)-1), (int64_t)V) : 0;
+    bm.len = lane < Kp ? (int)a.lens[n * a.le_sn + lane * a.le_sk] : 0;
+    bm.node = -1;
+    unsigned m = 0u;
+    if (lane < Kp)
+      for (int b = 0; b < Kp; ++b)
+        if (a.isp[n * a.ip_sn + lane * a.ip_sa + b * a.ip_sb]) m |= 1u << b;
+    bm.isp = m;
+    CtcArgs dummy{};
+    dummy.N = a.N;
+    int new_src, new_tok, new_kind;
+#ifdef PDT_STAMPS
+    unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
-  ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
+    ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
 
-  // ---- outputs (:855-934) ----------------------------------------------------------------
-  if (lane < W) {
-    const bool valid = new_kind >= 0;
-    a.y_next_last[n * W + lane] = bm.last;
-    a.y_next_lens[n * W + lane] = bm.len;
-    a.nb_next[n * W + lane] = bm.nb;
-    a.b_next[n * W + lane] = bm.b;
-    a.next_src[n * W + lane] = valid ? new_src : 0;
-    a.next_nonext[n * W + lane] = (uint8_t)(new_kind == 2);
-    for (int b = 0; b < W; ++b) a.next_isp[(n * W + lane) * W + b] = (uint8_t)((bm.isp >> b) & 1u);
-    srcs[lane] = valid ? new_src : -1;
-    L.info[lane] = bm.len;        // the frame's scratch is free again: per-entry length and
-    L.info[W + lane] = new_kind;  // kind for the copy loop (its tail runs with part of the wave)
-    // the new token sits right after the source prefix (:862-864)
-    if (valid && new_kind != 2) a.y_next[((int64_t)(bm.len - 1) * a.N + n) * W + lane] = new_tok;
+    // ---- outputs (:855-934) --------------------------------------------------------------
+    if (lane < W) {
+      const bool valid = new_kind >= 0;
+      a.y_next_last[n * W + lane] = bm.last;
+      a.y_next_lens[n * W + lane] = bm.len;
+      a.nb_next[n * W + lane] = bm.nb;
+      a.b_next[n * W + lane] = bm.b;
+      a.next_src[n * W + lane] = valid ? new_src : 0;
+      a.next_nonext[n * W + lane] = (uint8_t)(new_kind == 2);
+      for (int b = 0; b < W; ++b) a.next_isp[(n * W + lane) * W + b] = (uint8_t)((bm.isp >> b) & 1u);
+      srcs[lane] = valid ? new_src : -1;
+      L.info[lane] = bm.len;        // the frame's scratch is free again: per-entry length and
+      L.info[W + lane] = new_kind;  // kind for the copy loop
+      // the new token sits right after the source prefix (:862-864)
+      if (valid && new_kind != 2) a.y_next[((int64_t)(bm.len - 1) * a.N + n) * W + lane] = new_tok;
+    }
   }
-  wave_sync();
+  __syncthreads();
   // history rows of the source prefix, below the position just written
-  for (int idx = lane; idx < (S + 1) * W; idx += PDT_WAVE) {
+  for (int idx = (int)threadIdx.x; idx < (S + 1) * W; idx += NW * PDT_WAVE) {
     const int s = idx / W, i = idx - s * W;
     const int src = srcs[i];
     const int len_i = L.info[i], kind_i = L.info[W + i];
@@ -109,21 +122,20 @@ __global__ void __launch_bounds__(256) ctc_advance_kernel(const CtcAdvArgs a) {
 
 int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.W > kMaxWidth || a.Kp < 1 || a.Kp > kMaxWidth) return PDT_E_TOO_LONG;
-  size_t per_wave = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
-  per_wave = (per_wave + 15) & ~(size_t)15;
-  const size_t soft_cap = 64 * 1024, hard_cap = 160 * 1024;
-  if (per_wave > hard_cap) return PDT_E_TOO_LONG;
-  int wpw = (int)(soft_cap / per_wave);
-  wpw = wpw > 4 ? 4 : (wpw < 1 ? 1 : wpw);
-  a.waves_per_wg = wpw;
-  a.lds_per_wave = (int)per_wave;
-  const size_t smem = per_wave * wpw;
-  if (smem > soft_cap) {
+  int nw = 1;
+  while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
+  size_t frame = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
+  frame = (frame + 15) & ~(size_t)15;
+  const size_t smem = frame + (size_t)nw * PDT_SURV_CAP * 8;  // + one survivor scratch per wave
+  if (smem > 160 * 1024) return PDT_E_TOO_LONG;
+  a.waves_per_wg = nw;
+  a.lds_per_wave = (int)frame;
+  if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_advance_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(ctc_advance_kernel, dim3((a.N + wpw - 1) / wpw), dim3(64 * wpw), smem, stream, a);
+  hipLaunchKernelGGL(ctc_advance_kernel, dim3((unsigned)a.N), dim3(64 * nw), smem, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -140,19 +152,23 @@ struct BeamAdvArgs {
   int lds_per_wave, waves_per_wg;
 };
 
-__global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) {
+// One WORKGROUP per batch element (a.waves_per_wg waves): the Kp selections are independent and
+// each is a chain of round trips to HBM for a lone wave, so the waves take prefixes k = w, w + NW,
+// ... in turn; wave 0 merges the lists (values are kept with the tokens: no global load in the K
+// rounds); the history copy is spread over all the waves again.  N = 1024, K = 16, V = 1000:
+// 0.164 ms with one wave per element doing everything -> see DESIGN.md section 4.4.
+__global__ void __launch_bounds__(512) beam_advance_kernel(const BeamAdvArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  const int64_t n = (int64_t)blockIdx.x * a.waves_per_wg + wave;
-  if (n >= a.N) return;
+  const int wave = (int)(threadIdx.x >> 6), NW = a.waves_per_wg;
+  const int64_t n = blockIdx.x;
   const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
   const int K = min(W, (int)min((int64_t)Kp * V, (int64_t)PDT_WAVE));  // :121
   const int M = min(V, K);
-  unsigned char *base = smem + (size_t)wave * a.lds_per_wave;
-  u64 *surv = reinterpret_cast<u64 *>(base);
-  int *tl = reinterpret_cast<int *>(surv + PDT_SURV_CAP);
-  int *srcs = tl + Kp * PDT_WAVE;
+  u64 *surv = reinterpret_cast<u64 *>(smem) + (size_t)wave * PDT_SURV_CAP;  // one scratch per wave
+  int *tl = reinterpret_cast<int *>(reinterpret_cast<u64 *>(smem) + (size_t)NW * PDT_SURV_CAP);
+  float *tlm = reinterpret_cast<float *>(tl + Kp * PDT_WAVE);
+  int *srcs = reinterpret_cast<int *>(tlm + Kp * PDT_WAVE);
   int *toks = srcs + W;
   int *plens = toks + W;
 
@@ -160,53 +176,57 @@ __global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) 
   // log_probs_prev[k] + log_probs_t[k, v] (:122) -- so that candidates whose SUMS are equal come
   // out lowest token first although their log_probs_t differ: with "lowest lane first" in the
   // merge below an exact tie goes to the lowest flat index k * V + v, the oracle's order
-  for (int k = 0; k < Kp; ++k) {
-    const u64 tk = wave_top_sorted_strided<false, false, true>(
+  for (int k = wave; k < Kp; k += NW) {
+    const u64 tk = wave_top_sorted_strided<true, false, true>(  // (rows in HBM: eight loads in flight)
         a.lpt + n * a.lt_sn + k * a.lt_sk, a.lt_sv, V, M, surv, nullptr, nullptr, 1, a.lpp[n * a.lp_sn + k * a.lp_sk]);
-    if (lane < M) tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
+    if (lane < M) {
+      tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
+      tlm[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));  // the sum that was ranked
+    }
     wave_sync();
   }
-  const bool live = lane < Kp;
-  const float lp_prev = live ? a.lpp[n * a.lp_sn + lane * a.lp_sk] : 0.0f;
-  const float *myrow = a.lpt + n * a.lt_sn + (live ? lane : 0) * a.lt_sk;
-  const int *mytl = tl + (live ? lane : 0) * PDT_WAVE;
-  int ptr = 0;
-  int new_src = 0, new_tok = 0;
-  float new_lp = -PDT_INF;
-  bool valid = false;
-  for (int i = 0; i < K; ++i) {
-    const bool has = live && ptr < M;
-    const int tok = has ? mytl[ptr] : 0;
-    const float mass = has ? lp_prev + myrow[(int64_t)tok * a.lt_sv] : 0.0f;  // :122
-    const unsigned key = has ? fkey(mass) : 0u;
-    const unsigned mx = wave_max_u32(key);
-    if (mx == 0u) break;
-    const int win = (int)__builtin_ctzll(__ballot(key == mx));
-    const int wtok = __builtin_amdgcn_readlane(tok, win);
-    const float wmass = readlane_f(mass, win);
-    if (lane == i) {
-      new_src = win;
-      new_tok = wtok;
-      new_lp = wmass;
-      valid = true;
+  __syncthreads();
+  if (wave == 0) {
+    const bool live = lane < Kp;
+    const int *mytl = tl + (live ? lane : 0) * PDT_WAVE;
+    const float *mytlm = tlm + (live ? lane : 0) * PDT_WAVE;
+    int ptr = 0;
+    int new_src = 0, new_tok = 0;
+    float new_lp = -PDT_INF;
+    bool valid = false;
+    for (int i = 0; i < K; ++i) {
+      const bool has = live && ptr < M;
+      const int tok = has ? mytl[ptr] : 0;
+      const float mass = has ? mytlm[ptr] : 0.0f;  // :122
+      const unsigned key = has ? fkey(mass) : 0u;
+      const unsigned mx = wave_max_u32(key);
+      if (mx == 0u) break;
+      const int win = (int)__builtin_ctzll(__ballot(key == mx));
+      const int wtok = __builtin_amdgcn_readlane(tok, win);
+      const float wmass = readlane_f(mass, win);
+      if (lane == i) {
+        new_src = win;
+        new_tok = wtok;
+        new_lp = wmass;
+        valid = true;
+      }
+      if (lane == win) ++ptr;
     }
-    if (lane == win) ++ptr;
+    if (lane < W) {
+      const int plen = valid ? (a.lens ? (int)a.lens[n * a.le_sn + new_src * a.le_sk] : S) : -1;
+      a.lp_next[n * W + lane] = valid ? new_lp : -PDT_INF;            // :145-153 for the overflow
+      a.next_src[n * W + lane] = valid ? new_src : 0;
+      a.y_next_lens[n * W + lane] = valid ? plen + 1 : 0;
+      srcs[lane] = valid ? new_src : -1;
+      toks[lane] = new_tok;
+      plens[lane] = plen;
+    }
   }
-  int plen = 0;
-  if (lane < W) {
-    plen = valid ? (a.lens ? (int)a.lens[n * a.le_sn + new_src * a.le_sk] : S) : -1;
-    a.lp_next[n * W + lane] = valid ? new_lp : -PDT_INF;            // :145-153 for the overflow
-    a.next_src[n * W + lane] = valid ? new_src : 0;
-    a.y_next_lens[n * W + lane] = valid ? plen + 1 : 0;
-    srcs[lane] = valid ? new_src : -1;
-    toks[lane] = new_tok;
-    plens[lane] = plen;
-  }
-  wave_sync();
-  for (int idx = lane; idx < a.S_out * W; idx += PDT_WAVE) {
+  __syncthreads();
+  for (int idx = (int)threadIdx.x; idx < a.S_out * W; idx += NW * PDT_WAVE) {
     const int s = idx / W, i = idx - s * W;
     const int src = srcs[i];
-    const int pl = plens[i];  // (not a shuffle: the tail iteration runs with part of the wave)
+    const int pl = plens[i];
     int64_t v;
     if (src < 0)
       v = 0;
@@ -220,14 +240,12 @@ __global__ void __launch_bounds__(256) beam_advance_kernel(const BeamAdvArgs a) 
 
 int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.W > PDT_WAVE || a.Kp < 1 || a.Kp > PDT_WAVE) return PDT_E_TOO_LONG;
-  size_t per_wave = (size_t)PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 4 + (size_t)a.W * 12;
-  per_wave = (per_wave + 15) & ~(size_t)15;
-  int wpw = (int)((64 * 1024) / per_wave);
-  wpw = wpw > 4 ? 4 : (wpw < 1 ? 1 : wpw);
-  a.waves_per_wg = wpw;
-  a.lds_per_wave = (int)per_wave;
-  hipLaunchKernelGGL(beam_advance_kernel, dim3((a.N + wpw - 1) / wpw), dim3(64 * wpw),
-                     per_wave * wpw, stream, a);
+  int nw = 1;
+  while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
+  const size_t smem = ((size_t)nw * PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 8 + (size_t)a.W * 12 + 15) & ~(size_t)15;
+  a.waves_per_wg = nw;
+  a.lds_per_wave = 0;
+  hipLaunchKernelGGL(beam_advance_kernel, dim3((unsigned)a.N), dim3(64 * nw), smem, stream, a);
   return (int)hipGetLastError();
 }
 

@@ -82,6 +82,7 @@ struct DenseCtx {
   const int64_t *y_prev; // y_prev[:, n, :] : element (s, k) at y_prev[s * yp_ss + k * yp_sk]
   int64_t yp_ss, yp_sk;
   int S;
+  int lists_ready;       // the per-prefix lists are in L.tl_tok / L.tl_p already (built by the caller's waves)
 };
 
 // ints per next-token table: W * W, but at least 128 so that the table not in use (nxt_new
@@ -183,9 +184,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // ---- sorted token list(s): tokens by descending extension probability ----------------
   // shared form: L.tl_tok / L.tl_p / L.pos were filled by build_shared_list (possibly by
   // another wave); dense form: one list per prefix, built here
-  if (DENSE) {
+  if (DENSE && !dc.lists_ready) {
     for (int k = 0; k < Kp; ++k) {
-      const u64 tk = wave_top_sorted_strided(dc.ext + k * dc.ext_sk, dc.ext_sv, V, M, L.surv);
+      const u64 tk = wave_top_sorted_strided<true>(dc.ext + k * dc.ext_sk, dc.ext_sv, V, M, L.surv);  // (rows in HBM: eight loads in flight)
       if (lane < M) {
         L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
         L.tl_p[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));
