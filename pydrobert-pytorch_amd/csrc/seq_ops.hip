@@ -6,10 +6,99 @@
 //   pdt_sequence_log_probs_{forward,backward} -- sequence_log_probs on tensors
 //       (_decoding.py:1516-1551): log_softmax + gather + masked sum over the step axis, fused;
 //       the backward writes softmax-minus-onehot rows scaled by the upstream gradient.
-// Both are HBM-bound on the logits (4 * V bytes per frame).
+// Both are HBM-bound on the logits (4 * V bytes per frame) -- once every row is read with all its
+// loads in flight and the rows of one sequence are spread over the waves of a workgroup: frames
+// are independent, only the reductions over them are ordered.  (Round 1 walked the frames of a
+// sequence with one wave, one 64-element load at a time, and sequence_log_probs re-derived the
+// sequence length with a serial scan in every row's wave: 2.4 / 2.2 / 33 ms at N = 4096, T = 512,
+// V = 257, where the logits are 0.4 ms of HBM time.)
 #include "wave_select.hpp"
 
 namespace pdt {
+
+// Rows of up to 64 * NR elements are held in registers (one pass over memory); NR = 8 keeps the
+// kernels at eight waves per SIMD for the common vocabularies, 16 serves rows up to 1024.
+// One row x[0..V) (element stride sv) through a wave.  Returns the wave-wide maximum and, if asked,
+// the packed (value, lowest index) arg-max key and sum_v exp(x[v] - max).  Rows beyond 64 * NR
+// elements are streamed twice, eight loads in flight.
+struct RowStats {
+  float mx, sum;
+  u64 best;
+};
+template <int NR>
+__device__ __forceinline__ void row_load(const float *x, const int64_t sv, const int V, float (&r)[NR]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int v = lane + i * PDT_WAVE;
+    r[i] = (i * PDT_WAVE < V && v < V) ? x[(int64_t)v * sv] : -PDT_INF;
+  }
+}
+template <bool WANT_ARG, bool WANT_SUM, int NR>
+__device__ __forceinline__ RowStats row_stats(const float *x, const int64_t sv, const int V, float (&r)[NR]) {
+  const int lane = lane_id();
+  RowStats st;
+  st.sum = 0.0f;
+  st.best = 0ull;
+  float mx = -PDT_INF;
+  u64 best = 0ull;
+  const bool in_regs = V <= NR * PDT_WAVE;
+  if (in_regs) {
+    row_load<NR>(x, sv, V, r);
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (i * PDT_WAVE < V) {
+        mx = fmaxf(mx, r[i]);
+        if (WANT_ARG && lane + i * PDT_WAVE < V) {
+          const u64 k = pack_key(fkey(r[i]), (unsigned)(lane + i * PDT_WAVE));
+          best = k > best ? k : best;
+        }
+      }
+    }
+  } else {
+    for (int v0 = 0; v0 < V; v0 += 8 * PDT_WAVE) {
+      float t[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) t[i] = v0 + i * PDT_WAVE + lane < V ? x[(int64_t)(v0 + i * PDT_WAVE + lane) * sv] : -PDT_INF;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        mx = fmaxf(mx, t[i]);
+        if (WANT_ARG && v0 + i * PDT_WAVE + lane < V) {
+          const u64 k = pack_key(fkey(t[i]), (unsigned)(v0 + i * PDT_WAVE + lane));
+          best = k > best ? k : best;
+        }
+      }
+    }
+  }
+  if (WANT_ARG) {  // wave arg-max of the packed keys (highest value, lowest index)
+    const unsigned hi = (unsigned)(best >> 32);
+    const unsigned hmax = wave_max_u32(hi);
+    const unsigned lo = hi == hmax ? (unsigned)best : 0u;
+    const unsigned lmax = wave_max_u32(lo);
+    st.best = ((u64)hmax << 32) | lmax;
+    st.mx = fkey_inv(hmax);
+  } else {
+    st.mx = wave_max_f(mx);
+  }
+  if (WANT_SUM) {
+    float s = 0.0f;
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i * PDT_WAVE < V) s += expf(r[i] - st.mx);  // (exp(-inf) = 0 beyond V)
+    } else {
+      for (int v0 = 0; v0 < V; v0 += 8 * PDT_WAVE) {
+        float t[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = v0 + i * PDT_WAVE + lane < V ? x[(int64_t)(v0 + i * PDT_WAVE + lane) * sv] : -PDT_INF;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += expf(t[i] - st.mx);
+      }
+    }
+    st.sum = wave_sum_f(s);
+  }
+  return st;
+}
 
 struct GreedyArgs {
   const float *logits; int64_t lg_st, lg_sn, lg_sv;  // (T, N, V) through element strides
@@ -19,53 +108,45 @@ struct GreedyArgs {
   int64_t *paths;           // (T, N) through strides
   int64_t pa_st, pa_sn;
   int64_t *out_lens;        // (N,)
-  int lds_per_wave;
+  int nw;                   // waves per utterance
 };
 
-__global__ void __launch_bounds__(256) ctc_greedy_kernel(const GreedyArgs a) {
+// One workgroup per utterance; its waves take the frames t = w, w + NW, ...
+template <int NR>
+__global__ void __launch_bounds__(1024) ctc_greedy_kernel(const GreedyArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  if (n >= a.N) return;
-  int *arg = reinterpret_cast<int *>(smem + (size_t)wave * a.lds_per_wave);  // [T]
+  const int wave = (int)(threadIdx.x >> 6), NW = a.nw;
+  const int64_t n = blockIdx.x;
+  int *arg = reinterpret_cast<int *>(smem);                   // [T]
+  float *val = reinterpret_cast<float *>(arg + (a.T > 0 ? a.T : 1));  // [T] per-frame log-prob / prob of the arg-max
   const int T = a.T, V = a.V;
   const int in_len = a.in_lens ? (int)min((int64_t)T, max((int64_t)0, a.in_lens[n])) : T;
-  float total = a.is_probs ? 1.0f : 0.0f;  // lane-uniform
-  for (int t = 0; t < T; ++t) {
+  for (int t = wave; t < T; t += NW) {
     const float *x = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
-    // running (value, index) maximum with lowest-index ties, and sum-exp for the normaliser
-    u64 best = 0ull;
-    float mx = -PDT_INF;
-    for (int v = lane; v < V; v += PDT_WAVE) {
-      const float xv = x[(int64_t)v * a.lg_sv];
-      const u64 k = pack_key(fkey(xv), (unsigned)v);
-      best = k > best ? k : best;
-      mx = fmaxf(mx, xv);
-    }
-    // wave arg-max of the packed keys
-    {
-      unsigned hi = (unsigned)(best >> 32);
-      const unsigned hmax = wave_max_u32(hi);
-      const unsigned lo = hi == hmax ? (unsigned)best : 0u;
-      const unsigned lmax = wave_max_u32(lo);
-      best = ((u64)hmax << 32) | lmax;
-    }
-    const int am = (int)idx_of(best);
-    const float xmax = fkey_inv(key_of(best));
-    if (lane == 0) arg[t] = am;
-    if (t < in_len) {  // frames beyond the length contribute 0 (log) or 1 (prob): :540-543
-      if (a.is_probs) {
-        total *= xmax;
-      } else {
-        float s = 0.0f;
-        for (int v = lane; v < V; v += PDT_WAVE) s += expf(x[(int64_t)v * a.lg_sv] - xmax);
-        s = wave_sum_f(s);
-        total += -logf(s);  // log_softmax(x)[argmax] = -log sum exp(x - max)
-      }
+    float r[NR];
+    // frames beyond the length contribute 0 (log) or 1 (prob), :540-543 -- but their arg-max is
+    // still reported in the tail of `paths`
+    RowStats st;
+    if (t < in_len && !a.is_probs)
+      st = row_stats<true, true, NR>(x, a.lg_sv, V, r);
+    else
+      st = row_stats<true, false, NR>(x, a.lg_sv, V, r);
+    if (lane == 0) {
+      arg[t] = (int)idx_of(st.best);
+      // log_softmax(x)[argmax] = -log sum exp(x - max)
+      val[t] = t < in_len ? (a.is_probs ? st.mx : -logf(st.sum)) : (a.is_probs ? 1.0f : 0.0f);
     }
   }
-  wave_sync();
+  __syncthreads();
+  if (wave != 0) return;
+  // the joint (log-)probability: frames in order, 64 partial accumulators combined in lane order
+  float total = a.is_probs ? 1.0f : 0.0f;
+  for (int t = lane; t < T; t += PDT_WAVE) total = a.is_probs ? total * val[t] : total + val[t];
+  for (int off = 1; off < PDT_WAVE; off <<= 1) {
+    const float o = __shfl_xor(total, off);
+    total = a.is_probs ? total * o : total + o;
+  }
   // keep mask, compaction (:531-552): out[j] = j-th kept token; positions >= out_len keep
   // the raw arg-max, as masked_scatter_ leaves them in the reference
   int count = 0;
@@ -100,76 +181,92 @@ struct SlpArgs {
   float *out;               // (A, B)
   const float *grad_out;    // backward (A, B)
   float *grad_logits;       // backward, same layout as logits
+  int nw;                   // waves per sequence
 };
 
-// length of sequence (a, b) = index of first eos + 1, else S (:1533-1546)
-__device__ __forceinline__ int slp_len(const SlpArgs &a, int ai, int bi) {
-  if (!a.has_eos) return a.S;
-  for (int s = 0; s < a.S; ++s)
-    if (a.hyp[((int64_t)ai * a.S + s) * a.B + bi] == a.eos) return s + 1;
-  return a.S + 1;  // no eos: _lens_from_eos gives S, plus one -> nothing masked
-}
-
-template <bool BACKWARD>
-__global__ void __launch_bounds__(256) slp_kernel(const SlpArgs a) {
+// One workgroup per sequence (a, b); its waves take the steps s = w, w + NW, ...  Wave 0 first
+// finds the length (index of the first eos + 1, else S + 1: nothing masked, :1533-1546) with
+// ballots over 64 steps at a time.  Forward: per-wave partial sums in step order, combined in wave
+// order (deterministic).  Backward: each row is read once into registers and its gradient row
+// written once.
+template <bool BACKWARD, int NR>
+__global__ void __launch_bounds__(1024) slp_kernel(const SlpArgs a) {
+  __shared__ int s_len;
+  __shared__ float s_part[16];
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  const int64_t row = (int64_t)blockIdx.x * 4 + wave;  // row = (ai * S + s) * B + bi
-  const int64_t rows = (int64_t)a.A * a.S * a.B;
-  if (row >= rows) return;
-  const int bi = (int)(row % a.B);
-  const int s = (int)((row / a.B) % a.S);
-  const int ai = (int)(row / ((int64_t)a.B * a.S));
-  const int V = a.V;
-  const int64_t tok = a.hyp[row];
-  bool masked = tok < 0 || tok >= V;
-  if (a.has_eos && !masked) masked = s >= slp_len(a, ai, bi);
-  float *go = BACKWARD ? a.grad_logits + row * (int64_t)V : nullptr;
-  if (masked) {
-    if (BACKWARD)
-      for (int v = lane; v < V; v += PDT_WAVE) go[v] = 0.0f;
-    return;
-  }
-  const float *x = a.logits + row * (int64_t)V;
-  float mx = -PDT_INF;
-  for (int v = lane; v < V; v += PDT_WAVE) mx = fmaxf(mx, x[v]);
-  mx = wave_max_f(mx);
-  float sum = 0.0f;
-  for (int v = lane; v < V; v += PDT_WAVE) sum += expf(x[v] - mx);
-  sum = wave_sum_f(sum);
-  const float lse = mx + logf(sum);
-  if (!BACKWARD) {
-    if (lane == 0) atomicAdd(&a.out[(int64_t)ai * a.B + bi], x[tok] - lse);
-    return;
-  }
-  const float g = a.grad_out[(int64_t)ai * a.B + bi];
-  for (int v = lane; v < V; v += PDT_WAVE) go[v] = g * ((v == tok ? 1.0f : 0.0f) - expf(x[v] - lse));
-}
-
-// deterministic forward: one wave per output element sums its S steps in order
-__global__ void __launch_bounds__(256) slp_forward_kernel(const SlpArgs a) {
-  const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6);
-  const int64_t o = (int64_t)blockIdx.x * 4 + wave;  // o = ai * B + bi
-  if (o >= (int64_t)a.A * a.B) return;
+  const int wave = (int)(threadIdx.x >> 6), NW = a.nw;
+  const int64_t o = blockIdx.x;  // o = ai * B + bi
   const int ai = (int)(o / a.B), bi = (int)(o % a.B);
-  const int V = a.V;
-  const int len = slp_len(a, ai, bi);
-  float acc = 0.0f;
-  for (int s = 0; s < a.S; ++s) {
-    const int64_t row = ((int64_t)ai * a.S + s) * a.B + bi;
-    const int64_t tok = a.hyp[row];
-    if (tok < 0 || tok >= V || s >= len) continue;
-    const float *x = a.logits + row * (int64_t)V;
-    float mx = -PDT_INF;
-    for (int v = lane; v < V; v += PDT_WAVE) mx = fmaxf(mx, x[v]);
-    mx = wave_max_f(mx);
-    float sum = 0.0f;
-    for (int v = lane; v < V; v += PDT_WAVE) sum += expf(x[v] - mx);
-    sum = wave_sum_f(sum);
-    acc += (x[tok] - mx) - logf(sum);
+  const int V = a.V, S = a.S;
+  const int64_t *hseq = a.hyp + (int64_t)ai * S * a.B + bi;  // step s at hseq[s * B]
+  if (wave == 0) {
+    int len = S + 1;
+    if (a.has_eos) {
+      for (int s0 = 0; s0 < S && len == S + 1; s0 += 8 * PDT_WAVE) {
+        int64_t t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = s0 + q * PDT_WAVE + lane < S ? hseq[(int64_t)(s0 + q * PDT_WAVE + lane) * a.B] : a.eos + 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const u64 hit = __ballot(t[q] == a.eos);
+          if (hit && len == S + 1) len = s0 + q * PDT_WAVE + (int)__builtin_ctzll(hit) + 1;
+        }
+      }
+    }
+    if (lane == 0) s_len = len;
   }
-  if (lane == 0) a.out[o] = acc;
+  __syncthreads();
+  const int len = s_len;
+  const float g = BACKWARD ? a.grad_out[o] : 0.0f;
+  float acc = 0.0f;
+  // this wave's tokens, 64 steps at a time (lane l: step wave + NW * (j0 + l))
+  for (int j0 = 0; wave + (int64_t)NW * j0 < S; j0 += PDT_WAVE) {
+    const int s_mine = wave + NW * (j0 + lane);
+    const int64_t tok_mine = s_mine < S ? hseq[(int64_t)s_mine * a.B] : -1;
+    for (int j = 0; j < PDT_WAVE; ++j) {
+      const int s = wave + NW * (j0 + j);
+      if (s >= S) break;
+      const int64_t tok = __shfl(tok_mine, j);
+      const int64_t row = ((int64_t)ai * S + s) * a.B + bi;
+      const bool masked = tok < 0 || tok >= V || s >= len;
+      float *go = BACKWARD ? a.grad_logits + row * (int64_t)V : nullptr;
+      if (masked) {
+        if (BACKWARD)
+          for (int v = lane; v < V; v += PDT_WAVE) go[v] = 0.0f;
+        continue;
+      }
+      const float *x = a.logits + row * (int64_t)V;
+      float r[NR];
+      const RowStats st = row_stats<false, true, NR>(x, 1, V, r);
+      const float lse = st.mx + logf(st.sum);
+      if (!BACKWARD) {
+        acc += (x[tok] - st.mx) - logf(st.sum);
+      } else if (V <= NR * PDT_WAVE) {
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          const int v = lane + i * PDT_WAVE;
+          if (i * PDT_WAVE < V && v < V) go[v] = g * ((v == tok ? 1.0f : 0.0f) - expf(r[i] - lse));
+        }
+      } else {
+        for (int v = lane; v < V; v += PDT_WAVE) go[v] = g * ((v == tok ? 1.0f : 0.0f) - expf(x[v] - lse));
+      }
+    }
+  }
+  if (BACKWARD) return;
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float total = 0.0f;
+    for (int w = 0; w < NW; ++w) total += s_part[w];
+    a.out[o] = total;
+  }
+}
+
+// waves per sequence: a power of two <= 16, no more than the steps give work to
+static int seq_waves(int64_t steps) {
+  int nw = 1;
+  while (nw < 16 && nw * 4 <= steps) nw *= 2;
+  return nw;
 }
 
 }  // namespace pdt
@@ -184,21 +281,21 @@ int pdt_ctc_greedy_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   if (T < 0 || N < 0 || V < 1 || blank_idx < 0 || blank_idx >= V) return PDT_E_ARG;
   if (N == 0) return PDT_OK;
   if ((T > 0 && (!logits || !paths)) || !max_out || !out_lens) return PDT_E_ARG;
-  const size_t per_wave = ((size_t)(T > 0 ? T : 1) * 4 + 15) & ~(size_t)15;
-  if (per_wave * 4 > 160 * 1024) return PDT_E_TOO_LONG;
+  const size_t smem = ((size_t)(T > 0 ? T : 1) * 8 + 15) & ~(size_t)15;  // arg-max + value per frame
+  if (smem > 160 * 1024) return PDT_E_TOO_LONG;
+  if (N > 0x7fffffffll) return PDT_E_TOO_LONG;
   GreedyArgs a{};
   a.logits = logits; a.lg_st = lg_st; a.lg_sn = lg_sn; a.lg_sv = lg_sv;
   a.in_lens = in_lens; a.T = (int)T; a.N = (int)N; a.V = (int)V; a.blank = (int)blank_idx;
   a.is_probs = is_probs; a.max_out = max_out; a.paths = paths; a.pa_st = pa_st; a.pa_sn = pa_sn;
-  a.out_lens = out_lens; a.lds_per_wave = (int)per_wave;
-  const size_t smem = per_wave * 4;
+  a.out_lens = out_lens; a.nw = seq_waves(T);
+  auto kern = V <= 8 * PDT_WAVE ? ctc_greedy_kernel<8> : ctc_greedy_kernel<16>;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_greedy_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(ctc_greedy_kernel, dim3((unsigned)((N + 3) / 4)), dim3(256), smem,
-                     (hipStream_t)stream, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(64 * a.nw), smem, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -209,12 +306,12 @@ int pdt_sequence_log_probs_forward(const float *logits, const int64_t *hyp, int6
   if (A < 0 || S < 0 || B < 0 || V < 1) return PDT_E_ARG;
   if (A * B == 0) return PDT_OK;
   if ((S > 0 && (!logits || !hyp)) || !out) return PDT_E_ARG;
-  if (A * S * B >= (1ll << 31) * 4) return PDT_E_TOO_LONG;
+  if (A * B >= (1ll << 31) || A >= (1ll << 31) || S >= (1ll << 31) || B >= (1ll << 31)) return PDT_E_TOO_LONG;
   SlpArgs a{};
   a.logits = logits; a.hyp = hyp; a.A = (int)A; a.S = (int)S; a.B = (int)B; a.V = (int)V;
-  a.has_eos = has_eos; a.eos = eos; a.out = out;
-  hipLaunchKernelGGL(slp_forward_kernel, dim3((unsigned)((A * B + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  a.has_eos = has_eos; a.eos = eos; a.out = out; a.nw = seq_waves(S);
+  auto kern = V <= 8 * PDT_WAVE ? slp_kernel<false, 8> : slp_kernel<false, 16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(A * B)), dim3(64 * a.nw), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
@@ -225,12 +322,12 @@ int pdt_sequence_log_probs_backward(const float *logits, const int64_t *hyp, int
   if (A < 0 || S < 0 || B < 0 || V < 1) return PDT_E_ARG;
   if (A * S * B == 0) return PDT_OK;
   if (!logits || !hyp || !grad_out || !grad_logits) return PDT_E_ARG;
-  if (A * S * B >= (1ll << 31) * 4) return PDT_E_TOO_LONG;
+  if (A * B >= (1ll << 31) || A >= (1ll << 31) || S >= (1ll << 31) || B >= (1ll << 31)) return PDT_E_TOO_LONG;
   SlpArgs a{};
   a.logits = logits; a.hyp = hyp; a.A = (int)A; a.S = (int)S; a.B = (int)B; a.V = (int)V;
-  a.has_eos = has_eos; a.eos = eos; a.grad_out = grad_out; a.grad_logits = grad_logits;
-  hipLaunchKernelGGL(slp_kernel<true>, dim3((unsigned)((A * S * B + 3) / 4)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  a.has_eos = has_eos; a.eos = eos; a.grad_out = grad_out; a.grad_logits = grad_logits; a.nw = seq_waves(S);
+  auto kern = V <= 8 * PDT_WAVE ? slp_kernel<true, 8> : slp_kernel<true, 16>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(A * B)), dim3(64 * a.nw), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
