@@ -8,7 +8,7 @@
 // reading the logits row once.  Backward: d loss / d logits[v] =
 //     g * (Wsum / |S| * softmax[v] - [v in S] * w_v / |S|),   Wsum = sum_{t in S} w_t,
 // with set membership kept as a V-bit map in LDS.  Both passes are HBM-bound on the logits.
-#include "wave_select.hpp"
+#include "row_reduce.hpp"
 
 namespace pdt {
 
@@ -26,19 +26,33 @@ struct OcdArgs {
   int *status;                // bit 0: a target outside [0, V)
 };
 
-// Visits the tokens of the completion set of row (h, n): f(token) for every set bit.
+// Visits the tokens of the completion set of row (h, n): f(token) for every set bit -- four table
+// look-ups in flight at a time (one at a time each is a round trip to L2 / HBM, and a lane of a
+// 13-token set has several).
 template <typename F>
 __device__ __forceinline__ void for_each_target(const OcdArgs &a, int64_t row, int64_t n, F &&f) {
   const int lane = lane_id();
   unsigned w = lane < a.W ? a.bitmask[row * a.W + lane] : 0u;
+  const int64_t *tab = a.class_tokens + n * (int64_t)a.R + lane * 32;
   while (w) {
-    const int b = __builtin_ctz(w);
-    w &= w - 1u;
-    f(a.class_tokens[n * (int64_t)a.R + lane * 32 + b]);
+    int64_t tok[4];
+    int cnt = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (w) {
+        const int b = __builtin_ctz(w);
+        w &= w - 1u;
+        tok[q] = tab[b];
+        cnt = q + 1;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (q < cnt) f(tok[q]);
   }
 }
 
-template <bool BACKWARD>
+template <bool BACKWARD, int NR>
 __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -48,16 +62,20 @@ __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
   const int64_t h = row / a.N, n = row - h * a.N;
   const int V = a.V;
   const float *x = a.logits + h * a.lg_sh + n * a.lg_sn;
-  // log-sum-exp of the row
-  float mx = -PDT_INF;
-  for (int v = lane; v < V; v += PDT_WAVE) mx = fmaxf(mx, x[(int64_t)v * a.lg_sv]);
-  mx = wave_max_f(mx);
-  float s = 0.0f;
-  for (int v = lane; v < V; v += PDT_WAVE) s += expf(x[(int64_t)v * a.lg_sv] - mx);
-  s = wave_sum_f(s);
-  const float lse = mx + logf(s);
-
-  unsigned *member = reinterpret_cast<unsigned *>(smem) + (size_t)wave * ((V + 31) / 32);
+  // log-sum-exp of the row: read once into registers when it has at most 64 NR elements
+  float r[NR];
+  const RowStats st = row_stats<false, true, NR>(x, a.lg_sv, V, r);
+  const float lse = st.mx + logf(st.sum);
+  // the row again in LDS (rows that fit the registers): x[token] of the targets without a global load
+  const bool staged = V <= NR * PDT_WAVE;
+  float *xl = reinterpret_cast<float *>(smem) + (size_t)wave * (NR * PDT_WAVE);
+  if (staged) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i * PDT_WAVE < V) xl[lane + i * PDT_WAVE] = r[i];
+    wave_sync();
+  }
+  unsigned *member = reinterpret_cast<unsigned *>(smem + (size_t)4 * NR * PDT_WAVE * 4) + (size_t)wave * ((V + 31) / 32);
   if (BACKWARD) {
     for (int i = lane; i < (V + 31) / 32; i += PDT_WAVE) member[i] = 0u;
     wave_sync();
@@ -72,7 +90,7 @@ __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
       return;
     }
     const float w = a.weight ? a.weight[tok] : 1.0f;
-    acc += w * (lse - x[tok * a.lg_sv]);
+    acc += w * (lse - (staged ? xl[tok] : x[tok * a.lg_sv]));
     wsum += w;
     ++cnt;
     if (BACKWARD) atomicOr(&member[tok >> 5], 1u << (tok & 31));
@@ -92,11 +110,17 @@ __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
   wave_sync();
   const float g = a.grad_loss[row] / denom;
   float *go = a.grad_logits + row * (int64_t)V;
-  for (int v = lane; v < V; v += PDT_WAVE) {
-    const float p = expf(x[(int64_t)v * a.lg_sv] - lse);
-    float gv = g * wsum * p;
+  auto grad_of = [&](const int v, const float xv) {
+    float gv = g * wsum * expf(xv - lse);
     if ((member[v >> 5] >> (v & 31)) & 1u) gv -= g * (a.weight ? a.weight[v] : 1.0f);
     go[v] = gv;
+  };
+  if (V <= NR * PDT_WAVE) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i * PDT_WAVE < V && lane + i * PDT_WAVE < V) grad_of(lane + i * PDT_WAVE, r[i]);
+  } else {
+    for (int v = lane; v < V; v += PDT_WAVE) grad_of(v, x[(int64_t)v * a.lg_sv]);
   }
 }
 
@@ -107,13 +131,14 @@ extern "C" {
 static int ocd_launch(pdt::OcdArgs &a, bool backward, void *stream) {
   using namespace pdt;
   const int64_t rows = (int64_t)a.H * a.N;
-  const size_t smem = backward ? (size_t)4 * ((a.V + 31) / 32) * 4 : 0;
+  const bool small = a.V <= 8 * PDT_WAVE;
+  // staged rows of the four waves (64 NR floats each), then the membership maps of the backward pass
+  const size_t smem = (size_t)4 * (small ? 8 : 16) * PDT_WAVE * 4 + (backward ? (size_t)4 * ((a.V + 31) / 32) * 4 : 0);
   if (smem > 64 * 1024) return PDT_E_TOO_LONG;
   const unsigned grid = (unsigned)((rows + 3) / 4);
-  if (backward)
-    hipLaunchKernelGGL(ocd_loss_kernel<true>, dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
-  else
-    hipLaunchKernelGGL(ocd_loss_kernel<false>, dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
+  auto kern = backward ? (small ? ocd_loss_kernel<true, 8> : ocd_loss_kernel<true, 16>)
+                       : (small ? ocd_loss_kernel<false, 8> : ocd_loss_kernel<false, 16>);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), smem, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
