@@ -79,6 +79,39 @@ def test_sequence_log_probs_forward_backward(device):
         assert torch.allclose(ga.cpu().double(), ge, rtol=1e-4, atol=1e-5), it
 
 
+@pytest.mark.parametrize("V", [65, 512, 513, 1024, 1025, 2500])
+def test_sequence_ops_row_forms(device, V):
+    """Rows held in 8 registers per lane (V <= 512), in 16 (<= 1024) and streamed in two passes
+    (beyond); sequences long enough for all 16 waves of a workgroup and for more than 64 steps per
+    wave; eos in the first, a middle and no position."""
+    rng = np.random.default_rng(V)
+    S, N = (1100 if V == 65 else 70), 3
+    lg = rng.normal(size=(S, N, V)).astype(np.float32) * 3
+    hyp = rng.integers(0, V, (S, N))
+    eos = V - 1
+    hyp[hyp == eos] = 0
+    hyp[0, 0] = eos
+    hyp[S // 2, 1] = eos
+    hyp[5, 2] = -1  # masked by value
+    exp = oracle.sequence_log_probs(lg, hyp, 0, eos)
+    x = T(lg, device).requires_grad_(True)
+    act = F.sequence_log_probs(x, T(hyp, device), 0, eos)
+    assert np.allclose(act.detach().cpu().numpy(), exp, rtol=2e-5, atol=1e-4)
+    (ga,) = torch.autograd.grad(act.sum(), x)
+    xc = torch.from_numpy(lg).double().requires_grad_(True)
+    h = torch.from_numpy(hyp)
+    first = torch.where((h == eos).any(0), (h == eos).long().argmax(0), torch.tensor(S)) + 1
+    mask = (h < 0) | (torch.arange(S).unsqueeze(1) >= first.unsqueeze(0))
+    ref = xc.log_softmax(-1).gather(-1, h.masked_fill(mask, 0).unsqueeze(-1)).squeeze(-1).masked_fill(mask, 0.0).sum()
+    (ge,) = torch.autograd.grad(ref, xc)
+    assert torch.allclose(ga.cpu().double(), ge, rtol=1e-4, atol=1e-5)
+    lens = np.array([S, S // 3, 0])
+    e_max, e_paths, e_lens = oracle.ctc_greedy_search(lg, lens, V - 1, False, False)
+    a_max, a_paths, a_lens = F.ctc_greedy_search(T(lg, device), T(lens, device), V - 1)
+    assert np.array_equal(a_lens.cpu().numpy(), e_lens) and np.array_equal(a_paths.cpu().numpy(), e_paths)
+    assert np.allclose(a_max.cpu().numpy(), e_max, rtol=2e-5, atol=1e-3)
+
+
 def test_sequence_log_probs_packed(device):
     rng = np.random.default_rng(4)
     S, N, V = 7, 4, 5
