@@ -435,3 +435,19 @@ def test_lev_workspace_is_optional(device):
     assert torch.equal(outs[0], outs[2]) and torch.equal(outs[1], outs[3])
     exp = oracle.error_rate(ref.cpu().numpy(), hyp.cpu().numpy(), eos=3, include_eos=True, norm=True)
     assert np.array_equal(exp, outs[0].numpy())
+
+
+def test_bitpar_empty_sequences(device):
+    """No hypothesis tokens / no reference tokens at all (zero-length dimensions), one utterance."""
+    rng = np.random.default_rng(9)
+    for R, H, N in ((0, 5, 3), (7, 0, 2), (0, 0, 1), (1, 1, 1), (40, 33, 1)):
+        ref = rng.integers(0, 4, (R, N))
+        hyp = rng.integers(0, 4, (H, N))
+        for name in _BITPAR_OPS:
+            kw = dict(norm=True) if "rate" in name else dict(norm=False)
+            exp = getattr(oracle, name)(ref, hyp, faithful=False, **kw)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                act = getattr(F, name)(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device),
+                                       warn=False, **kw).cpu().numpy()  # fmt: skip
+            _assert_same(exp, act, (name, R, H, N))
