@@ -29,10 +29,10 @@ struct OcdArgs {
 // Visits the tokens of the completion set of row (h, n): f(token) for every set bit -- four table
 // look-ups in flight at a time (one at a time each is a round trip to L2 / HBM, and a lane of a
 // 13-token set has several).
+// `w`: this lane's word of the row's class bitmask (loaded by the caller together with the logits).
 template <typename F>
-__device__ __forceinline__ void for_each_target(const OcdArgs &a, int64_t row, int64_t n, F &&f) {
+__device__ __forceinline__ void for_each_target(const OcdArgs &a, unsigned w, int64_t n, F &&f) {
   const int lane = lane_id();
-  unsigned w = lane < a.W ? a.bitmask[row * a.W + lane] : 0u;
   const int64_t *tab = a.class_tokens + n * (int64_t)a.R + lane * 32;
   while (w) {
     int64_t tok[4];
@@ -62,6 +62,7 @@ __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
   const int64_t h = row / a.N, n = row - h * a.N;
   const int V = a.V;
   const float *x = a.logits + h * a.lg_sh + n * a.lg_sn;
+  const unsigned my_word = lane < a.W ? a.bitmask[row * a.W + lane] : 0u;  // (in flight with the row)
   // log-sum-exp of the row: read once into registers when it has at most 64 NR elements
   float r[NR];
   const RowStats st = row_stats<false, true, NR>(x, a.lg_sv, V, r);
@@ -83,7 +84,7 @@ __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
   float acc = 0.0f, wsum = 0.0f;
   int cnt = 0;
   bool bad = false;
-  for_each_target(a, row, n, [&](int64_t tok) {
+  for_each_target(a, my_word, n, [&](int64_t tok) {
     if (tok == a.ignore_index) return;
     if (tok < 0 || tok >= V) {
       bad = true;
