@@ -136,7 +136,11 @@ __global__ void __launch_bounds__(1024) slp_kernel(const SlpArgs a) {
   const float g = BACKWARD ? a.grad_out[o] : 0.0f;
   float acc = 0.0f;
   // this wave's tokens, 64 steps at a time (lane l: step wave + NW * (j0 + l))
-  for (int j0 = 0; wave + (int64_t)NW * j0 < S; j0 += PDT_WAVE) {
+  // (backward: blockIdx.y selects a block of 64 NW steps -- gradient rows are independent, so long
+  // sequences spread over several workgroups; forward: one workgroup sums all the steps in order)
+  const int j_begin = BACKWARD ? (int)blockIdx.y * PDT_WAVE : 0;
+  const int j_end = BACKWARD ? j_begin + PDT_WAVE : 0x7fffffff;
+  for (int j0 = j_begin; j0 < j_end && wave + (int64_t)NW * j0 < S; j0 += PDT_WAVE) {
     const int s_mine = wave + NW * (j0 + lane);
     const int64_t tok_mine = s_mine < S ? hseq[(int64_t)s_mine * a.B] : -1;
     for (int j = 0; j < PDT_WAVE; ++j) {
@@ -243,7 +247,9 @@ int pdt_sequence_log_probs_backward(const float *logits, const int64_t *hyp, int
   a.logits = logits; a.hyp = hyp; a.A = (int)A; a.S = (int)S; a.B = (int)B; a.V = (int)V;
   a.has_eos = has_eos; a.eos = eos; a.grad_out = grad_out; a.grad_logits = grad_logits; a.nw = seq_waves(S);
   auto kern = V <= 8 * PDT_WAVE ? slp_kernel<true, 8> : slp_kernel<true, 16>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(A * B)), dim3(64 * a.nw), 0, (hipStream_t)stream, a);
+  const unsigned ny = (unsigned)((S + (int64_t)a.nw * PDT_WAVE - 1) / ((int64_t)a.nw * PDT_WAVE));  // blocks of 64 nw steps
+  if (ny > 65535u) return PDT_E_TOO_LONG;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(A * B), ny ? ny : 1u), dim3(64 * a.nw), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
