@@ -49,18 +49,18 @@ __device__ __forceinline__ int find_child(const LmArgs &a, int node, int tok) {
 
 constexpr int kMaxOrder = 16;
 
+// One workgroup per query row: the walk of the row's CONTEXT (its back-off chain) does not depend
+// on the vocabulary entry, so a thread does it once and then takes v = tid, tid + 256, ...
+// (one thread per (row, v) repeated it V times: a third of a trigram model's searches).
 __global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (gid >= a.rows * a.V) return;
-  const int64_t r = gid / a.V;
-  const int v = (int)(gid - r * a.V);
+  const int64_t r = blockIdx.x;
   int64_t pos;
   int b;
   if (a.idx) {
     b = (int)r;
     pos = a.idx[r * a.idx_stride];
     if (pos < 0 || pos > a.S) {
-      if (v == 0) atomicOr(a.status, 1);
+      if (threadIdx.x == 0) atomicOr(a.status, 1);
       pos = pos < 0 ? 0 : a.S;
     }
   } else {
@@ -76,36 +76,40 @@ __global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
     return (tok >= 0 && tok < a.U - 1) ? (int)tok : -1;
   };
   const int N = a.N;
+  int ct[kMaxOrder];  // the context tokens, read once
+  for (int n = 1; n <= N - 1; ++n) ct[n] = ctx(n);
   // back-off chain of the context: bo[n] = log-backoff of the length-n context, 0 once the
   // context is no longer in the trie (:491-497)
   float bo[kMaxOrder];
   {
-    int node = ctx(1);
+    int node = ct[1];
     bo[1] = node >= 0 ? a.logbs[node] : 0.0f;
     for (int n = 2; n <= N - 1; ++n) {
       if (node >= 0) {
-        const int tok = ctx(n);
+        const int tok = ct[n];
         node = tok >= 0 ? find_child(a, node, tok) : -1;
       }
       bo[n] = node >= 0 ? a.logbs[node] : 0.0f;
     }
   }
-  float lp = a.logps[v];
-  float last_b = bo[1];
-  int node = v;
-  for (int n = 1; n <= N - 1; ++n) {
-    if (node >= 0) {
-      const int tok = ctx(n);
-      node = tok >= 0 ? find_child(a, node, tok) : -1;
+  for (int v = (int)threadIdx.x; v < a.V; v += 256) {
+    float lp = a.logps[v];
+    float last_b = bo[1];
+    int node = v;
+    for (int n = 1; n <= N - 1; ++n) {
+      if (node >= 0) {
+        const int tok = ct[n];
+        node = tok >= 0 ? find_child(a, node, tok) : -1;
+      }
+      const float cur_b = n == N - 1 ? 0.0f : bo[n + 1];
+      const float lpd = node >= 0 ? a.logps[node] : 0.0f;
+      // an infinite entry marks a node that only exists for its children (:499-503)
+      const bool clobber = node >= 0 && isfinite(lpd);
+      lp = clobber ? lpd : (lp + cur_b) + last_b;
+      last_b = clobber ? cur_b : 0.0f;
     }
-    const float cur_b = n == N - 1 ? 0.0f : bo[n + 1];
-    const float lpd = node >= 0 ? a.logps[node] : 0.0f;
-    // an infinite entry marks a node that only exists for its children (:499-503)
-    const bool clobber = node >= 0 && isfinite(lpd);
-    lp = clobber ? lpd : (lp + cur_b) + last_b;
-    last_b = clobber ? cur_b : 0.0f;
+    a.out[r * a.V + v] = lp;
   }
-  a.out[gid] = lp;
 }
 
 }  // namespace pdt
@@ -132,9 +136,8 @@ int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h
   a.logps = logps; a.logbs = logbs; a.child_start = child_start; a.ids = ids;
   a.V = (int)V; a.N = (int)N; a.U = (int)U; a.shift = (int)(U - V - 1); a.sos = sos;
   a.out = out; a.status = status;
-  const int64_t total = rows * V;
-  hipLaunchKernelGGL(lm_lookup_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, a);
+  if (rows >= (1ll << 31)) return PDT_E_TOO_LONG;
+  hipLaunchKernelGGL(lm_lookup_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
