@@ -320,11 +320,17 @@ int pdt_sparse_image_warp_backward(const float *grad_out, const float *train_poi
  * element b at position t -- calc_full_log_probs (:793-848).  Positions before the start of
  * the history read sos (:452-461).  out (rows, V) float32: log P(v | the N - 1 tokens before
  * the position).  status bit 0: a position outside [0, S] (clamped).
+ *
+ * succ_start [U + 1], succ_tok [E], succ_node [E] int32 (all three or NULL): a forward index of
+ * the trie's second level, derived from the buffers above -- for a context token c, entries
+ * succ_start[c] .. succ_start[c + 1] list the last tokens v (ascending) and nodes of the bigrams
+ * "c v".  With it a row searches the children of the listed successors only (same results).
  * ------------------------------------------------------------------------------------- */
 int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h_ss, int64_t h_sb,
                             const int64_t *idx, int64_t idx_stride, int64_t rows,
                             const float *logps, const float *logbs, const int32_t *child_start,
-                            const int32_t *ids, int64_t V, int64_t N, int64_t U, int64_t sos,
+                            const int32_t *ids, const int32_t *succ_start, const int32_t *succ_tok,
+                            const int32_t *succ_node, int64_t V, int64_t N, int64_t U, int64_t sos,
                             float *out, int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------------------------------

@@ -7,8 +7,11 @@
 // children of every node.  Here one thread owns one (row, v) pair and keeps the walk in
 // registers: a binary search among the node's children per order (children are sorted by id,
 // invariant 3 at :628), the back-off chain of the row's context is walked alongside.  The only
-// HBM traffic that scales is the dense (rows, V) float32 result -- the kernel is bound by that
-// store stream; the trie tables (a few MB) stay in L2 / MALL.
+// HBM traffic that scales is the dense (rows, V) float32 result; the trie tables (a few MB) stay
+// in L2 / MALL.  With the forward index (LmArgs::succ_*, built by the host from the same buffers)
+// a row no longer searches the children of EVERY vocabulary entry for its last context token: all
+// entries get the no-match value (two adds), and only the successors the model lists for that
+// token -- a hundredth of the vocabulary, typically -- walk on from their known node.
 //
 // Arithmetic is the reference's, in the reference's order (float32,
 // (last_logp + cur_backoff) + last_backoff, :504-506), so results are bit-identical.
@@ -29,6 +32,9 @@ struct LmArgs {
   const float *logps, *logbs;
   const int *child_start;  // [O] absolute index of a node's first child; end = child_start[i + 1]
   const int *ids;          // labels of nodes >= U, indexed node - U
+  // forward index of the second level (optional): for a context token c the (last token v, node)
+  // pairs of the bigrams "c v" the model holds, v ascending: entries succ_start[c] .. succ_start[c + 1]
+  const int *succ_start, *succ_tok, *succ_node;
   int V, N, U, shift;
   int64_t sos;
   float *out;           // (rows, V)
@@ -92,11 +98,9 @@ __global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
       bo[n] = node >= 0 ? a.logbs[node] : 0.0f;
     }
   }
-  for (int v = (int)threadIdx.x; v < a.V; v += 256) {
-    float lp = a.logps[v];
-    float last_b = bo[1];
-    int node = v;
-    for (int n = 1; n <= N - 1; ++n) {
+  // the walk of one vocabulary entry from order n0 on, given its node at order n0 - 1
+  auto walk = [&](float lp, float last_b, int node, const int n0) {
+    for (int n = n0; n <= N - 1; ++n) {
       if (node >= 0) {
         const int tok = ct[n];
         node = tok >= 0 ? find_child(a, node, tok) : -1;
@@ -108,7 +112,28 @@ __global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
       lp = clobber ? lpd : (lp + cur_b) + last_b;
       last_b = clobber ? cur_b : 0.0f;
     }
-    a.out[r * a.V + v] = lp;
+    return lp;
+  };
+  if (!a.succ_start) {
+    for (int v = (int)threadIdx.x; v < a.V; v += 256) a.out[r * a.V + v] = walk(a.logps[v], bo[1], v, 1);
+    return;
+  }
+  // every entry as if no bigram "c1 v" existed (node = -1 from the first order on) ...
+  for (int v = (int)threadIdx.x; v < a.V; v += 256) a.out[r * a.V + v] = walk(a.logps[v], bo[1], -1, 1);
+  __syncthreads();  // (a workgroup's own global writes are visible to it after the barrier)
+  // ... then the listed successors of c1 again, from their bigram node
+  const int c1 = ct[1];
+  if (c1 < 0) return;
+  for (int e = a.succ_start[c1] + (int)threadIdx.x; e < a.succ_start[c1 + 1]; e += 256) {
+    const int v = a.succ_tok[e];
+    if (v >= a.V) continue;
+    const int node = a.succ_node[e];
+    // order 1 with the node known, then orders 2 .. N - 1 as usual
+    const float cur_b = 1 == N - 1 ? 0.0f : bo[2];
+    const float lpd = a.logps[node];
+    const bool clobber = isfinite(lpd);
+    const float lp = clobber ? lpd : (a.logps[v] + cur_b) + bo[1];
+    a.out[r * a.V + v] = walk(lp, clobber ? cur_b : 0.0f, node, 2);
   }
 }
 
@@ -119,7 +144,8 @@ extern "C" {
 int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h_ss, int64_t h_sb,
                             const int64_t *idx, int64_t idx_stride, int64_t rows,
                             const float *logps, const float *logbs, const int32_t *child_start,
-                            const int32_t *ids, int64_t V, int64_t N, int64_t U, int64_t sos,
+                            const int32_t *ids, const int32_t *succ_start, const int32_t *succ_tok,
+                            const int32_t *succ_node, int64_t V, int64_t N, int64_t U, int64_t sos,
                             float *out, int32_t *status, void *stream) {
   using namespace pdt;
   if (S < 0 || B < 0 || rows < 0 || V < 1 || N < 2 || U < V + 1 || U > V + 2) return PDT_E_ARG;
@@ -134,6 +160,9 @@ int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h
   a.hist = hist; a.h_ss = h_ss; a.h_sb = h_sb; a.idx = idx; a.idx_stride = idx_stride;
   a.S = (int)S; a.B = (int)B; a.rows = rows;
   a.logps = logps; a.logbs = logbs; a.child_start = child_start; a.ids = ids;
+  if (succ_start && succ_tok && succ_node) {
+    a.succ_start = succ_start; a.succ_tok = succ_tok; a.succ_node = succ_node;
+  }
   a.V = (int)V; a.N = (int)N; a.U = (int)U; a.shift = (int)(U - V - 1); a.sos = sos;
   a.out = out; a.status = status;
   if (rows >= (1ll << 31)) return PDT_E_TOO_LONG;

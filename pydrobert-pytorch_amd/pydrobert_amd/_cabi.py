@@ -95,7 +95,7 @@ SIGNATURES = {
     ),
     "pdt_lookup_lm_log_probs": (
         _INT,
-        [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
+        [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
     ),
     "pdt_pad_variable": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _INT, _P, _I64, _P, _P]),
     "pdt_pad_variable_backward": (_INT, [_P, _I64, _I64, _I64, _P, _P, _INT, _I64, _P, _P]),

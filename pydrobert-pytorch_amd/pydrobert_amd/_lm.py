@@ -286,6 +286,9 @@ def _lookup_lm_log_probs_op(
     logbs: torch.Tensor,
     child_start: torch.Tensor,
     ids: torch.Tensor,
+    succ_start: torch.Tensor,
+    succ_tok: torch.Tensor,
+    succ_node: torch.Tensor,
     vocab_size: int,
     max_ngram: int,
     sos: int,
@@ -296,7 +299,7 @@ def _lookup_lm_log_probs_op(
         raise RuntimeError("hist must be 2 dimensional")
     S, B = hist.shape
     V, N = vocab_size, max_ngram
-    device = _cabi.require_hip(hist, idx, logps, logbs, child_start, ids)
+    device = _cabi.require_hip(hist, idx, logps, logbs, child_start, ids, succ_start, succ_tok, succ_node)
     rows = B if idx is not None else (S + 1) * B
     if idx is not None:
         if idx.numel() == 0:
@@ -308,6 +311,7 @@ def _lookup_lm_log_probs_op(
     if h.dtype != torch.long:
         h = h.long()
     shift = 0 if (0 <= sos < V) else 1
+    have_index = succ_start.numel() == V + shift + 2  # (U + 1 entries; empty: search every entry)
     with torch.cuda.device(device):
         out = torch.empty((rows, V), device=device, dtype=torch.float)
         status = torch.zeros(1, device=device, dtype=torch.int32)
@@ -315,14 +319,15 @@ def _lookup_lm_log_probs_op(
             _cabi.ptr(h) if S and B else None, S, B, h.stride(0), h.stride(1),
             _cabi.ptr(idx), 0 if (idx is None or idx.numel() == 1) else 1, rows,
             _cabi.ptr(logps), _cabi.ptr(logbs), _cabi.ptr(child_start), _cabi.ptr(ids),
-            V, N, V + shift + 1, sos, _cabi.ptr(out), _cabi.ptr(status), _cabi.stream_ptr(device),
+            _cabi.ptr(succ_start) if have_index else None, _cabi.ptr(succ_tok) if have_index else None,
+            _cabi.ptr(succ_node) if have_index else None, V, N, V + shift + 1, sos, _cabi.ptr(out), _cabi.ptr(status), _cabi.stream_ptr(device),
         )  # fmt: skip
     _cabi.check(rc, "pdt_lookup_lm_log_probs")
     return out
 
 
 @_lookup_lm_log_probs_op.register_fake
-def _(hist, idx, logps, logbs, child_start, ids, vocab_size, max_ngram, sos):
+def _(hist, idx, logps, logbs, child_start, ids, succ_start, succ_tok, succ_node, vocab_size, max_ngram, sos):
     S, B = hist.shape
     return logps.new_empty((B if idx is not None else (S + 1) * B, vocab_size))
 
@@ -369,6 +374,9 @@ class LookupLanguageModel(MixableSequentialLanguageModel):
         self.register_buffer("offsets", offsets)
         self.register_buffer("child_start", torch.empty(0, dtype=torch.int32), persistent=False)
         self.register_buffer("ids_wide", torch.empty(0, dtype=torch.int32), persistent=False)
+        self.register_buffer("succ_start", torch.empty(0, dtype=torch.int32), persistent=False)
+        self.register_buffer("succ_tok", torch.empty(0, dtype=torch.int32), persistent=False)
+        self.register_buffer("succ_node", torch.empty(0, dtype=torch.int32), persistent=False)
         self._widen()
 
     @torch.jit.unused
@@ -377,6 +385,22 @@ class LookupLanguageModel(MixableSequentialLanguageModel):
         dev = self.offsets.device
         self.child_start = self.offsets.to(torch.int32) + torch.arange(O, device=dev, dtype=torch.int32)
         self.ids_wide = self.ids.to(torch.int32)
+        # forward index of the second level: the bigram nodes (children of the unigram nodes
+        # 0 .. U - 2) grouped by their label -- the context token -- with the unigram they hang
+        # under, i.e. the LAST token of the bigram, ascending inside a group
+        U = self.vocab_size + self.shift + 1
+        if self.max_ngram >= 2 and O >= U:
+            cs = self.child_start[:U].long()
+            counts = cs[1:] - cs[:-1]
+            nodes = torch.arange(int(cs[0]), int(cs[-1]), device=dev)
+            last_tok = torch.repeat_interleave(torch.arange(U - 1, device=dev), counts)
+            label = self.ids_wide[nodes - U].long()
+            order = torch.sort(label, stable=True)[1]
+            start = torch.zeros(U + 1, dtype=torch.long, device=dev)
+            start[1:] = torch.bincount(label, minlength=U)[:U].cumsum(0)
+            self.succ_start = start.to(torch.int32)
+            self.succ_tok = last_tok[order].to(torch.int32)
+            self.succ_node = nodes[order].to(torch.int32)
 
     def extra_repr(self) -> str:
         return super().extra_repr() + ", max_ngram={}, sos={}".format(self.max_ngram, self.sos)
@@ -416,8 +440,8 @@ class LookupLanguageModel(MixableSequentialLanguageModel):
             rows = hist.size(1) if idx is not None else (hist.size(0) + 1) * hist.size(1)
             return self.logps[:V].expand(rows, V)
         return torch.ops.pydrobert_amd.lookup_lm_log_probs(
-            hist, idx, self.logps, self.logbs, self.child_start, self.ids_wide, V, self.max_ngram,
-            self.sos,
+            hist, idx, self.logps, self.logbs, self.child_start, self.ids_wide, self.succ_start,
+            self.succ_tok, self.succ_node, V, self.max_ngram, self.sos,
         )  # fmt: skip
 
     @torch.jit.export

@@ -83,9 +83,9 @@ def test_abi_version_and_arg_validation_without_gpu(lib):
     assert lib.pdt_pad_variable(0, 2, 4, 3, 3, 0, 0, 0, 0, 6, 0, 0) == _cabi.PDT_E_ARG  # null pointers
     assert lib.pdt_pad_variable(0, 2, 4, 3, 4, 0, 0, 9, 0, 6, 0, 0) == _cabi.PDT_E_ARG  # bad mode
     assert lib.pdt_pad_variable_backward(0, 0, 4, 3, 0, 0, 1, 6, 0, 0) == _cabi.PDT_OK
-    assert lib.pdt_lookup_lm_log_probs(0, 3, 2, 2, 1, 0, 0, 0, 0, 0, 0, 0, 10, 3, 11, 0, 0, 0, 0) == _cabi.PDT_OK  # rows == 0
-    assert lib.pdt_lookup_lm_log_probs(0, 3, 2, 2, 1, 0, 0, 2, 0, 0, 0, 0, 10, 1, 11, 0, 0, 0, 0) == _cabi.PDT_E_ARG  # order < 2
-    assert lib.pdt_lookup_lm_log_probs(0, 3, 2, 2, 1, 0, 0, 2, 0, 0, 0, 0, 10, 40, 11, 0, 0, 0, 0) == _cabi.PDT_E_TOO_LONG
+    assert lib.pdt_lookup_lm_log_probs(0, 3, 2, 2, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 10, 3, 11, 0, 0, 0, 0) == _cabi.PDT_OK  # rows == 0
+    assert lib.pdt_lookup_lm_log_probs(0, 3, 2, 2, 1, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 10, 1, 11, 0, 0, 0, 0) == _cabi.PDT_E_ARG  # order < 2
+    assert lib.pdt_lookup_lm_log_probs(0, 3, 2, 2, 1, 0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 10, 40, 11, 0, 0, 0, 0) == _cabi.PDT_E_TOO_LONG
     assert lib.pdt_spec_augment_apply_backward(0, 0, 5, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0) == _cabi.PDT_OK
     assert lib.pdt_dense_image_warp_backward(0, 0, 1, 1, 4, 4, 0, 0, 0, 0, 0) == _cabi.PDT_E_ARG
     del z
