@@ -66,8 +66,9 @@ static int fill_common(LevArgs &a, const int64_t *ref, int64_t R, int64_t ref_st
 
 extern "C" {
 
-// 2: pdt_ctc_prefix_search_workspace_bytes takes V; 3: pdt_lev takes a workspace
-int pdt_amd_abi_version(void) { return 3; }
+// 2: pdt_ctc_prefix_search_workspace_bytes takes V; 3: pdt_lev takes a workspace;
+// 4: pdt_lookup_lm_log_probs takes the forward index of the trie's second level
+int pdt_amd_abi_version(void) { return 4; }
 
 int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {
   if (R < 0 || H < 0 || N <= 0 || !pdt::bitpar_enabled()) return 0;
