@@ -334,6 +334,19 @@ int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h
                             float *out, int32_t *status, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Extension probabilities of one frame of CTCPrefixSearch with a language model (reference
+ * _decoding.py:1110-1135), fused into one pass over the LM scores:
+ *   lm_log_probs (N, Kp, V) float32 contiguous (unnormalised scores, as the LM returns them),
+ *   nonext (N, V) / blank (N,) the frame's CTC probabilities through element strides;
+ *   valid_mixture == 0: out = nonext * exp(beta * log_softmax(lm_log_probs))        (shallow fusion)
+ *   valid_mixture != 0: out = (1 - beta) * nonext + beta * softmax(lm_log_probs) * (1 - blank)
+ *   out (N, Kp, V) float32 contiguous.  No gradient (the differentiable path composes torch ops).
+ * ------------------------------------------------------------------------------------- */
+int pdt_fusion_ext(const float *lm_log_probs, int64_t N, int64_t Kp, int64_t V, const float *nonext,
+                   int64_t ne_sn, int64_t ne_sv, const float *blank, int64_t bl_sn, float beta,
+                   int valid_mixture, float *out, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * Variable-length padding (reference _pad.py:108-149), the data movement of RandomShift
  * (_img.py:883-908).  x (N, T, F) contiguous, elements of elem_bytes in {1, 2, 4, 8} moved as
  * opaque words; lens (N,), pad (2, N) int64; out (N, Tp, F) with Tp >= max(lens + pad sums):

@@ -97,6 +97,7 @@ SIGNATURES = {
         _INT,
         [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],
     ),
+    "pdt_fusion_ext": (_INT, [_P, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _F, _INT, _P, _P]),
     "pdt_pad_variable": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P, _INT, _P, _I64, _P, _P]),
     "pdt_pad_variable_backward": (_INT, [_P, _I64, _I64, _I64, _P, _P, _INT, _I64, _P, _P]),
     "pdt_ctc_prefix_search_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),

@@ -443,6 +443,37 @@ def ctc_prefix_search(
     return CTCPrefixSearch(width)(logits, lens)
 
 
+@custom_op("pydrobert_amd::fusion_ext", mutates_args=())
+def _fusion_ext_op(
+    lm_log_probs: torch.Tensor, nonext: torch.Tensor, blank: torch.Tensor, beta: float, valid_mixture: bool
+) -> torch.Tensor:
+    """Extension probabilities ``(N, K', V)`` of one frame from the LM scores ``(N * K', V)`` and
+    the frame's CTC probabilities, in one pass (``csrc/fusion_ext.hip``; reference
+    _decoding.py:1110-1135).  No gradient: ``CTCPrefixSearch`` composes torch ops instead when
+    one is wanted."""
+    N, V = nonext.shape
+    if lm_log_probs.dim() != 2 or lm_log_probs.size(1) != V or (N and lm_log_probs.size(0) % N):
+        raise RuntimeError("lm_log_probs must be of shape (N * K', V)")
+    Kp = lm_log_probs.size(0) // N if N else 1
+    device = _cabi.require_hip(lm_log_probs, nonext, blank)
+    lm, ne, bl = _f32(lm_log_probs).contiguous(), _f32(nonext), _f32(blank)
+    with torch.cuda.device(device):
+        out = torch.empty((N, Kp, V), device=device, dtype=torch.float)
+        if N and V:
+            rc = _cabi.lib().pdt_fusion_ext(
+                _cabi.ptr(lm), N, Kp, V, _cabi.ptr(ne), ne.stride(0), ne.stride(1), _cabi.ptr(bl),
+                bl.stride(0), float(beta), int(valid_mixture), _cabi.ptr(out), _cabi.stream_ptr(device),
+            )  # fmt: skip
+            _cabi.check(rc, "pdt_fusion_ext")
+    return out.to(nonext.dtype)
+
+
+@_fusion_ext_op.register_fake
+def _(lm_log_probs, nonext, blank, beta, valid_mixture):
+    N, V = nonext.shape
+    return nonext.new_empty((N, lm_log_probs.shape[0] // max(N, 1), V))
+
+
 class CTCPrefixSearch(torch.nn.Module):
     """Beam search over CTC prefixes, optionally with shallow fusion (reference
     _decoding.py:937-1204).
@@ -537,6 +568,10 @@ class CTCPrefixSearch(torch.nn.Module):
             if fuse:
                 state = self.lm.update_input(state, y)
         Kp = 1
+        # row of batch element n's first prefix in the flattened (N * K') LM state, before and after
+        # the beam has its full width
+        first_rows = torch.arange(0, N, 1, device=device).unsqueeze(1)
+        beam_rows = torch.arange(0, W * N, W, device=device).unsqueeze(1)
         for t in range(n_frames):
             nonext_t, blank_t = probs[t, :, :V], probs[t, :, V]
             ext_t = nonext_t.unsqueeze(1).expand(N, Kp, V)
@@ -544,7 +579,12 @@ class CTCPrefixSearch(torch.nn.Module):
             if self.lm is not None:
                 if fuse:
                     lm_lp, state_next = self.lm.calc_idx_log_probs(y.flatten(1), state, y_lens.flatten())
-                    if self.valid_mixture:  # convex combination that still sums to 1 - blank (:1120-1128)
+                    if not (torch.is_grad_enabled() and (lm_lp.requires_grad or probs.requires_grad)):
+                        # one pass over the LM scores instead of four (csrc/fusion_ext.hip)
+                        ext_t = torch.ops.pydrobert_amd.fusion_ext(
+                            lm_lp.reshape(N * Kp, V), nonext_t, blank_t, self.beta, self.valid_mixture
+                        )
+                    elif self.valid_mixture:  # convex combination that still sums to 1 - blank (:1120-1128)
                         lm_p = lm_lp.softmax(-1).view(N, Kp, V) * (1 - blank_t.view(N, 1, 1))
                         ext_t = (1.0 - self.beta) * ext_t + self.beta * lm_p
                     else:  # shallow fusion: p_ctc * p_lm ** beta (:1130-1135)
@@ -555,7 +595,7 @@ class CTCPrefixSearch(torch.nn.Module):
             nb_new, b_new = masses
             if self.lm is not None:
                 if fuse:
-                    rows = (src + torch.arange(0, Kp * N, Kp, device=device).unsqueeze(1)).flatten()
+                    rows = (src + (first_rows if Kp == 1 else beam_rows)).flatten()
                     state = self.lm.mix_by_mask(
                         self.lm.extract_by_src(state, rows), self.lm.extract_by_src(state_next, rows), kept.flatten()
                     )  # :1154-1163
