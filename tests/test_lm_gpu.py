@@ -187,3 +187,23 @@ def test_scripted_lookup_lm():
     exp, act = search(logits), torch.jit.script(search)(logits)
     for a, b in zip(exp, act):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("V", [7, 512, 513, 1024, 1500])
+def test_fusion_ext_matches_the_torch_composition(V):
+    """pdt_fusion_ext against the expressions CTCPrefixSearch composes when a gradient is wanted
+    (reference _decoding.py:1120-1135): rows in 8 / 16 registers per lane and streamed rows, a
+    strided view of the frame's probabilities."""
+    g = torch.Generator(device=DEV).manual_seed(V)
+    N, Kp = 5, 3
+    probs = torch.randn((N, V + 1), device=DEV, generator=g).softmax(1)
+    nonext, blank = probs[:, :V], probs[:, V]
+    lm_lp = torch.randn((N * Kp, V), device=DEV, generator=g) * 4
+    beta = 0.37
+    ext = nonext.unsqueeze(1).expand(N, Kp, V)
+    exp_shallow = ext * (beta * lm_lp.log_softmax(-1)).exp().view(N, Kp, V)
+    exp_mix = (1.0 - beta) * ext + beta * (lm_lp.softmax(-1).view(N, Kp, V) * (1 - blank.view(N, 1, 1)))
+    act_shallow = torch.ops.pydrobert_amd.fusion_ext(lm_lp, nonext, blank, beta, False)
+    act_mix = torch.ops.pydrobert_amd.fusion_ext(lm_lp, nonext, blank, beta, True)
+    assert torch.allclose(act_shallow, exp_shallow, rtol=2e-5, atol=1e-12)
+    assert torch.allclose(act_mix, exp_mix, rtol=2e-5, atol=1e-12)
