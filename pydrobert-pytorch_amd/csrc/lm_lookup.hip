@@ -56,9 +56,13 @@ __device__ __forceinline__ int find_child(const LmArgs &a, int node, int tok) {
 constexpr int kMaxOrder = 16;
 
 // One workgroup per query row: the walk of the row's CONTEXT (its back-off chain) does not depend
-// on the vocabulary entry, so a thread does it once and then takes v = tid, tid + 256, ...
+// on the vocabulary entry, so a thread does it once and then takes v = tid, tid + 128, ...
 // (one thread per (row, v) repeated it V times: a third of a trigram model's searches).
-__global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
+#ifndef PDT_LM_THREADS
+#define PDT_LM_THREADS 128  // (more rows per CU at once: a row's context walk is a chain of ~10 loads)
+#endif
+constexpr int kLmThreads = PDT_LM_THREADS;
+__global__ void __launch_bounds__(kLmThreads) lm_lookup_kernel(const LmArgs a) {
   const int64_t r = blockIdx.x;
   int64_t pos;
   int b;
@@ -115,16 +119,23 @@ __global__ void __launch_bounds__(256) lm_lookup_kernel(const LmArgs a) {
     return lp;
   };
   if (!a.succ_start) {
-    for (int v = (int)threadIdx.x; v < a.V; v += 256) a.out[r * a.V + v] = walk(a.logps[v], bo[1], v, 1);
+    for (int v = (int)threadIdx.x; v < a.V; v += kLmThreads) a.out[r * a.V + v] = walk(a.logps[v], bo[1], v, 1);
     return;
   }
   // every entry as if no bigram "c1 v" existed (node = -1 from the first order on) ...
-  for (int v = (int)threadIdx.x; v < a.V; v += 256) a.out[r * a.V + v] = walk(a.logps[v], bo[1], -1, 1);
+  for (int v0 = (int)threadIdx.x; v0 < a.V; v0 += 4 * kLmThreads) {  // (four loads in flight)
+    float lp[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lp[q] = v0 + q * kLmThreads < a.V ? a.logps[v0 + q * kLmThreads] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (v0 + q * kLmThreads < a.V) a.out[r * a.V + v0 + q * kLmThreads] = walk(lp[q], bo[1], -1, 1);
+  }
   __syncthreads();  // (a workgroup's own global writes are visible to it after the barrier)
   // ... then the listed successors of c1 again, from their bigram node
   const int c1 = ct[1];
   if (c1 < 0) return;
-  for (int e = a.succ_start[c1] + (int)threadIdx.x; e < a.succ_start[c1 + 1]; e += 256) {
+  for (int e = a.succ_start[c1] + (int)threadIdx.x; e < a.succ_start[c1 + 1]; e += kLmThreads) {
     const int v = a.succ_tok[e];
     if (v >= a.V) continue;
     const int node = a.succ_node[e];
@@ -166,7 +177,7 @@ int pdt_lookup_lm_log_probs(const int64_t *hist, int64_t S, int64_t B, int64_t h
   a.V = (int)V; a.N = (int)N; a.U = (int)U; a.shift = (int)(U - V - 1); a.sos = sos;
   a.out = out; a.status = status;
   if (rows >= (1ll << 31)) return PDT_E_TOO_LONG;
-  hipLaunchKernelGGL(lm_lookup_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(lm_lookup_kernel, dim3((unsigned)rows), dim3(kLmThreads), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 
