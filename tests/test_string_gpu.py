@@ -451,3 +451,18 @@ def test_bitpar_empty_sequences(device):
                 act = getattr(F, name)(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device),
                                        warn=False, **kw).cpu().numpy()  # fmt: skip
             _assert_same(exp, act, (name, R, H, N))
+
+
+@pytest.mark.parametrize("R", [10000, 20000])
+def test_bitpar_long_reference_short_hypothesis(device, R):
+    """A reference far longer than the hypothesis: its look-up pairs fill most of a CU's LDS
+    (R = 10 000: one utterance per wave) or do not fit (R = 20 000: the cell-by-cell kernel)."""
+    rng = np.random.default_rng(R)
+    N, H, V = 3, 50, 6
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    ref[R // 2, 1] = V  # one reference ends half way
+    for name in ("error_rate", "prefix_edit_distances"):
+        exp = getattr(oracle, name)(ref, hyp, eos=V, faithful=False)
+        act = getattr(F, name)(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device), eos=V, warn=False)
+        _assert_same(exp, act.cpu().numpy(), (name, R))
