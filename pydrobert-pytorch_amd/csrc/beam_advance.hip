@@ -27,7 +27,7 @@ struct CtcAdvArgs {
   float *nb_next, *b_next;                        // (N, W)
   uint8_t *next_isp;                              // (N, W, W)
   uint8_t *next_nonext;                           // (N, W)
-  int lds_per_wave, waves_per_wg;
+  int frame_bytes, waves_per_wg;  // LDS of the frame routine (the per-wave survivor scratch follows it)
 };
 
 // One WORKGROUP per batch element (a.waves_per_wg waves).  The Kp per-prefix selections over the
@@ -44,7 +44,7 @@ __global__ void __launch_bounds__(512) ctc_advance_kernel(const CtcAdvArgs a) {
   FrameLds L;
   L.carve(smem + (size_t)((V + 1 + 3) & ~3) * 4, V, W, Kp, true);
   int *srcs = reinterpret_cast<int *>(L.surv);  // reused after the frame
-  u64 *my_surv = reinterpret_cast<u64 *>(smem + a.lds_per_wave) + (size_t)wave * PDT_SURV_CAP;
+  u64 *my_surv = reinterpret_cast<u64 *>(smem + a.frame_bytes) + (size_t)wave * PDT_SURV_CAP;
 
   const int M = ctc_list_len(V, W, Kp);
   for (int k = wave; k < Kp; k += NW) {
@@ -129,7 +129,7 @@ int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
   const size_t smem = frame + (size_t)nw * PDT_SURV_CAP * 8;  // + one survivor scratch per wave
   if (smem > 160 * 1024) return PDT_E_TOO_LONG;
   a.waves_per_wg = nw;
-  a.lds_per_wave = (int)frame;
+  a.frame_bytes = (int)frame;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_advance_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -149,7 +149,7 @@ struct BeamAdvArgs {
   int64_t *y_next;      // (S_out, N, W)
   int64_t *y_next_lens, *next_src;  // (N, W)
   float *lp_next;                   // (N, W)
-  int lds_per_wave, waves_per_wg;
+  int waves_per_wg;
 };
 
 // One WORKGROUP per batch element (a.waves_per_wg waves): the Kp selections are independent and
@@ -244,7 +244,6 @@ int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   const size_t smem = ((size_t)nw * PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 8 + (size_t)a.W * 12 + 15) & ~(size_t)15;
   a.waves_per_wg = nw;
-  a.lds_per_wave = 0;
   hipLaunchKernelGGL(beam_advance_kernel, dim3((unsigned)a.N), dim3(64 * nw), smem, stream, a);
   return (int)hipGetLastError();
 }

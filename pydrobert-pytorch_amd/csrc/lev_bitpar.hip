@@ -47,7 +47,6 @@ struct BitparArgs {
   int32_t *status;
   int X, Y;      // capacities of the bit-vector sequence and of the consumed sequence
   int lgL, upw;  // lanes per utterance = 1 << lgL; utterances per wave (<= 64 >> lgL)
-  int P;         // sort capacity: power of two >= X
   int32_t *lens;   // [N][2]     ref_len, hyp_len
   uint2 *yh;       // [N][Y]     (block presence, offset) of the class of Y[j]; (0, 0) = no match
   uint32_t *msk;   // [N][X + 1] packed match-mask words
@@ -63,9 +62,6 @@ BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N) {
   int lgL = 0;
   while ((32 << lgL) < X) ++lgL;
   p.lgL = lgL;
-  int P = 2;
-  while (P < X) P <<= 1;
-  p.P = P;
   const size_t Xs = (size_t)(X > 0 ? X : 1), Ys = (size_t)(Y > 0 ? Y : 1);
   // classify: [(presence, offset) per class X * 8] [tokens (X + 1) * 8 (later: the mask words)]
   //           [classes of Y, 2 bytes each]
@@ -379,7 +375,7 @@ int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStrea
   a.ref_lens_out = la.ref_lens_out; a.hyp_lens_out = la.hyp_lens_out; a.status = la.status;
   a.X = la.H;
   a.Y = la.R;
-  a.lgL = p.lgL; a.upw = p.upw; a.P = p.P;
+  a.lgL = p.lgL; a.upw = p.upw;
   unsigned char *w = reinterpret_cast<unsigned char *>(ws);
   a.lens = reinterpret_cast<int32_t *>(w + p.off_lens);
   a.yh = reinterpret_cast<uint2 *>(w + p.off_yh);

@@ -30,7 +30,7 @@ struct LevArgs {
 // utterances per wave, LDS slices and the offsets of the workspace pieces.  ok = 0: the shape is
 // not served (bit-vector sequence longer than 1024 tokens, or lookups that do not fit the LDS).
 struct BitparPlan {
-  int ok, lgL, upw, P;
+  int ok, lgL, upw;
   size_t lds_classify, lds_sub;  // bytes: per wave / per utterance
   size_t off_lens, off_yh, off_msk, total;  // workspace
 };
