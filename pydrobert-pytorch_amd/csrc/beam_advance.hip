@@ -1,11 +1,11 @@
-// Step functions of the two beam searches for gfx950, one wave per batch element:
+// Step functions of the two beam searches for gfx950, one workgroup per batch element:
 //   * pdt_ctc_prefix_search_advance -- ctc_prefix_search_advance (reference
 //     _decoding.py:636-934) with arbitrary per-prefix extension probabilities (language-model
 //     fusion) and dense (S, N, K') histories, as the reference's signature requires;
 //   * pdt_beam_search_advance       -- beam_search_advance (_decoding.py:41-155).
 // Both select the top-K of K'*V (+K') candidates WITHOUT materialising them: each old prefix
-// gets the sorted list of its best tokens (wave_top_sorted), then K rounds of a wave-wide
-// max-reduce over the list heads pick the winners in order.  Ties go to the lowest flat
+// gets the sorted list of its best tokens (wave_top_sorted; the waves of the workgroup share the
+// prefixes), then K rounds of a wave-wide max-reduce over the list heads pick the winners in order.  Ties go to the lowest flat
 // candidate index (the reference's torch.topk leaves them unspecified).
 #include "ctc_frame.hpp"
 
