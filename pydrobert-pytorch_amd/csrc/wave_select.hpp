@@ -324,6 +324,49 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
   }
   return cur;
 }
+// The same selection for a row in global memory of at most 64 * NR elements, read ONCE: the row
+// stays in registers (all loads in flight) between the per-lane maxima and the survivor pass.
+// Longer rows fall through to wave_top_sorted_strided<LONG>.
+template <int NR, bool BIAS = false>
+__device__ __forceinline__ u64 wave_top_sorted_regs(const float *xb, const int64_t sx, int V, int M,
+                                                    u64 *surv, float bias = 0.0f) {
+  if (V > NR * PDT_WAVE || V <= PDT_WAVE)
+    return wave_top_sorted_strided<true, false, BIAS>(xb, sx, V, M, surv, nullptr, nullptr, 1, bias);
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));
+  unsigned keys[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int v = lane + i * PDT_WAVE;
+    float x = 0.0f;
+    if (i * PDT_WAVE < V && v < V) x = BIAS ? bias + xb[(int64_t)v * sx] : xb[(int64_t)v * sx];
+    keys[i] = (i * PDT_WAVE < V && v < V) ? fkey(x) : 0u;  // 0 < every key: never a survivor
+  }
+  unsigned lmax = 0u;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) lmax = max(lmax, keys[i]);
+  const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
+  const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+  int count = 0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    if (i * PDT_WAVE < V) {
+      const int v = lane + i * PDT_WAVE;
+      const bool pred = keys[i] >= tau && keys[i] != 0u;
+      const u64 b = __ballot(pred);
+      if (b) {
+        const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+        if (pred && pos < PDT_SURV_CAP) surv[pos] = pack_key(keys[i], (unsigned)v);
+        count += __popcll(b);
+      }
+    }
+  }
+  wave_sync();
+  if (count <= PDT_SURV_CAP) return wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
+  // too many survivors (heavy ties): the chunked merge of the general form
+  return wave_top_sorted_strided<true, false, BIAS>(xb, sx, V, M, surv, nullptr, nullptr, 1, bias);
+}
+
 template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv,
                                                const unsigned *lmax_in = nullptr,
