@@ -92,16 +92,21 @@ int pdt_fill_after_eos(const int64_t *tokens, int64_t outer, int64_t L, int64_t 
  *     class_tokens[n * R + k] = token value of class k            (N, R) int64
  *     max_count (device int32, must be zeroed by the caller) = max set size = the
  *     reference's `C = counts.max().item()` (:511).
+ *     workspace: pdt_oc_mask_workspace_bytes(R, H, N) bytes -- 0 up to R = 2048 (the DP row lives in
+ *     registers); longer references run a plain one-workgroup-per-utterance form whose rows, sort
+ *     buffer and class ids live there (costs exact in float32 only).
  * Phase 2, pdt_oc_expand (after the caller has read max_count and allocated targets):
  *     targets[h * tgt_sh + n * tgt_sn + i], i < C, ascending tokens then `padding`.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_oc_mask_words(int64_t R);
+int64_t pdt_oc_mask_workspace_bytes(int64_t R, int64_t H, int64_t N);
 
 int pdt_oc_mask(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
                 const int64_t *hyp, int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N,
                 int has_eos, int64_t eos, int include_eos, float ins_cost, float del_cost,
                 float sub_cost, int exclude_last, uint32_t *bitmask,
-                int64_t *class_tokens, int32_t *max_count, int32_t *status, void *stream);
+                int64_t *class_tokens, int32_t *max_count, int32_t *status, void *workspace,
+                int64_t workspace_bytes, void *stream);
 
 int pdt_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int64_t R,
                   int64_t Hout, int64_t N, int64_t C, int64_t padding, int64_t *targets,

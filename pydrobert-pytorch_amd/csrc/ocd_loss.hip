@@ -29,26 +29,30 @@ struct OcdArgs {
 // Visits the tokens of the completion set of row (h, n): f(token) for every set bit -- four table
 // look-ups in flight at a time (one at a time each is a round trip to L2 / HBM, and a lane of a
 // 13-token set has several).
-// `w`: this lane's word of the row's class bitmask (loaded by the caller together with the logits).
+// `w`: this lane's word of the row's class bitmask (loaded by the caller together with the logits);
+// rows wider than 64 words (references beyond 2048 tokens) take the remaining words 64 at a time.
 template <typename F>
-__device__ __forceinline__ void for_each_target(const OcdArgs &a, unsigned w, int64_t n, F &&f) {
+__device__ __forceinline__ void for_each_target(const OcdArgs &a, unsigned w, int64_t row, int64_t n, F &&f) {
   const int lane = lane_id();
-  const int64_t *tab = a.class_tokens + n * (int64_t)a.R + lane * 32;
-  while (w) {
-    int64_t tok[4];
-    int cnt = 0;
+  for (int w0 = 0; w0 < a.W; w0 += PDT_WAVE) {
+    if (w0 > 0) w = w0 + lane < a.W ? a.bitmask[row * a.W + w0 + lane] : 0u;
+    const int64_t *tab = a.class_tokens + n * (int64_t)a.R + (int64_t)(w0 + lane) * 32;
+    while (w) {
+      int64_t tok[4];
+      int cnt = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      if (w) {
-        const int b = __builtin_ctz(w);
-        w &= w - 1u;
-        tok[q] = tab[b];
-        cnt = q + 1;
+      for (int q = 0; q < 4; ++q) {
+        if (w) {
+          const int b = __builtin_ctz(w);
+          w &= w - 1u;
+          tok[q] = tab[b];
+          cnt = q + 1;
+        }
       }
-    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (q < cnt) f(tok[q]);
+      for (int q = 0; q < 4; ++q)
+        if (q < cnt) f(tok[q]);
+    }
   }
 }
 
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(256) ocd_loss_kernel(const OcdArgs a) {
   float acc = 0.0f, wsum = 0.0f;
   int cnt = 0;
   bool bad = false;
-  for_each_target(a, my_word, n, [&](int64_t tok) {
+  for_each_target(a, my_word, row, n, [&](int64_t tok) {
     if (tok == a.ignore_index) return;
     if (tok < 0 || tok >= V) {
       bad = true;
@@ -152,7 +156,7 @@ int pdt_ocd_loss_forward(const float *logits, int64_t H, int64_t N, int64_t V, i
   if (H < 0 || N < 0 || V < 1 || R < 0) return PDT_E_ARG;
   if (H == 0 || N == 0) return PDT_OK;
   if (!logits || !bitmask || !class_tokens || !loss || !count) return PDT_E_ARG;
-  if (R > 64 * 32 || H * N >= (1ll << 31) * 4) return PDT_E_TOO_LONG;
+  if (H * N >= (1ll << 31) * 4) return PDT_E_TOO_LONG;
   OcdArgs a{};
   a.logits = logits; a.lg_sh = lg_sh; a.lg_sn = lg_sn; a.lg_sv = lg_sv;
   a.bitmask = bitmask; a.class_tokens = class_tokens; a.weight = weight;
@@ -170,7 +174,7 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
   if (H < 0 || N < 0 || V < 1 || R < 0) return PDT_E_ARG;
   if (H == 0 || N == 0) return PDT_OK;
   if (!logits || !bitmask || !class_tokens || !grad_loss || !grad_logits) return PDT_E_ARG;
-  if (R > 64 * 32 || H * N >= (1ll << 31) * 4) return PDT_E_TOO_LONG;
+  if (H * N >= (1ll << 31) * 4) return PDT_E_TOO_LONG;
   OcdArgs a{};
   a.logits = logits; a.lg_sh = lg_sh; a.lg_sn = lg_sn; a.lg_sv = lg_sv;
   a.bitmask = bitmask; a.class_tokens = class_tokens; a.weight = weight;

@@ -10,6 +10,11 @@ namespace pdt {
 int launch_lev_skewed(LevArgs a, hipStream_t stream);
 int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream);
 int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream);
+int launch_oc_mask_generic(const LevArgs &a, void *ws, int64_t ws_bytes, hipStream_t stream);
+int launch_oc_expand_generic(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
+                             int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
+                             int64_t tgt_sn, hipStream_t stream);
+int64_t generic_oc_ws_per_utt(int64_t R, int64_t H, int *P_out);
 int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
                      int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
                      int64_t tgt_sn, hipStream_t stream);
@@ -118,11 +123,16 @@ int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const
 
 int64_t pdt_oc_mask_words(int64_t R) { return R <= 0 ? 1 : (R + 31) / 32; }
 
+int64_t pdt_oc_mask_workspace_bytes(int64_t R, int64_t H, int64_t N) {
+  if (R <= 64 * 32 || H < 0 || N <= 0) return 0;  // (the register-resident kernel needs none)
+  return pdt::generic_oc_ws_per_utt(R, H, nullptr) * N;
+}
+
 int pdt_oc_mask(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
                 int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,
                 int include_eos, float ins_cost, float del_cost, float sub_cost, int exclude_last,
                 uint32_t *bitmask, int64_t *class_tokens, int32_t *max_count, int32_t *status,
-                void *stream) {
+                void *workspace, int64_t workspace_bytes, void *stream) {
   using namespace pdt;
   if (exclude_last && H == 0) return PDT_E_ARG;
   if (N > 0 && (!bitmask || !class_tokens || !max_count)) return PDT_E_ARG;
@@ -140,8 +150,11 @@ int pdt_oc_mask(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, c
   a.bitmask = bitmask; a.class_tokens = class_tokens; a.max_count = max_count;
   a.status = status;
   a.W = (int)pdt_oc_mask_words(R);
-  if (a.W > 64) return PDT_E_TOO_LONG;
   const bool exact = !costs_exact_in_f32(ins_cost, del_cost, sub_cost, R, H);
+  if (a.W > 64) {  // beyond the 2048 columns the row-synchronous kernel holds: the plain formulation
+    if (exact) return PDT_E_TOO_LONG;
+    return launch_oc_mask_generic(a, workspace, workspace_bytes, (hipStream_t)stream);
+  }
   return launch_lev_rowsync(a, exact, (hipStream_t)stream);
 }
 
@@ -151,7 +164,9 @@ int pdt_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int64_t 
   if (R < 0 || Hout < 0 || N < 0 || C < 0) return PDT_E_ARG;
   if (N == 0 || Hout == 0 || C == 0) return PDT_OK;
   if (!bitmask || !class_tokens || !targets) return PDT_E_ARG;
-  if (R > 64 * 32) return PDT_E_TOO_LONG;
+  if (R > 64 * 32)
+    return pdt::launch_oc_expand_generic(bitmask, class_tokens, (int)R, (int)Hout, N, (int)C, padding, targets,
+                                         tgt_sh, tgt_sn, (hipStream_t)stream);
   return pdt::launch_oc_expand(bitmask, class_tokens, (int)R, (int)Hout, N, (int)C, padding,
                                targets, tgt_sh, tgt_sn, (hipStream_t)stream);
 }

@@ -39,8 +39,9 @@ SIGNATURES = {
     "pdt_oc_mask": (
         _INT,
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
-        + [_INT, _P, _P, _P, _P, _P],
+        + [_INT, _P, _P, _P, _P, _P, _I64, _P],
     ),
+    "pdt_oc_mask_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_oc_expand": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P]),
     "pdt_ocd_loss_forward": (
         _INT, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _I64, _P, _I64, _P, _P, _P, _P],

@@ -427,12 +427,14 @@ def _oc_mask(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_co
         bitmask = torch.empty((Hout, N, W), device=device, dtype=torch.int32)
         class_tokens = torch.empty((N, max(R, 1)), device=device, dtype=torch.long)
         scal = torch.zeros(3, device=device, dtype=torch.int32)  # [max_count, status, aux status]
+        ws_bytes = int(L.pdt_oc_mask_workspace_bytes(R, H, N))  # (references beyond 2048 tokens only)
+        ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8) if ws_bytes > 0 else None
         rc = L.pdt_oc_mask(
             _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
             int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
             float(ins_cost), float(del_cost), float(sub_cost), int(exclude_last),
             _cabi.ptr(bitmask), _cabi.ptr(class_tokens), scal.data_ptr(),
-            scal.data_ptr() + 4, _cabi.stream_ptr(device),
+            scal.data_ptr() + 4, _cabi.ptr(ws), ws_bytes, _cabi.stream_ptr(device),
         )  # fmt: skip
     _cabi.check(rc, what)
     return device, bitmask, class_tokens, scal, (R, Hout, N)

@@ -57,6 +57,21 @@ def test_hocd_random_vs_oracle_and_autograd(device):
             assert torch.allclose(ga.cpu().double(), ge, rtol=1e-4, atol=1e-5), (it, (ga.cpu().double() - ge).abs().max())
 
 
+def test_hocd_long_reference(device):
+    """A reference beyond 2048 tokens: class bitmasks wider than 64 words through the loss."""
+    rng = np.random.default_rng(23)
+    N, R, H, V = 2, 2600, 21, 700
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    logits = rng.normal(size=(H, N, V)).astype(np.float32)
+    exp = oracle.hard_optimal_completion_distillation_loss(logits, ref, hyp, reduction="none")
+    x = T(logits, device).requires_grad_(True)
+    act = F.hard_optimal_completion_distillation_loss(x, T(ref, device), T(hyp, device), reduction="none", warn=False)
+    assert np.allclose(act.detach().cpu().numpy(), exp, rtol=1e-5, atol=1e-6)
+    (g,) = torch.autograd.grad(act.sum(), x)
+    assert torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
 def test_loss_goldens(device):
     g = np.load(os.path.join(G, "losses.npz"))
     ref, hyp, w = T(g["ref"], device), T(g["hyp"], device), T(g["weight"], device)

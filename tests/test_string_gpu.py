@@ -266,8 +266,8 @@ def test_full_size_properties(device):
 
 
 def test_optimal_completion_long_reference(device):
-    """R > 512: the row-synchronous kernel's BIG instantiation (more than 8 columns per lane),
-    and the documented size limit (R <= 2048) raising instead of computing garbage."""
+    """R > 512: the row-synchronous kernel's BIG instantiation (more than 8 columns per lane);
+    R = 2048 is the last reference it holds in registers."""
     rng = np.random.default_rng(13)
     N, R, H, V = 3, 700, 90, 9
     ref = rng.integers(0, V, (R, N))
@@ -279,15 +279,34 @@ def test_optimal_completion_long_reference(device):
         act = F.optimal_completion(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device),
                                    warn=False, **kw).cpu().numpy()  # fmt: skip
         assert exp.shape == act.shape and np.array_equal(exp, act), kw
-    # R = 2048 is the largest supported reference for the row-synchronous kernels
     ref = torch.from_numpy(rng.integers(0, V, (2048, 2))).to(device)
     hyp2 = torch.from_numpy(rng.integers(0, V, (5, 2))).to(device)
     oc = F.optimal_completion(ref, hyp2, warn=False)
     exp = oracle.optimal_completion(ref.cpu().numpy(), hyp2.cpu().numpy(), faithful=False)
     assert np.array_equal(exp, oc.cpu().numpy())
-    too_long = torch.zeros((2049, 2), dtype=torch.long, device=device)
+
+
+@pytest.mark.parametrize("R,V", [(2049, 5), (3000, 40), (5000, 3000)])
+def test_optimal_completion_beyond_the_register_rows(device, R, V):
+    """References longer than 2048 tokens run the plain one-workgroup-per-utterance form
+    (csrc/lev_generic.hip): class bitmasks wider than a wave, the generic expansion; ragged
+    lengths, batch-first layout, costs that are exact in float32.  Inexact costs still raise."""
+    rng = np.random.default_rng(R)
+    N, H = 3, 37
+    ref = rng.integers(0, V, (R, N))
+    hyp = rng.integers(0, V, (H, N))
+    ref[R - 300, 1] = V
+    hyp[20, 2] = V
+    for kw in (dict(eos=V), dict(eos=V, include_eos=False, exclude_last=True, ins_cost=3.0, del_cost=3.0, sub_cost=4.0),
+               dict(batch_first=True)):  # fmt: skip
+        r, h = (ref.T.copy(), hyp.T.copy()) if kw.get("batch_first") else (ref, hyp)
+        exp = oracle.optimal_completion(r, h, faithful=False, **kw)
+        act = F.optimal_completion(torch.from_numpy(r).to(device), torch.from_numpy(h).to(device),
+                                   warn=False, **kw).cpu().numpy()  # fmt: skip
+        assert exp.shape == act.shape and np.array_equal(exp, act), kw
     with pytest.raises(RuntimeError, match="too long|limit|supported"):
-        F.optimal_completion(too_long, hyp2, warn=False)
+        F.optimal_completion(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device), warn=False,
+                             ins_cost=0.1, del_cost=0.7, sub_cost=1.3)  # fmt: skip
 
 
 def test_fill_after_eos(device):
