@@ -242,8 +242,81 @@ __global__ void __launch_bounds__(512) beam_advance_kernel(const BeamAdvArgs a) 
   }
 }
 
+// Beams wider than a wave (width or K' above 64): the plain form -- one workgroup per batch element,
+// K rounds of a workgroup-wide arg-max over all K' * V candidates.  Candidates are ordered by
+// (value descending, flat index k * V + v ascending); a round takes the best candidate strictly
+// after the previous winner in that order, so nothing has to be marked as taken and exact ties go to
+// the lowest flat index like in the wave form.  O(K * K' * V) per element: a way to get the answer.
+__global__ void __launch_bounds__(256) beam_advance_wide_kernel(const BeamAdvArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ u64 red[256];
+  const int tid = (int)threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
+  const int64_t total = (int64_t)Kp * V;
+  const int K = (int)min((int64_t)W, total);  // :121
+  int *srcs = reinterpret_cast<int *>(smem);
+  int *toks = srcs + W;
+  int *plens = toks + W;
+  // candidate -> key: larger = better; equal values: lower flat index first
+  auto key_of_cand = [&](const int64_t c) {
+    const int k = (int)(c / V), v = (int)(c - (int64_t)k * V);
+    const float m = a.lpp[n * a.lp_sn + k * a.lp_sk] + a.lpt[n * a.lt_sn + k * a.lt_sk + v * a.lt_sv];  // :122
+    return pack_key(fkey(m + 0.0f), (unsigned)c);  // (-0.0 ties with +0.0)
+  };
+  u64 prev = ~0ull;  // every key is below it
+  for (int i = 0; i < W; ++i) {
+    u64 best = 0ull;
+    if (i < K)
+      for (int64_t c = tid; c < total; c += 256) {
+        const u64 key = key_of_cand(c);
+        if (key < prev && key > best) best = key;
+      }
+    red[tid] = best;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] = red[tid] > red[tid + s] ? red[tid] : red[tid + s];
+      __syncthreads();
+    }
+    const u64 win = red[0];
+    __syncthreads();
+    const bool valid = i < K && win != 0ull;
+    if (tid == 0) {
+      const int64_t c = valid ? (int64_t)idx_of(win) : 0;
+      const int src = (int)(c / V), tok = (int)(c - (int64_t)src * V);
+      const int plen = valid ? (a.lens ? (int)a.lens[n * a.le_sn + src * a.le_sk] : S) : -1;
+      a.lp_next[n * W + i] = valid ? fkey_inv(key_of(win)) : -PDT_INF;  // :145-153 for the overflow
+      a.next_src[n * W + i] = valid ? src : 0;
+      a.y_next_lens[n * W + i] = valid ? plen + 1 : 0;
+      srcs[i] = valid ? src : -1;
+      toks[i] = tok;
+      plens[i] = plen;
+    }
+    if (valid) prev = win;
+  }
+  __syncthreads();
+  for (int64_t idx = tid; idx < (int64_t)a.S_out * W; idx += 256) {
+    const int s = (int)(idx / W), i = (int)(idx - (int64_t)s * W);
+    const int src = srcs[i], pl = plens[i];
+    int64_t v;
+    if (src < 0)
+      v = 0;
+    else if (s == pl || s >= S)  // :130/:135 the appended token row, :137 the scatter
+      v = toks[i];
+    else
+      v = a.y_prev[(int64_t)s * a.yp_ss + n * a.yp_sn + src * a.yp_sk];
+    a.y_next[((int64_t)s * a.N + n) * W + i] = v;
+  }
+}
+
 int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
-  if (a.W < 1 || a.W > PDT_WAVE || a.Kp < 1 || a.Kp > PDT_WAVE) return PDT_E_TOO_LONG;
+  if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
+  if (a.W > PDT_WAVE || a.Kp > PDT_WAVE) {  // wider than a wave: the plain form
+    const size_t smem = ((size_t)a.W * 12 + 15) & ~(size_t)15;
+    if (smem > 64 * 1024 || (int64_t)a.Kp * a.V >= (1ll << 32)) return PDT_E_TOO_LONG;
+    hipLaunchKernelGGL(beam_advance_wide_kernel, dim3((unsigned)a.N), dim3(256), smem, stream, a);
+    return (int)hipGetLastError();
+  }
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   const size_t smem = ((size_t)nw * PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 8 + (size_t)a.W * 12 + 15) & ~(size_t)15;

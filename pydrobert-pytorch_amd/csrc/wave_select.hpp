@@ -256,7 +256,7 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // probe / probe_rank: if given (and V > 64), *probe receives the probe_rank-th largest per-lane
 // maximum (as a key) -- a by-product callers use to guess the next row's threshold.
 // BIAS: the ranked values are bias + x[v] (one float32 add, as the caller's own arithmetic forms
-// them): elements whose sums round to the same float tie and come out lowest index first, even
+// them; + 0.0f turns a -0.0 sum into +0.0 so the two zeros tie as in a float compare): elements whose sums round to the same float tie and come out lowest index first, even
 // when their x differ.
 template <bool LONG = false, bool NONNEG = false, bool BIAS = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
@@ -266,7 +266,7 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
                                                        int probe_rank = 1, float bias = 0.0f) {
   int lane = lane_id();
   asm volatile("" : "+v"(lane));  // nothing lane-derived is hoisted out of the caller's frame loop
-  auto X = [&](int v) { return BIAS ? bias + xb[(int64_t)v * sx] : xb[(int64_t)v * sx]; };
+  auto X = [&](int v) { return BIAS ? (bias + xb[(int64_t)v * sx]) + 0.0f : xb[(int64_t)v * sx]; };
   auto fkey = [](float f) { return NONNEG ? fkey_nonneg(f) : pdt::fkey(f); };
   if (V <= PDT_WAVE) {
     const u64 k = lane < V ? pack_key(fkey(X(lane)), (unsigned)lane) : 0ull;
@@ -339,7 +339,7 @@ __device__ __forceinline__ u64 wave_top_sorted_regs(const float *xb, const int64
   for (int i = 0; i < NR; ++i) {
     const int v = lane + i * PDT_WAVE;
     float x = 0.0f;
-    if (i * PDT_WAVE < V && v < V) x = BIAS ? bias + xb[(int64_t)v * sx] : xb[(int64_t)v * sx];
+    if (i * PDT_WAVE < V && v < V) x = BIAS ? (bias + xb[(int64_t)v * sx]) + 0.0f : xb[(int64_t)v * sx];
     keys[i] = (i * PDT_WAVE < V && v < V) ? fkey(x) : 0u;  // 0 < every key: never a survivor
   }
   unsigned lmax = 0u;

@@ -31,7 +31,6 @@ __all__ = [
 ]
 
 MAX_CTC_WIDTH = 32
-MAX_BEAM_WIDTH = 64
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
@@ -79,8 +78,6 @@ def _beam_search_advance_op(
             "Expected y_prev_lens to have shape {}, got {}".format((N, Kp), tuple(y_prev_lens.shape))
         )
     device = _cabi.require_hip(log_probs_t, log_probs_prev, y_prev, y_prev_lens)
-    if width > MAX_BEAM_WIDTH or Kp > MAX_BEAM_WIDTH:
-        raise RuntimeError("beam widths above {} are not supported".format(MAX_BEAM_WIDTH))
     lpt, lpp, yp = _f32(log_probs_t), _f32(log_probs_prev), _i64(y_prev)
     ypl = None if y_prev_lens is None else _i64(y_prev_lens)
     grow = True

@@ -334,6 +334,32 @@ def test_beam_search_advance_without_growth(device):
         assert np.array_equal(np.where(valid, act[0], 0), np.where(valid, exp[0], 0)), it
 
 
+def test_beam_search_advance_wider_than_a_wave(device):
+    """Widths and beam counts above 64 take the plain workgroup form: same answers, ties to the
+    lowest flat index k * V + v (quantised values make exact ties common)."""
+    rng = np.random.default_rng(77)
+    shapes = [(2, 1, 200, 65), (2, 70, 9, 70), (1, 100, 37, 100), (3, 65, 3, 300), (2, 5, 300, 128), (1, 128, 130, 96)]
+    for it, (N, Kp, V, W) in enumerate(shapes):
+        for with_lens in (False, True):
+            S = int(rng.integers(0, 5))
+            lpt = np.log(rng.dirichlet(np.ones(V), (N, Kp))).astype(np.float32)
+            lpp = rng.normal(size=(N, Kp)).astype(np.float32)
+            if it % 2:
+                lpt, lpp = np.round(lpt * 2) / 2, np.round(lpp * 2) / 2
+            yp = rng.integers(0, V, (S, N, Kp))
+            ypl = rng.integers(0, S + 1, (N, Kp)) if with_lens else None
+            exp = oracle.beam_search_advance(lpt, W, lpp, yp, ypl)
+            tt = lambda a: None if a is None else torch.from_numpy(a).to(device)  # noqa: E731
+            act = [x.cpu().numpy() for x in F.beam_search_advance(tt(lpt), W, tt(lpp), tt(yp), tt(ypl))]
+            K = min(W, Kp * V)
+            assert act[0].shape == exp[0].shape, (it, act[0].shape, exp[0].shape)
+            assert np.array_equal(act[1], exp[1]) and np.array_equal(act[3], exp[3]), (it, with_lens)
+            assert np.array_equal(act[2], exp[2]), (it, with_lens)
+            valid = np.arange(exp[0].shape[0])[:, None, None] < exp[1][None]
+            valid[..., K:] = False
+            assert np.array_equal(np.where(valid, act[0], 0), np.where(valid, exp[0], 0)), (it, with_lens)
+
+
 def test_beam_search_advance_errors(device):
     lpt = torch.zeros(2, 3, 4, device=device)
     with pytest.raises(RuntimeError, match="3 dimensional"):
