@@ -147,7 +147,7 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *   workspace: pdt_ctc_prefix_search_workspace_bytes(T, N, V, width) bytes of scratch
  *          (the prefix trie: one (parent, token) record per frame and beam entry, the
  *          checkpoints of the output walk and, for rows beyond the LDS, the rows of the ring).
- *   width <= 32.  S must be at least min(T, max lens): frames beyond S are not decoded.
+ *   width <= 32 (wider beams: one pdt_ctc_prefix_search_advance per frame).  S must be at least min(T, max lens): frames beyond S are not decoded.
  *   Rows of up to about 16 000 tokens live in LDS (one row of probabilities per ring slot);
  *   longer ones stay in the workspace (L2-resident), any V below 2^30.
  * pdt_ctc_prefix_search_plan (host only, no device work): the launch configuration the library
@@ -174,7 +174,8 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
  * Outputs, contiguous: y_next (S + 1, N, width) int64 (entries beyond y_next_lens
  *   unspecified, as in the reference); y_next_last, y_next_lens, next_src (N, width) int64;
  *   nb_next, b_next (N, width) float32; next_is_prefix (N, width, width) and next_is_nonext
- *   (N, width) bool bytes.  Kp, width <= 32.
+ *   (N, width) bool bytes.  Kp or width above 32: the plain workgroup form (csrc/advance_wide.hip),
+ *   same results; PDT_E_TOO_LONG once its LDS (about 56 Kp + 32 width bytes + 10 KB) exceeds 160 KB.
  * ------------------------------------------------------------------------------------- */
 int pdt_ctc_prefix_search_advance(
     const float *ext, int64_t ext_sn, int64_t ext_sk, int64_t ext_sv, const float *nonext,
@@ -194,7 +195,7 @@ int pdt_ctc_prefix_search_advance(
  *   y_prev_lens is NULL or some length equals S (the caller decides, :133-135), else S.
  * Outputs, contiguous: y_next (S_out, N, width), y_next_lens / next_src (N, width) int64,
  *   log_probs_next (N, width).  Slots beyond min(width, Kp * V) get -inf / length 0 / source 0.
- *   Kp, width <= 64.
+ *   Kp or width above 64: the plain workgroup form (csrc/advance_wide.hip), same results.
  * ------------------------------------------------------------------------------------- */
 int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_sk, int64_t lt_sv,
                             int64_t N, int64_t Kp, int64_t V, int64_t width,

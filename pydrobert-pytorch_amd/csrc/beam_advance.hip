@@ -7,28 +7,10 @@
 // gets the sorted list of its best tokens (wave_top_sorted; the waves of the workgroup share the
 // prefixes), then K rounds of a wave-wide max-reduce over the list heads pick the winners in order.  Ties go to the lowest flat
 // candidate index (the reference's torch.topk leaves them unspecified).
+#include "advance_args.hpp"
 #include "ctc_frame.hpp"
 
 namespace pdt {
-
-struct CtcAdvArgs {
-  const float *ext;     int64_t ext_sn, ext_sk, ext_sv;   // (N, Kp, V)
-  const float *nonext;  int64_t ne_sn, ne_sv;             // (N, V)
-  const float *blank;   int64_t bl_sn;                    // (N,)
-  const float *nb_prev; const float *b_prev; int64_t pb_sn, pb_sk, pbb_sn, pbb_sk;  // (N, Kp)
-  const int64_t *y_prev; int64_t yp_ss, yp_sn, yp_sk;     // (S, N, Kp)
-  const int64_t *last;  int64_t la_sn, la_sk;             // (N, Kp)
-  const int64_t *lens;  int64_t le_sn, le_sk;             // (N, Kp)
-  const uint8_t *isp;   int64_t ip_sn, ip_sa, ip_sb;      // (N, Kp, Kp) bool
-  int N, Kp, V, W, S;
-  // outputs, contiguous
-  int64_t *y_next;      // (S + 1, N, W)
-  int64_t *y_next_last, *y_next_lens, *next_src;  // (N, W)
-  float *nb_next, *b_next;                        // (N, W)
-  uint8_t *next_isp;                              // (N, W, W)
-  uint8_t *next_nonext;                           // (N, W)
-  int frame_bytes, waves_per_wg;  // LDS of the frame routine (the per-wave survivor scratch follows it)
-};
 
 // One WORKGROUP per batch element (a.waves_per_wg waves).  The Kp per-prefix selections over the
 // dense extension probabilities are independent and each is a chain of round trips to HBM for a
@@ -125,7 +107,9 @@ __global__ void __launch_bounds__(512) ctc_advance_kernel(const CtcAdvArgs a) {
 }
 
 int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
-  if (a.W < 1 || a.W > kMaxWidth || a.Kp < 1 || a.Kp > kMaxWidth) return PDT_E_TOO_LONG;
+  if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
+  static const bool force_wide = getenv("PDT_STEP_WIDE") != nullptr;
+  if (force_wide || a.W > kMaxWidth || a.Kp > kMaxWidth) return launch_ctc_advance_wide(a, stream);  // (advance_wide.hip)
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   size_t frame = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
@@ -144,18 +128,6 @@ int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
 }
 
 // -------------------------------------------------------------------------------------------
-struct BeamAdvArgs {
-  const float *lpt;     int64_t lt_sn, lt_sk, lt_sv;   // log_probs_t (N, Kp, V)
-  const float *lpp;     int64_t lp_sn, lp_sk;          // log_probs_prev (N, Kp)
-  const int64_t *y_prev; int64_t yp_ss, yp_sn, yp_sk;  // (S, N, Kp)
-  const int64_t *lens;  int64_t le_sn, le_sk;          // (N, Kp) or null
-  int N, Kp, V, W, S, S_out;
-  int64_t *y_next;      // (S_out, N, W)
-  int64_t *y_next_lens, *next_src;  // (N, W)
-  float *lp_next;                   // (N, W)
-  int waves_per_wg;
-};
-
 // One WORKGROUP per batch element (a.waves_per_wg waves): the Kp selections are independent and
 // each is a chain of round trips to HBM for a lone wave, so the waves take prefixes k = w, w + NW,
 // ... in turn; wave 0 merges the lists (values are kept with the tokens: no global load in the K
@@ -242,81 +214,10 @@ __global__ void __launch_bounds__(512) beam_advance_kernel(const BeamAdvArgs a) 
   }
 }
 
-// Beams wider than a wave (width or K' above 64): the plain form -- one workgroup per batch element,
-// K rounds of a workgroup-wide arg-max over all K' * V candidates.  Candidates are ordered by
-// (value descending, flat index k * V + v ascending); a round takes the best candidate strictly
-// after the previous winner in that order, so nothing has to be marked as taken and exact ties go to
-// the lowest flat index like in the wave form.  O(K * K' * V) per element: a way to get the answer.
-__global__ void __launch_bounds__(256) beam_advance_wide_kernel(const BeamAdvArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  __shared__ u64 red[256];
-  const int tid = (int)threadIdx.x;
-  const int64_t n = blockIdx.x;
-  const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
-  const int64_t total = (int64_t)Kp * V;
-  const int K = (int)min((int64_t)W, total);  // :121
-  int *srcs = reinterpret_cast<int *>(smem);
-  int *toks = srcs + W;
-  int *plens = toks + W;
-  // candidate -> key: larger = better; equal values: lower flat index first
-  auto key_of_cand = [&](const int64_t c) {
-    const int k = (int)(c / V), v = (int)(c - (int64_t)k * V);
-    const float m = a.lpp[n * a.lp_sn + k * a.lp_sk] + a.lpt[n * a.lt_sn + k * a.lt_sk + v * a.lt_sv];  // :122
-    return pack_key(fkey(m + 0.0f), (unsigned)c);  // (-0.0 ties with +0.0)
-  };
-  u64 prev = ~0ull;  // every key is below it
-  for (int i = 0; i < W; ++i) {
-    u64 best = 0ull;
-    if (i < K)
-      for (int64_t c = tid; c < total; c += 256) {
-        const u64 key = key_of_cand(c);
-        if (key < prev && key > best) best = key;
-      }
-    red[tid] = best;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) red[tid] = red[tid] > red[tid + s] ? red[tid] : red[tid + s];
-      __syncthreads();
-    }
-    const u64 win = red[0];
-    __syncthreads();
-    const bool valid = i < K && win != 0ull;
-    if (tid == 0) {
-      const int64_t c = valid ? (int64_t)idx_of(win) : 0;
-      const int src = (int)(c / V), tok = (int)(c - (int64_t)src * V);
-      const int plen = valid ? (a.lens ? (int)a.lens[n * a.le_sn + src * a.le_sk] : S) : -1;
-      a.lp_next[n * W + i] = valid ? fkey_inv(key_of(win)) : -PDT_INF;  // :145-153 for the overflow
-      a.next_src[n * W + i] = valid ? src : 0;
-      a.y_next_lens[n * W + i] = valid ? plen + 1 : 0;
-      srcs[i] = valid ? src : -1;
-      toks[i] = tok;
-      plens[i] = plen;
-    }
-    if (valid) prev = win;
-  }
-  __syncthreads();
-  for (int64_t idx = tid; idx < (int64_t)a.S_out * W; idx += 256) {
-    const int s = (int)(idx / W), i = (int)(idx - (int64_t)s * W);
-    const int src = srcs[i], pl = plens[i];
-    int64_t v;
-    if (src < 0)
-      v = 0;
-    else if (s == pl || s >= S)  // :130/:135 the appended token row, :137 the scatter
-      v = toks[i];
-    else
-      v = a.y_prev[(int64_t)s * a.yp_ss + n * a.yp_sn + src * a.yp_sk];
-    a.y_next[((int64_t)s * a.N + n) * W + i] = v;
-  }
-}
-
 int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
-  if (a.W > PDT_WAVE || a.Kp > PDT_WAVE) {  // wider than a wave: the plain form
-    const size_t smem = ((size_t)a.W * 12 + 15) & ~(size_t)15;
-    if (smem > 64 * 1024 || (int64_t)a.Kp * a.V >= (1ll << 32)) return PDT_E_TOO_LONG;
-    hipLaunchKernelGGL(beam_advance_wide_kernel, dim3((unsigned)a.N), dim3(256), smem, stream, a);
-    return (int)hipGetLastError();
-  }
+  static const bool force_wide = getenv("PDT_STEP_WIDE") != nullptr;
+  if (force_wide || a.W > PDT_WAVE || a.Kp > PDT_WAVE) return launch_beam_advance_wide(a, stream);  // (advance_wide.hip)
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   const size_t smem = ((size_t)nw * PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 8 + (size_t)a.W * 12 + 15) & ~(size_t)15;

@@ -229,8 +229,6 @@ def _ctc_prefix_search_advance_op(
         )
     device = _cabi.require_hip(ext, nonext, blank, nb, b, y_prev, y_prev_last, y_prev_lens,
                                prev_is_prefix)  # fmt: skip
-    if width > MAX_CTC_WIDTH or Kp > MAX_CTC_WIDTH:
-        raise RuntimeError("CTC beam widths above {} are not supported".format(MAX_CTC_WIDTH))
     dtype = ext.dtype
     ext, nonext, blank, nb, b = (_f32(x) for x in (ext, nonext, blank, nb, b))
     yp, last, lens = _i64(y_prev), _i64(y_prev_last), _i64(y_prev_lens)
@@ -381,8 +379,8 @@ def _ctc_prefix_search_op(
         raise RuntimeError("logits must have at least one non-blank class")
     if width < 1:
         raise RuntimeError("width must be positive")
-    if width > MAX_CTC_WIDTH:
-        raise RuntimeError("CTC beam widths above {} are not supported".format(MAX_CTC_WIDTH))
+    if width > MAX_CTC_WIDTH:  # (CTCPrefixSearch / ctc_prefix_search run such beams frame by frame)
+        raise RuntimeError("the one-kernel search holds at most {} prefixes".format(MAX_CTC_WIDTH))
     dtype = logits.dtype
     logits = _f32(logits)
     if lens is None:
@@ -435,7 +433,9 @@ def ctc_prefix_search(
     probabilities are cut off from the graph; logits that require grad take the frame-by-frame
     route of :class:`CTCPrefixSearch` instead (same beams, differentiable probabilities).
     """
-    if torch.jit.is_scripting() or not (torch.is_grad_enabled() and logits.requires_grad):
+    if torch.jit.is_scripting() or not (
+        width > 32 or (torch.is_grad_enabled() and logits.requires_grad)  # (32: MAX_CTC_WIDTH)
+    ):
         return torch.ops.pydrobert_amd.ctc_prefix_search(logits, width, lens)
     return CTCPrefixSearch(width)(logits, lens)
 
@@ -519,12 +519,14 @@ class CTCPrefixSearch(torch.nn.Module):
         # caller wants gradients with respect to the logits (the reference's probabilities are
         # differentiable, _decoding.py:1093, :1188), the search runs frame by frame instead: every
         # frame is one kernel whose masses carry an autograd formula.
-        wants_grad = torch.is_grad_enabled() and logits.requires_grad
+        # Beams wider than the one-kernel search holds (32 prefixes) also go frame by frame, on the
+        # plain step kernel (csrc/advance_wide.hip).
+        stepwise = (torch.is_grad_enabled() and logits.requires_grad) or self.width > 32  # (MAX_CTC_WIDTH; TorchScript takes no globals)
         prev: Dict[str, torch.Tensor] = dict()
         if initial_state is not None:
             prev = initial_state
         if self.lm is None:
-            if wants_grad:
+            if stepwise:
                 return self._frame_by_frame(logits, lens, prev)
             return ctc_prefix_search(logits, self.width, lens)
         else:
@@ -532,7 +534,7 @@ class CTCPrefixSearch(torch.nn.Module):
                 raise RuntimeError(
                     "Expected dim 2 of logits to be {}, got {}".format(self.lm.vocab_size + 1, logits.size(2))
                 )
-            if self.beta == 0.0 and not wants_grad:
+            if self.beta == 0.0 and not stepwise:
                 return ctc_prefix_search(logits, self.width, lens)
             return self._frame_by_frame(logits, lens, prev)
 

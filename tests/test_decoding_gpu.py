@@ -203,6 +203,21 @@ def test_ctc_wide_beam(device):
         assert set(tot) <= seen or len(seen) == K
 
 
+@pytest.mark.parametrize("V,K", [(40, 33), (64, 64), (150, 100)])
+def test_ctc_prefix_search_wider_than_the_kernel_holds(device, V, K):
+    """More than 32 prefixes: frame by frame on the plain step kernel (csrc/advance_wide.hip), through
+    the same entry points."""
+    rng = np.random.default_rng(V + K)
+    for it, (T, N) in enumerate([(1, 2), (9, 3), (25, 4)]):
+        lg = _peaky_logits(rng, T, N, V, scale=3.0)
+        lens = None if it % 2 == 0 else rng.integers(0, T + 1, N)
+        exp = oracle.ctc_prefix_search(lg, K, lens)
+        tl = None if lens is None else torch.from_numpy(lens).to(device)
+        _check_search(F.ctc_prefix_search(torch.from_numpy(lg).to(device), K, tl), exp, (V, K, T, N))
+        if it == 1:
+            _check_search(M.CTCPrefixSearch(K)(torch.from_numpy(lg).to(device), tl), exp, (V, K, T, N, "module"))
+
+
 def test_ctc_strided_logits_and_errors(device):
     rng = np.random.default_rng(6)
     lg = _peaky_logits(rng, 12, 4, 9)
@@ -242,8 +257,10 @@ def _cmp_ctc_step(act, exp, what):
 
 
 @pytest.mark.parametrize(
-    "V,W", [(3, 2), (4, 5), (9, 4), (30, 8), (100, 16), (300, 32), (12, 7), (40, 13), (60, 27), (33, 31)]
-)
+    "V,W",
+    [(3, 2), (4, 5), (9, 4), (30, 8), (100, 16), (300, 32), (12, 7), (40, 13), (60, 27), (33, 31),
+     (50, 33), (39, 40), (70, 64), (200, 70), (1000, 100)],  # (beyond 32: the plain workgroup form)
+)  # fmt: skip
 def test_ctc_prefix_search_advance_teacher_forced(device, V, W):
     """Run the oracle's search with per-prefix (LM-like) extension probabilities and, at every
     frame, feed the oracle's state to the kernel and compare all seven outputs.  Widths that do
