@@ -30,6 +30,8 @@ while time.time() < t_end:
     kind = rng.integers(0, 5)
     if kind == 0:  # teacher-forced CTC step
         V, W, N, Tn = int(rng.integers(1, 50)), int(rng.integers(1, 33)), int(rng.integers(1, 4)), int(rng.integers(1, 16))
+        if rng.random() < 0.2:  # more than 32 prefixes: the radix-select form (csrc/advance_wide.hip)
+            W = int(rng.integers(33, 120)); V = W + int(rng.integers(0, 60)); Tn = int(rng.integers(1, 8))
         if W > V + 1: continue
         nb, b = np.zeros((N, 1), np.float32), np.ones((N, 1), np.float32)
         y = np.zeros((0, N, 1), np.int64); last = lens = np.zeros((N, 1), np.int64); isp = np.ones((N, 1, 1), bool)

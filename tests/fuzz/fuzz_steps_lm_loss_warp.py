@@ -20,8 +20,13 @@ while time.time() < t_end:
     kind = rng.integers(0, 4)
     if kind == 0:  # beam_search_advance
         N, Kp, V, W = int(rng.integers(1, 6)), int(rng.integers(1, 20)), int(rng.integers(1, 60)), int(rng.integers(1, 40))
+        if rng.random() < 0.2:  # wider than a wave: the radix-select form (csrc/advance_wide.hip)
+            Kp, V, W = int(rng.integers(1, 140)), int(rng.integers(1, 300)), int(rng.integers(1, 200))
+            if rng.random() < 0.5: Kp = max(Kp, 65)
+            else: W = max(W, 65)
         S = int(rng.integers(0, 9))
         lpt = rng.normal(size=(N, Kp, V)).astype(np.float32)
+        if rng.random() < 0.3: lpt = np.round(lpt * 4) / 4  # exact ties: lowest flat index first
         lpp = rng.normal(size=(N, Kp)).astype(np.float32)
         yp = rng.integers(0, V, (S, N, Kp))
         ypl = rng.integers(1 if S else 0, S + 1, (N, Kp)) if (rng.random() < 0.5) else None
