@@ -132,8 +132,11 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 // INREG (P = 1 only): the whole row, V + 1 <= 512 elements, sits in the eight prefetch registers
 // of the producer's lanes; longer rows take the generic LDS-staged row pass of the P > 1 forms.
 // GROW (generic row pass): rows no LDS ring can hold -- see RingLayout::row_global.
+#ifndef PDT_CTC_SGPRS
+#define PDT_CTC_SGPRS 80
+#endif
 template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
-__global__ void __launch_bounds__(256, INREG ? 8 : 4) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(256, INREG ? 8 : 4) __attribute__((amdgpu_num_sgpr(PDT_CTC_SGPRS)))
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
   static_assert(!GROW || !INREG, "rows in the workspace are a form of the generic row pass");
