@@ -21,6 +21,8 @@ while time.time() < t_end:
     if kind == 0:  # string ops
         N, R, H, V = int(rng.integers(1, 9)), int(rng.integers(0, 140)), int(rng.integers(0, 140)), int(rng.integers(1, 12))
         if rng.random() < 0.1: R = int(rng.integers(500, 700))
+        long_ref = rng.random() < 0.02  # beyond the register-row kernels: csrc/lev_generic.hip for optimal_completion
+        if long_ref: N, R, H, V = int(rng.integers(1, 3)), int(rng.integers(2049, 2700)), int(rng.integers(0, 40)), int(rng.integers(1, 300))
         ref, hyp = rng.integers(0, V, (R, N)), rng.integers(0, V, (H, N))
         eos = None if rng.random() < 0.3 else int(rng.integers(0, V))
         costs = [(1., 1., 1.), (2., 2., 2.), (3., 3., 4.), (2., .5, 1.), (1., 2., 1.5)][rng.integers(0, 5)]
