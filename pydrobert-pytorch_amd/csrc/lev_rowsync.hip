@@ -456,25 +456,28 @@ struct OcTileArgs {
   int64_t *targets;
   int64_t N, padding, outer_stride;  // outer_stride: elements between tiles' outer index
   int R, W, lgWp, Hout, C, NB, over_n, chunk, ntiles, wide;
+  int nw;  // waves per workgroup
 };
 
-__host__ __device__ inline size_t oc_tile_lds(int R, int W, int C, int NB, int over_n, int chunk, size_t *bm_off,
-                                              size_t *stage_off) {
+__host__ __device__ inline size_t oc_tile_lds(int R, int W, int C, int NB, int over_n, int chunk, int nw,
+                                              size_t *bm_off, size_t *stage_off) {
   const size_t ctok = (((size_t)(over_n ? NB : 1) * R + 1) & ~(size_t)1) * 8;
   const size_t bm = (((size_t)chunk * NB * W + 3) & ~(size_t)3) * 4;  // rows of the chunk x W words
   const size_t stage = (((size_t)NB * C + 3) & ~(size_t)3) * 4;
   if (bm_off) *bm_off = ctok;
   if (stage_off) *stage_off = ctok + bm;
-  return ctok + bm + 4 * stage;
+  return ctok + bm + (size_t)nw * stage;
 }
 
-__global__ void __launch_bounds__(256) oc_expand_tiles_kernel(const OcTileArgs a) {
+template <int NW>
+__global__ void __launch_bounds__(NW * PDT_WAVE) oc_expand_tiles_kernel(const OcTileArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
   const int C = a.C, NB = a.NB, W = a.W, R = a.R;
   size_t bm_off, stage_off;
-  oc_tile_lds(R, W, C, NB, a.over_n, a.chunk, &bm_off, &stage_off);
+  constexpr int kOcWaves = NW, kOcThreads = NW * PDT_WAVE;
+  oc_tile_lds(R, W, C, NB, a.over_n, a.chunk, a.nw, &bm_off, &stage_off);
   int64_t *ctok = reinterpret_cast<int64_t *>(smem);
   unsigned *bm = reinterpret_cast<unsigned *>(smem + bm_off);
   int *stage = reinterpret_cast<int *>(smem + stage_off) + (size_t)wave * (((size_t)NB * C + 3) & ~(size_t)3);
@@ -493,28 +496,28 @@ __global__ void __launch_bounds__(256) oc_expand_tiles_kernel(const OcTileArgs a
   {  // the tables of consecutive utterances are one contiguous block of class_tokens
     const int64_t *src = a.class_tokens + n_first * (int64_t)R;
     const int total = tabs_valid * R;
-    for (int k0 = (int)threadIdx.x; k0 < total; k0 += 256 * 8) {
+    for (int k0 = (int)threadIdx.x; k0 < total; k0 += kOcThreads * 8) {
       int64_t v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = k0 + q * 256 < total ? src[k0 + q * 256] : 0;
+      for (int q = 0; q < 8; ++q) v[q] = k0 + q * kOcThreads < total ? src[k0 + q * kOcThreads] : 0;
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        if (k0 + q * 256 < total) ctok[k0 + q * 256] = v[q];
+        if (k0 + q * kOcThreads < total) ctok[k0 + q * kOcThreads] = v[q];
     }
   }
   {  // bm[(hi * tabs_valid + u) * W + word]: tabs_valid * W consecutive words per h
     const int per_h = tabs_valid * W, total = h_count * per_h;
-    for (int k0 = (int)threadIdx.x; k0 < total; k0 += 256 * 8) {
+    for (int k0 = (int)threadIdx.x; k0 < total; k0 += kOcThreads * 8) {
       unsigned v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const int k = k0 + q * 256;
+        const int k = k0 + q * kOcThreads;
         const int hi = k / per_h, r = k - hi * per_h;
         v[q] = k < total ? a.bitmask[((int64_t)(h_base + hi) * a.N + n_first) * W + r] : 0u;
       }
 #pragma unroll
       for (int q = 0; q < 8; ++q)
-        if (k0 + q * 256 < total) bm[k0 + q * 256] = v[q];
+        if (k0 + q * kOcThreads < total) bm[k0 + q * kOcThreads] = v[q];
     }
   }
   __syncthreads();  // from here on: LDS reads and global stores only
@@ -523,7 +526,7 @@ __global__ void __launch_bounds__(256) oc_expand_tiles_kernel(const OcTileArgs a
   const int seg = lane & ~(Wp - 1);
   // the jobs of this wave: over_n -> h = h_base + wave, + 4, ...; else tiles of NB rows
   const int j_end = a.over_n ? h_base + h_count : min(a.ntiles, (inner + 1) * a.chunk);
-  for (int j = (a.over_n ? h_base : inner * a.chunk) + wave; j < j_end; j += 4) {
+  for (int j = (a.over_n ? h_base : inner * a.chunk) + wave; j < j_end; j += kOcWaves) {
     const int h_first = a.over_n ? j : j * NB;
     const int rows = a.over_n ? tabs_valid : min(NB, a.Hout - h_first);
     // image of the run as indices into the class-token tables: -1 (padding) everywhere, then
@@ -620,10 +623,24 @@ int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R
 #endif
     int NB = PDT_OC_TILE_ROWS;
     int chunk = over_n ? PDT_OC_CHUNK : 16;
-    while (oc_tile_lds(R, W, C, NB, a.over_n, chunk, nullptr, nullptr) > cap && (NB > 1 || chunk > 8)) {
+    while (oc_tile_lds(R, W, C, NB, a.over_n, chunk, 4, nullptr, nullptr) > cap && (NB > 1 || chunk > 8)) {
       if (chunk > 16 || NB == 1) chunk >>= 1; else NB >>= 1;
     }
-    const size_t smem = oc_tile_lds(R, W, C, NB, a.over_n, chunk, nullptr, nullptr);
+    // waves per workgroup (they share the tables): eight when that puts more waves on a CU than
+    // four do (bench shape: 3 x 8 against 4 x 4, 1.05-1.07 -> 0.98-1.00 ms for the whole op,
+    // batch-first 1.04 -> 0.95; with the wide images of V = 5000 a workgroup of eight would be
+    // alone on its CU)
+    int nw = 4;
+    {
+      const size_t l4 = oc_tile_lds(R, W, C, NB, a.over_n, chunk, 4, nullptr, nullptr);
+      const size_t l8 = oc_tile_lds(R, W, C, NB, a.over_n, chunk, 8, nullptr, nullptr);
+      const size_t lds_cu = 160 * 1024;
+      if (min(lds_cu / l8, (size_t)4) * 8 > min(lds_cu / l4, (size_t)8) * 4) nw = 8;
+      static const char *force = getenv("PDT_OC_WAVES");
+      if (force && (atoi(force) == 4 || atoi(force) == 8)) nw = atoi(force);
+    }
+    a.nw = nw;
+    const size_t smem = oc_tile_lds(R, W, C, NB, a.over_n, chunk, nw, nullptr, nullptr);
     if (smem <= 160 * 1024) {
       a.NB = NB;
       a.chunk = chunk;
@@ -634,12 +651,13 @@ int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R
       a.wide = ((a.outer_stride & 1) == 0 && (((int64_t)NB * C) & 1) == 0 &&
                 (reinterpret_cast<uintptr_t>(targets) & 15) == 0) ? 1 : 0;
       if (grid > 0 && grid < (1ll << 31)) {
+        auto kern = nw == 8 ? oc_expand_tiles_kernel<8> : oc_expand_tiles_kernel<4>;
         if (smem > cap) {
-          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(oc_expand_tiles_kernel),
+          hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
           if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL(oc_expand_tiles_kernel, dim3((unsigned)grid), dim3(256), smem, stream, a);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(nw * PDT_WAVE), smem, stream, a);
         return (int)hipGetLastError();
       }
     }
