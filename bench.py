@@ -489,9 +489,9 @@ def run_rank(args):
     dom = max((o for o in ops if o in alg_bytes), key=lambda o: op_ms[o])
     achieved = alg_bytes[dom] * N / (op_ms[dom] * 1e-3) / 1e9
     kernel_names = {
-        "error_rate": "pdt::lev_skewed_kernel<false>",
-        "prefix_error_rates": "pdt::lev_skewed_kernel<false>",
-        "optimal_completion": "pdt::lev_rowsync_kernel<false,false> + pdt::oc_expand_kernel",
+        "error_rate": "pdt::lev_classify_kernel<8> + pdt::lev_bitpar_kernel",
+        "prefix_error_rates": "pdt::lev_classify_kernel<8> + pdt::lev_bitpar_kernel",
+        "optimal_completion": "pdt::lev_rowsync_kernel<false, false> + pdt::oc_expand_tiles_kernel<8>",
         "ctc_prefix_search": ctc_kernel_name(args.V, args.beam),
     }
     # HBM bytes per launch and instruction counts from the rocprofv3 PMC passes (profiles/), only
