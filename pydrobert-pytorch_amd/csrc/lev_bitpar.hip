@@ -27,6 +27,7 @@
 // (Pv, Mv) words and searched them for the arg-min rows (nibble-table block minima, bounds from
 // popcounts, one lane per column) measured 0.48 ms against 0.51 -- its cost is the arg-min sets
 // (13 rows per column at the bench shape, each a class look-up), not the recurrence.
+#include <algorithm>
 #include <type_traits>
 
 #include "lev_classes.hpp"
@@ -54,6 +55,11 @@ struct BitparArgs {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// the recurrence kernel's ring of match words: two buffers of 16 words per lane, lane stride 20
+// words (conflict-free 16-byte accesses)
+constexpr int kBitparChunk = 16, kBitparLaneStride = 20;
+constexpr size_t kBitparRingBytes = (size_t)2 * PDT_WAVE * kBitparLaneStride * 4;
+
 // X: length of the bit-vector sequence, Y: of the consumed one.  Blocks are 32 rows and the
 // presence word has 32 bits: X <= 1024.
 BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N) {
@@ -66,12 +72,15 @@ BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N) {
   // classify: [(presence, offset) per class X * 8] [tokens (X + 1) * 8 (later: the mask words)]
   //           [classes of Y, 2 bytes each]
   p.lds_classify = align_up(Xs * 8 + (Xs + 1) * 8 + Ys * 2, 16);
-  // DP: [yh Y * 8] [mask words (X + 1) * 4] [distances (X + 1) * 4]
-  p.lds_sub = align_up(Ys * 8 + (Xs + 1) * 4 + (Xs + 1) * 4, 16);
+  // DP: per utterance [yh Y * 8] [mask words (X + 1) * 4]; per workgroup the ring of match words
+  // (two chunks of kRingWords per lane), which the distances (X + 1) * 4 per utterance take over
+  p.lds_sub = align_up(Ys * 8 + (Xs + 1) * 4, 16);
   int upw = 64 >> lgL;
-  while (upw > 1 && p.lds_sub * upw > 40 * 1024) upw >>= 1;  // (four waves per CU)
-  if (p.lds_sub * upw > 150 * 1024 || p.lds_classify * 4 > 160 * 1024) return p;
+  auto tail = [&](int u) { return align_up(std::max<size_t>((size_t)u * (Xs + 1) * 4, kBitparRingBytes), 16); };
+  while (upw > 1 && p.lds_sub * upw + tail(upw) > 40 * 1024) upw >>= 1;  // (four workgroups per CU)
+  if (p.lds_sub * upw + tail(upw) > 150 * 1024 || p.lds_classify * 4 > 160 * 1024) return p;
   p.upw = upw;
+  p.lds_tail = tail(upw);
   size_t off = 0;
   auto take = [&](size_t bytes) {
     const size_t o = off;
@@ -192,9 +201,13 @@ __global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, c
 }
 
 // ---- kernel 2: the column recurrence ----------------------------------------------------------
-__global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, const int lds_per_sub) {
+// Two waves per workgroup: wave 1 looks the match words up one chunk of steps ahead and leaves
+// them in an LDS ring, wave 0 runs the recurrence -- a lone wave issues an instruction every ~5.5
+// cycles whatever it is, and the look-ups were 12 of the loop's 40 instructions per step.
+__global__ void __launch_bounds__(128) lev_bitpar_kernel(const BitparArgs a, const int lds_per_sub, const int ring_off) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6);
   const int L = 1 << a.lgL;
   const int sub = lane >> a.lgL, b = lane & (L - 1);
   const int64_t n_raw = (int64_t)blockIdx.x * a.upw + sub;
@@ -204,7 +217,8 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
   unsigned char *base = smem + (size_t)(valid ? sub : 0) * lds_per_sub;
   uint2 *yh_l = reinterpret_cast<uint2 *>(base);
   unsigned *msk_l = reinterpret_cast<unsigned *>(yh_l + Y);
-  float *bnd = reinterpret_cast<float *>(msk_l + X + 1);
+  unsigned *ring = reinterpret_cast<unsigned *>(smem + ring_off);
+  float *bnd = reinterpret_cast<float *>(smem + ring_off) + (size_t)(valid ? sub : 0) * (X + 1);  // (after the loop)
 
   const int ref_len = a.lens[2 * n], hyp_len = a.lens[2 * n + 1];
   int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;
@@ -214,7 +228,7 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
   // ---- stage this utterance's lookups in LDS (eight loads in flight per lane) --------------
   {
     const uint2 *src = a.yh + n * (int64_t)Y;
-    for (int j0 = b; j0 < y_len; j0 += 8 * L) {
+    for (int j0 = b + wave * 8 * L; j0 < y_len; j0 += 16 * L) {
       uint2 v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = j0 + q * L < y_len ? src[j0 + q * L] : make_uint2(0u, 0u);
@@ -222,9 +236,9 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
       for (int q = 0; q < 8; ++q)
         if (j0 + q * L < y_len) yh_l[j0 + q * L] = v[q];
     }
-    if (valid && y_len == 0 && b == 0) yh_l[0] = make_uint2(0u, 0u);
+    if (valid && y_len == 0 && b == 0 && wave == 0) yh_l[0] = make_uint2(0u, 0u);
     const unsigned *msrc = a.msk + n * (int64_t)(X + 1);
-    for (int i0 = b; i0 <= x_len && valid; i0 += 8 * L) {
+    for (int i0 = b + wave * 8 * L; i0 <= x_len && valid; i0 += 16 * L) {
       unsigned v[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) v[q] = i0 + q * L <= x_len ? msrc[i0 + q * L] : 0u;
@@ -233,7 +247,7 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
         if (i0 + q * L <= x_len) msk_l[i0 + q * L] = v[q];
     }
   }
-  wave_sync();
+  __syncthreads();
   int ymax = y_len;
 #pragma unroll
   for (int t = 1; t < PDT_WAVE; t <<= 1) ymax = max(ymax, __shfl_xor(ymax, t));
@@ -250,7 +264,7 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
   // a waiting lane sees Eq = 0 (its lookups are forced to 0) and the horizontal delta 0 its waiting
   // neighbour emits, which leaves the column-0 state (Pv = ~0, Mv = 0) as it is and emits 0 again.
   // Only the last steps (the first utterance of the wave to finish, onwards) are guarded.
-  constexpr int kChunk = 16;
+  constexpr int kChunk = kBitparChunk;
   unsigned Pv = 0xffffffffu, Mv = 0u;  // column 0: D[i][0] = i
   unsigned hop = 0u, hon = 0u;         // horizontal delta of this block's last row: +1 / -1 flags
   const unsigned lowmask = (1u << b) - 1u, bbit = 1u << b;
@@ -283,11 +297,22 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
     Pv = Mh | ~(Xv | Ph);
     Mv = Ph & Xv;
   };
+  auto ring_at = [&](const int s0) {
+    return reinterpret_cast<uint4 *>(ring + ((s0 / kChunk) & 1) * (PDT_WAVE * kBitparLaneStride) + lane * kBitparLaneStride);
+  };
   auto sweep = [&](auto row16_tag, auto guarded_tag, const int s_begin, const int s_end) {
     constexpr bool ROW16 = decltype(row16_tag)::value, GUARDED = decltype(guarded_tag)::value;
     for (int s0 = s_begin; s0 < s_end; s0 += kChunk) {
+      __syncthreads();  // chunk s0 is in the ring (and wave 1 may fill the other buffer)
       unsigned eq[kChunk];
-      lookups(s0, eq);
+      {
+        const uint4 *src = ring_at(s0);
+#pragma unroll
+        for (int q = 0; q < kChunk / 4; ++q) {
+          const uint4 v = src[q];
+          eq[4 * q] = v.x; eq[4 * q + 1] = v.y; eq[4 * q + 2] = v.z; eq[4 * q + 3] = v.w;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < kChunk; ++q) {
         unsigned hp, hn;
@@ -311,6 +336,17 @@ __global__ void __launch_bounds__(64) lev_bitpar_kernel(const BitparArgs a, cons
   };
   using T = std::true_type;
   using F = std::false_type;
+  if (wave == 1) {  // the look-ups, one chunk ahead of the recurrence (one barrier per chunk on both sides)
+    for (int s0 = 0; s0 < nsteps; s0 += kChunk) {
+      unsigned eq[kChunk];
+      lookups(s0, eq);
+      uint4 *dst = ring_at(s0);
+#pragma unroll
+      for (int q = 0; q < kChunk / 4; ++q) dst[q] = make_uint4(eq[4 * q], eq[4 * q + 1], eq[4 * q + 2], eq[4 * q + 3]);
+      __syncthreads();
+    }
+    return;
+  }
   if (row16) {
     sweep(T{}, F{}, 0, nfree);
     sweep(T{}, T{}, nfree, nsteps);
@@ -386,12 +422,12 @@ int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStrea
   if (rc) return rc;
   hipLaunchKernelGGL(ck, dim3((unsigned)((a.N + 3) / 4)), dim3(256), p.lds_classify * 4,
                      stream, a, (int)p.lds_classify);
-  const size_t smem = p.lds_sub * p.upw;
+  const size_t smem = p.lds_sub * p.upw + p.lds_tail;
   const unsigned grid = (unsigned)((a.N + p.upw - 1) / p.upw);
   auto kern = lev_bitpar_kernel;
   rc = set_lds(reinterpret_cast<const void *>(kern), smem);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), smem, stream, a, (int)p.lds_sub);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(128), smem, stream, a, (int)p.lds_sub, (int)(p.lds_sub * p.upw));
   return (int)hipGetLastError();
 }
 

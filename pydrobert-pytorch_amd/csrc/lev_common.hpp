@@ -32,6 +32,7 @@ struct LevArgs {
 struct BitparPlan {
   int ok, lgL, upw;
   size_t lds_classify, lds_sub;  // bytes: per wave / per utterance
+  size_t lds_tail;               // bytes per workgroup after the utterances' tables (ring of match words, then distances)
   size_t off_lens, off_yh, off_msk, total;  // workspace
 };
 BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N);
