@@ -297,6 +297,23 @@ __global__ void __launch_bounds__(128) lev_bitpar_kernel(const BitparArgs a, con
     Pv = Mh | ~(Xv | Ph);
     Mv = Ph & Xv;
   };
+  // ROW16 form of the step: the neighbour's WHOLE Ph / Mh words travel (xp, xm; lane b = 0 of a
+  // row is never written by the row shift and keeps the D[0][j] = j deltas: bit 31 of xp set, of xm
+  // clear), and (Ph << 1) | (xp >> 31) is one v_alignbit -- three instructions per step less than
+  // shifting the top bits out first and presetting the shift's `old` operand every step.
+  unsigned xp = b == 0 ? 0x80000000u : 0u, xm = 0u, Phw = 0u, Mhw = 0u;
+  auto step16 = [&](const unsigned eq0) {
+    const unsigned hn = xm >> 31;
+    const unsigned Xv = eq0 | Mv;
+    const unsigned Eq = eq0 | hn;
+    const unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+    Phw = Mv | ~(Xh | Pv);
+    Mhw = Pv & Xh;
+    const unsigned Ph = __builtin_amdgcn_alignbit(Phw, xp, 31);
+    const unsigned Mh = __builtin_amdgcn_alignbit(Mhw, xm, 31);
+    Pv = Mh | ~(Xv | Ph);
+    Mv = Ph & Xv;
+  };
   auto ring_at = [&](const int s0) {
     return reinterpret_cast<uint4 *>(ring + ((s0 / kChunk) & 1) * (PDT_WAVE * kBitparLaneStride) + lane * kBitparLaneStride);
   };
@@ -315,10 +332,10 @@ __global__ void __launch_bounds__(128) lev_bitpar_kernel(const BitparArgs a, con
       }
 #pragma unroll
       for (int q = 0; q < kChunk; ++q) {
-        unsigned hp, hn;
+        unsigned hp = 0u, hn = 0u;
         if (ROW16) {
-          hp = (unsigned)__builtin_amdgcn_update_dpp(1, (int)hop, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
-          hn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hon, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
+          xp = (unsigned)__builtin_amdgcn_update_dpp((int)xp, (int)Phw, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
+          xm = (unsigned)__builtin_amdgcn_update_dpp((int)xm, (int)Mhw, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
         } else {
           hp = (unsigned)shr1((int)hop, 0);
           hn = (unsigned)shr1((int)hon, 0);
@@ -329,7 +346,8 @@ __global__ void __launch_bounds__(128) lev_bitpar_kernel(const BitparArgs a, con
         }
         const int j = s0 + q - b;
         if (!GUARDED || (unsigned)j < (unsigned)y_len) {
-          step(eq[q], hp, hn);
+          if (ROW16) step16(eq[q]);
+          else step(eq[q], hp, hn);
         }
       }
     }
