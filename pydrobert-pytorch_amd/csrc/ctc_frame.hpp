@@ -103,6 +103,7 @@ struct FrameLds {
   // c < K + K'; ctc_frame completes it when a frame needs more) and the slot header to record that
   int list_len;
   float *hdr;
+  int2 *trie_u = nullptr;  // trie form: this utterance's records, trie + n * T * W (wave-uniform)
   static __host__ __device__ size_t bytes(int V, int W, int Kp, bool dense) {
     const int RS = W > Kp ? W : Kp;
     size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)(dense ? Kp : 1) * PDT_WAVE * 8;
@@ -645,7 +646,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   nw.node = !is_valid ? -1 : (is_ext ? t * W + lane : node_s);
   if (!DENSE) nw.origin = shfl_i(bm.origin, srcl);
   if (!DENSE && is_valid && is_ext)
-    a.trie[((int64_t)n * a.T + t) * W + lane] = make_int2(node_s, new_tok);
+    // (uniform base + 32-bit byte offset: T * W * 8 < 2^32 is checked on the host.  The full
+    // 64-bit index was ~20 scalar instructions and five reloads of spilled scalars per frame.)
+    *reinterpret_cast<int2 *>(reinterpret_cast<char *>(L.trie_u) + (unsigned)(t * W + lane) * 8u) = make_int2(node_s, new_tok);
 
   PDT_STAMP(4);
   // ---- is-prefix relation and next-token table of the new beam (:883-898) ---------------

@@ -132,11 +132,11 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 // INREG (P = 1 only): the whole row, V + 1 <= 512 elements, sits in the eight prefetch registers
 // of the producer's lanes; longer rows take the generic LDS-staged row pass of the P > 1 forms.
 // GROW (generic row pass): rows no LDS ring can hold -- see RingLayout::row_global.
-#ifndef PDT_CTC_SGPRS
-#define PDT_CTC_SGPRS 80
-#endif
+// (No amdgpu_num_sgpr: eight waves per SIMD cap the register-resident form at 80 scalar registers
+// by themselves -- 96 admit seven waves, measured 2.65 against 2.14 ms -- and the long-row forms,
+// four waves per SIMD, may take the 102 there are: an explicit 80 cost them 92-118 scalar spills.)
 template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
-__global__ void __launch_bounds__(256, INREG ? 8 : 4) __attribute__((amdgpu_num_sgpr(PDT_CTC_SGPRS)))
+__global__ void __launch_bounds__(256, INREG ? 8 : 4)
 ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
   static_assert(!GROW || !INREG, "rows in the workspace are a form of the generic row pass");
@@ -486,6 +486,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #endif
   FrameLds L;
   L.surv = surv;  // unused by the shared-list form
+  L.trie_u = a.trie + (int64_t)n * a.T * W;
   L.nxt_old = reinterpret_cast<int *>(cs);  // 8-byte aligned: nxt_new doubles as u64 scratch
   L.nxt_new = L.nxt_old + nxt_stride(W);
   L.chm = reinterpret_cast<unsigned *>(L.nxt_new + nxt_stride(W));
