@@ -396,7 +396,7 @@ def test_beam_search_advance_gradients(device):
     """log_probs_next carries gradients to log_probs_prev and log_probs_t exactly like the
     reference's graph (_decoding.py:121-131: sum, then top-k VALUES)."""
     rng = np.random.default_rng(3)
-    for N, Kp, V, W in [(3, 4, 9, 5), (2, 1, 6, 6), (4, 7, 30, 16), (2, 3, 2, 8)]:
+    for N, Kp, V, W in [(3, 4, 9, 5), (2, 1, 6, 6), (4, 7, 30, 16), (2, 3, 2, 8), (2, 70, 11, 80), (2, 3, 90, 66)]:  # (the last two: wider than a wave)
         lpt = torch.from_numpy(rng.normal(size=(N, Kp, V)).astype(np.float32)).log_softmax(-1)
         lpp = torch.from_numpy(rng.normal(size=(N, Kp)).astype(np.float32))
         yp = torch.from_numpy(rng.integers(0, V, (2, N, Kp)))
@@ -419,7 +419,7 @@ def test_ctc_prefix_search_advance_gradients(device):
     from oracle import torch_cpu as tc
 
     rng = np.random.default_rng(5)
-    for V, W in [(4, 3), (6, 5), (3, 6), (9, 4)]:
+    for V, W in [(4, 3), (6, 5), (3, 6), (9, 4), (40, 34)]:  # (34 prefixes: the plain workgroup form of the step)
         N = 3
         nb, b = torch.zeros(N, 1), torch.ones(N, 1)
         y = torch.zeros((0, N, 1), dtype=torch.long)
