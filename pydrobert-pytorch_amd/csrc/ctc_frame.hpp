@@ -396,7 +396,12 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // list.  As a loop the second pass made the first one's values loop-carried, and the spills
   // landed in every frame's state update.)
   auto full_tiers = [&](const bool list_done) -> bool {
-  const int G = Kp <= 16 ? 16 : 32, GS = Kp <= 16 ? 4 : 5, R = PDT_WAVE >> GS;
+  // (laundered: otherwise these are the lean tier's values kept alive -- four scalar spills
+  // written in every frame for the 3 % that get here)
+  int Kp_f = Kp;
+  asm volatile("" : "+s"(Kp_f));
+  const int G = Kp_f <= 16 ? 16 : 32, GS = Kp_f <= 16 ? 4 : 5, R = PDT_WAVE >> GS;
+  const int M = min(V, K + Kp_f);  // (shadows the frame's M for the same reason)
   const int kb = lane & (G - 1), rr = lane >> (G == 16 ? 4 : 5);  // (a shift, not a division by a runtime G)
   const int ksrc = kb < Kp ? kb : 0;
   const bool kvalid = kb < Kp && (shfl_i((int)valid_beam, ksrc) != 0);
