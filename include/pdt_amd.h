@@ -58,6 +58,8 @@ int pdt_amd_abi_version(void);
  *   aligned, contents irrelevant.  With it, unit (i.e. uniform) costs run on the bit-parallel
  *   kernels of lev_bitpar.hip; without it (NULL / too small), or when that function returns 0
  *   (a hypothesis longer than 1024 tokens), on the cell-by-cell kernels.  Same results.
+ *   Cost semantics with costs that are NOT exact in float32 and R > 2048 need the workspace (the
+ *   plain workgroup kernel of lev_generic.hip keeps its rows there): PDT_E_TOO_LONG without it.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N);
 
@@ -94,7 +96,8 @@ int pdt_fill_after_eos(const int64_t *tokens, int64_t outer, int64_t L, int64_t 
  *     reference's `C = counts.max().item()` (:511).
  *     workspace: pdt_oc_mask_workspace_bytes(R, H, N) bytes -- 0 up to R = 2048 (the DP row lives in
  *     registers); longer references run a plain one-workgroup-per-utterance form whose rows, sort
- *     buffer and class ids live there (costs exact in float32 only).
+ *     buffer and class ids live there (costs that are not exact in float32 replay the reference's
+ *     unrolled deletion term by term there as well, O(R^2) per row).
  * Phase 2, pdt_oc_expand (after the caller has read max_count and allocated targets):
  *     targets[h * tgt_sh + n * tgt_sn + i], i < C, ascending tokens then `padding`.
  * ------------------------------------------------------------------------------------- */

@@ -2,13 +2,18 @@
 // (reference _string.py:464-517 has no such bound): the same class bitmasks and class-token
 // tables, from a plain formulation -- ONE WORKGROUP per utterance, the DP rows, the sort buffer and
 // the class ids in a global workspace (pdt_oc_mask_workspace_bytes), workgroup barriers between
-// the phases of a row.  A way to get an answer, not a fast one (~10 us per DP row and utterance);
-// costs must be exact in float32 (the inexact-cost replay of lev_rowsync.hip stays bounded).
+// the phases of a row.  A way to get an answer, not a fast one (~10 us per DP row and utterance).
+// The same kernel serves the cost-mode DISTANCES for such references when the costs are not exact
+// in float32 (the other cost sets take lev_skewed.hip at any length): bitmask == nullptr, the
+// value of column ref_len of every row is what comes out.
 //
 // Per row h:  t[c] = min(prev[c] + ins, prev[c-1] + sub * [ref[c-1] != hyp[h-1]])   (:293, :316)
 //             row[c] = min_k<=c (t[k] + (c - k) * del)                               (:264-266, :317)
-// as a prefix minimum of t[k] - k * del (exact for such costs), then the row minimum and the class
-// bits of the columns that attain it (:333-334, :347-355), OR-ed into the bitmask row in HBM.
+// as a prefix minimum of t[k] - k * del when the costs are exact in float32; otherwise (inexact = 1)
+// the reference's unrolled form term by term, row[c] = min_k<=c ((row0[c] - row0[k]) + t[k]) with
+// row0[k] = float(k) * del, O(R^2) per row like lev_rowsync.hip's EXACT path.  Then the row minimum
+// and the class bits of the columns that attain it (:333-334, :347-355), OR-ed into the bitmask row
+// in HBM.
 #include "lev_common.hpp"
 
 namespace pdt {
@@ -18,14 +23,16 @@ struct GenericOcArgs {
   unsigned char *ws;
   int64_t ws_per_utt;
   int P;  // sort capacity: a power of two >= R
+  int inexact;  // replay the reference's deletion unroll term by term
 };
 
 int64_t generic_oc_ws_per_utt(int64_t R, int64_t H, int *P_out) {
   int P = 2;
   while (P < R) P <<= 1;
   if (P_out) *P_out = P;
-  // sort buffer, class of every reference position, class of every hypothesis position, two rows
-  int64_t b = (int64_t)P * 8 + (R + 1) * 4 + (H + 1) * 4 + 2 * (R + 2) * 4;
+  // sort buffer, class tokens (distance mode has no caller's table), class of every reference
+  // position, class of every hypothesis position, three rows, the per-row distances
+  int64_t b = (int64_t)P * 8 + (R + 1) * 8 + (R + 1) * 4 + (H + 1) * 4 + 3 * (R + 2) * 4 + (H + 2) * 4;
   return (b + 255) & ~(int64_t)255;
 }
 
@@ -66,11 +73,14 @@ __global__ void __launch_bounds__(kGenThreads) oc_mask_generic_kernel(const Gene
   const int R = a.R, H = a.H, W = a.W, P = g.P;
   unsigned char *w = g.ws + n * g.ws_per_utt;
   int64_t *srt = reinterpret_cast<int64_t *>(w);
-  int *rid = reinterpret_cast<int *>(srt + P);      // [R + 1]
-  int *hcls = rid + (R + 1);                         // [H + 1]
+  int64_t *ctok_ws = srt + P;                               // [R + 1]
+  int *rid = reinterpret_cast<int *>(ctok_ws + (R + 1));    // [R + 1]
+  int *hcls = rid + (R + 1);                                // [H + 1]
   float *rowA = reinterpret_cast<float *>(hcls + (H + 1));  // [R + 2]
-  float *rowB = rowA + (R + 2);
-  int64_t *ctok = a.class_tokens + n * (int64_t)R;
+  float *rowB = rowA + (R + 2), *rowC = rowB + (R + 2);
+  float *bnd = rowC + (R + 2);                              // [H + 2] distance mode: D[h][ref_len]
+  const bool mask_mode = a.bitmask != nullptr;
+  int64_t *ctok = mask_mode ? a.class_tokens + n * (int64_t)R : ctok_ws;
   const int64_t roff = n * a.ref_sn, hoff = n * a.hyp_sn;
   auto ref_at = [&](int i) { return a.ref[(int64_t)i * a.ref_st + roff]; };
   auto hyp_at = [&](int i) { return a.hyp[(int64_t)i * a.hyp_st + hoff]; };
@@ -153,13 +163,14 @@ __global__ void __launch_bounds__(kGenThreads) oc_mask_generic_kernel(const Gene
 
   // ---- row 0 and its set: only column 0 exists (:271-278) -------------------------------------
   const float ins = a.ins, del = a.del, sub = a.sub;
-  float *prev = rowA, *cur = rowB;
+  float *prev = rowA, *cur = rowB, *nxt = rowC;
   for (int c = tid; c <= ref_len; c += kGenThreads) prev[c] = (float)c * del;
-  uint32_t *brow = a.bitmask + ((int64_t)0 * a.N + n) * W;
-  for (int i = tid; i < W; i += kGenThreads) brow[i] = 0u;
+  uint32_t *brow = mask_mode ? a.bitmask + ((int64_t)0 * a.N + n) * W : nullptr;
+  if (mask_mode)
+    for (int i = tid; i < W; i += kGenThreads) brow[i] = 0u;
   __syncthreads();
   int max_cnt = 0;
-  if (ref_len > 0) {
+  if (mask_mode && ref_len > 0) {
     if (tid == 0) brow[rid[0] >> 5] = 1u << (rid[0] & 31);
     max_cnt = 1;
   }
@@ -167,48 +178,99 @@ __global__ void __launch_bounds__(kGenThreads) oc_mask_generic_kernel(const Gene
   const int cper = (ref_len + 1 + kGenThreads - 1) / kGenThreads, c0 = tid * cper;
   for (int h = 1; h <= Heff; ++h) {
     const int tok = hcls[h - 1];
-    brow = a.bitmask + ((int64_t)h * a.N + n) * W;
-    for (int i = tid; i < W; i += kGenThreads) brow[i] = 0u;
-    // t[c] - c * del over this thread's columns, and their running minimum
-    float run = PDT_INF;
-    for (int q = 0; q < cper; ++q) {
-      const int c = c0 + q;
-      if (c > ref_len) break;
-      float t = prev[c] + ins;
-      if (c > 0) t = fminf(t, prev[c - 1] + ((rid[c - 1] != tok) ? sub : 0.0f));
-      run = fminf(run, t - (float)c * del);
-      cur[c] = run;  // (prefix minimum inside the piece; the pieces before it are folded in below)
+    if (mask_mode) {
+      brow = a.bitmask + ((int64_t)h * a.N + n) * W;
+      for (int i = tid; i < W; i += kGenThreads) brow[i] = 0u;
     }
-    fred[tid] = run;
-    __syncthreads();
-    float carry = PDT_INF;
-    for (int t = 0; t < tid; ++t) carry = fminf(carry, fred[t]);
-    __syncthreads();
     float m = PDT_INF;
-    for (int q = 0; q < cper; ++q) {
-      const int c = c0 + q;
-      if (c > ref_len) break;
-      const float v = fminf(cur[c], carry) + (float)c * del;
-      cur[c] = v;
-      m = fminf(m, v);
+    float *row;  // the finished row h
+    if (g.inexact) {
+      // t into `cur`, then every column's minimum over the columns at or before it, in the
+      // reference's own arithmetic: (row0[c] - row0[k]) + t[k]
+      for (int q = 0; q < cper; ++q) {
+        const int c = c0 + q;
+        if (c > ref_len) break;
+        float t = prev[c] + ins;
+        if (c > 0) t = fminf(t, prev[c - 1] + ((rid[c - 1] != tok) ? sub : 0.0f));
+        cur[c] = t;
+      }
+      __syncthreads();
+      for (int c = tid; c <= ref_len; c += kGenThreads) {  // (interleaved: the work per column grows with c)
+        const float rc = (float)c * del;
+        float best = PDT_INF;
+        for (int k = 0; k <= c; ++k) best = fminf(best, (rc - (float)k * del) + cur[k]);
+        nxt[c] = best;
+        m = fminf(m, best);
+      }
+      row = nxt;
+    } else {
+      // t[c] - c * del over this thread's columns, and their running minimum
+      float run = PDT_INF;
+      for (int q = 0; q < cper; ++q) {
+        const int c = c0 + q;
+        if (c > ref_len) break;
+        float t = prev[c] + ins;
+        if (c > 0) t = fminf(t, prev[c - 1] + ((rid[c - 1] != tok) ? sub : 0.0f));
+        run = fminf(run, t - (float)c * del);
+        cur[c] = run;  // (prefix minimum inside the piece; the pieces before it are folded in below)
+      }
+      fred[tid] = run;
+      __syncthreads();
+      float carry = PDT_INF;
+      for (int t = 0; t < tid; ++t) carry = fminf(carry, fred[t]);
+      __syncthreads();
+      for (int q = 0; q < cper; ++q) {
+        const int c = c0 + q;
+        if (c > ref_len) break;
+        const float v = fminf(cur[c], carry) + (float)c * del;
+        cur[c] = v;
+        m = fminf(m, v);
+      }
+      row = cur;
     }
-    m = block_min(m, fred);  // (its barriers also order the zeroing of the bitmask row)
-    for (int q = 0; q < cper; ++q) {
-      const int c = c0 + q;
-      if (c >= ref_len) break;  // the r < ref_len cut of :349-354
-      if (cur[c] == m) atomicOr(&brow[rid[c] >> 5], 1u << (rid[c] & 31));
+    m = block_min(m, fred);  // (its barriers also order the row's writes and the zeroing of the bitmask row)
+    if (mask_mode) {
+      for (int c = tid; c < ref_len; c += kGenThreads)  // the r < ref_len cut of :349-354
+        if (row[c] == m) atomicOr(&brow[rid[c] >> 5], 1u << (rid[c] & 31));
+      __syncthreads();
+      int cnt = 0;
+      for (int i = tid; i < W; i += kGenThreads) cnt += __popc(brow[i]);
+      cnt = block_sum(cnt, ired);
+      max_cnt = cnt > max_cnt ? cnt : max_cnt;
+    } else if (tid == 0) {
+      bnd[h] = row[ref_len];
     }
+    // rotate: the finished row becomes `prev`; the old `prev` is free
+    if (g.inexact) {
+      float *tmp = prev;
+      prev = nxt;
+      nxt = tmp;
+    } else {
+      float *tmp = prev;
+      prev = cur;
+      cur = tmp;
+    }
+  }
+  if (!mask_mode) {  // cost-mode distances (the epilogue of lev_rowsync.hip)
     __syncthreads();
-    int cnt = 0;
-    for (int i = tid; i < W; i += kGenThreads) cnt += __popc(brow[i]);
-    cnt = block_sum(cnt, ired);
-    max_cnt = cnt > max_cnt ? cnt : max_cnt;
-    float *tmp = prev;
-    prev = cur;
-    cur = tmp;
+    const float r0 = (float)ref_len * del;
+    if (a.mode == PDT_MODE_FINAL) {
+      if (tid == 0)
+        a.out[n * a.out_sn] = lev_finish(Heff > 0 ? bnd[Heff] : r0, a.mult, a.norm, ref_len, hyp_len > 0 ? 1.0f : 0.0f);
+    } else {
+      const int pad_from = hyp_len + (a.exclude_last ? 0 : 1);
+      for (int h = tid; h < Hout; h += kGenThreads) {
+        float v;
+        if (h >= pad_from)
+          v = a.padding;
+        else
+          v = lev_finish(h == 0 ? r0 : bnd[h], a.mult, a.norm, ref_len, h > 0 ? 1.0f : 0.0f);
+        a.out[(int64_t)h * a.out_sh + n * a.out_sn] = v;
+      }
+    }
   }
   // rows of finished hypotheses carry empty sets (`& not_done`, :334)
-  for (int h = Heff + 1; h < Hout; ++h) {
+  for (int h = Heff + 1; h < Hout && mask_mode; ++h) {
     brow = a.bitmask + ((int64_t)h * a.N + n) * W;
     for (int i = tid; i < W; i += kGenThreads) brow[i] = 0u;
   }
@@ -216,6 +278,7 @@ __global__ void __launch_bounds__(kGenThreads) oc_mask_generic_kernel(const Gene
     int flags = 0;
     if (rmiss) flags |= PDT_WARN_REF_NO_EOS;
     if (hmiss) flags |= PDT_WARN_HYP_NO_EOS;
+    if (!mask_mode && a.norm && ref_len == 0) flags |= PDT_WARN_EMPTY_REF;
     if (flags && a.status) atomicOr(a.status, flags);
     if (a.max_count && max_cnt > 0) atomicMax(a.max_count, max_cnt);
     if (a.ref_lens_out) a.ref_lens_out[n] = ref_len;
@@ -252,9 +315,10 @@ oc_expand_generic_kernel(const uint32_t *__restrict__ bitmask, const int64_t *__
   for (int i = total + lane; i < C; i += PDT_WAVE) dst[i] = padding;
 }
 
-int launch_oc_mask_generic(const LevArgs &a, void *ws, int64_t ws_bytes, hipStream_t stream) {
+int launch_oc_mask_generic(const LevArgs &a, bool inexact, void *ws, int64_t ws_bytes, hipStream_t stream) {
   GenericOcArgs g{};
   g.l = a;
+  g.inexact = inexact ? 1 : 0;
   g.ws_per_utt = generic_oc_ws_per_utt(a.R, a.H, &g.P);
   if (!ws || ws_bytes < g.ws_per_utt * a.N) return PDT_E_TOO_LONG;  // (no workspace: the bounded kernels only)
   g.ws = reinterpret_cast<unsigned char *>(ws);

@@ -2,6 +2,7 @@
 // the host-side part of _string_matching's preamble (uniform-cost shortcut,
 // reference _string.py:168-174) and kernel selection.  No allocation, no synchronisation.
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 
 #include "lev_common.hpp"
@@ -10,7 +11,7 @@ namespace pdt {
 int launch_lev_skewed(LevArgs a, hipStream_t stream);
 int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream);
 int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream);
-int launch_oc_mask_generic(const LevArgs &a, void *ws, int64_t ws_bytes, hipStream_t stream);
+int launch_oc_mask_generic(const LevArgs &a, bool inexact, void *ws, int64_t ws_bytes, hipStream_t stream);
 int launch_oc_expand_generic(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
                              int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
                              int64_t tgt_sn, hipStream_t stream);
@@ -76,9 +77,16 @@ extern "C" {
 int pdt_amd_abi_version(void) { return 4; }
 
 int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {
-  if (R < 0 || H < 0 || N <= 0 || !pdt::bitpar_enabled()) return 0;
-  const pdt::BitparPlan p = pdt::plan_bitpar(H, R, N);
-  return p.ok ? (int64_t)p.total : 0;
+  if (R < 0 || H < 0 || N <= 0) return 0;
+  int64_t need = 0;
+  if (pdt::bitpar_enabled()) {
+    const pdt::BitparPlan p = pdt::plan_bitpar(H, R, N);
+    if (p.ok) need = (int64_t)p.total;
+  }
+  // references beyond the row-synchronous kernel's 2048 columns: costs that are inexact in float32
+  // take the plain workgroup kernel (lev_generic.hip), whose rows live in the workspace
+  if (R > 64 * 32) need = std::max(need, pdt::generic_oc_ws_per_utt(R, H, nullptr) * N);
+  return need;
 }
 
 int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
@@ -110,8 +118,10 @@ int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const
   a.padding = padding;
   a.out = out; a.out_sh = out_sh; a.out_sn = out_sn;
   a.ref_lens_out = ref_lens_out; a.hyp_lens_out = hyp_lens_out; a.status = status;
-  if (!return_mistakes && !costs_exact_in_f32(ins_cost, del_cost, sub_cost, R, H))
+  if (!return_mistakes && !costs_exact_in_f32(ins_cost, del_cost, sub_cost, R, H)) {
+    if (R > 64 * 32) return launch_oc_mask_generic(a, /*inexact=*/true, workspace, workspace_bytes, (hipStream_t)stream);
     return launch_lev_rowsync(a, /*exact=*/true, (hipStream_t)stream);
+  }
   if (!return_mistakes && ins_cost == 1.0f && del_cost == 1.0f && sub_cost == 1.0f && workspace &&
       bitpar_enabled()) {
     const BitparPlan p = plan_bitpar(H, R, N);
@@ -152,8 +162,7 @@ int pdt_oc_mask(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, c
   a.W = (int)pdt_oc_mask_words(R);
   const bool exact = !costs_exact_in_f32(ins_cost, del_cost, sub_cost, R, H);
   if (a.W > 64) {  // beyond the 2048 columns the row-synchronous kernel holds: the plain formulation
-    if (exact) return PDT_E_TOO_LONG;
-    return launch_oc_mask_generic(a, workspace, workspace_bytes, (hipStream_t)stream);
+    return launch_oc_mask_generic(a, exact, workspace, workspace_bytes, (hipStream_t)stream);
   }
   return launch_lev_rowsync(a, exact, (hipStream_t)stream);
 }

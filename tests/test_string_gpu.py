@@ -290,7 +290,8 @@ def test_optimal_completion_long_reference(device):
 def test_optimal_completion_beyond_the_register_rows(device, R, V):
     """References longer than 2048 tokens run the plain one-workgroup-per-utterance form
     (csrc/lev_generic.hip): class bitmasks wider than a wave, the generic expansion; ragged
-    lengths, batch-first layout, costs that are exact in float32.  Inexact costs still raise."""
+    lengths, batch-first layout, costs that are exact in float32 and (up to R = 3000: the replay is
+    O(R^2) per row in the oracle too) costs that are not."""
     rng = np.random.default_rng(R)
     N, H = 3, 37
     ref = rng.integers(0, V, (R, N))
@@ -304,9 +305,32 @@ def test_optimal_completion_beyond_the_register_rows(device, R, V):
         act = F.optimal_completion(torch.from_numpy(r).to(device), torch.from_numpy(h).to(device),
                                    warn=False, **kw).cpu().numpy()  # fmt: skip
         assert exp.shape == act.shape and np.array_equal(exp, act), kw
-    with pytest.raises(RuntimeError, match="too long|limit|supported"):
-        F.optimal_completion(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device), warn=False,
-                             ins_cost=0.1, del_cost=0.7, sub_cost=1.3)  # fmt: skip
+    if R <= 3000:  # costs that are NOT exact in float32: the reference's unrolled deletion, term by term
+        kw = dict(eos=V, ins_cost=0.1, del_cost=0.7, sub_cost=1.3)
+        exp = oracle.optimal_completion(ref, hyp, **kw)
+        act = F.optimal_completion(torch.from_numpy(ref).to(device), torch.from_numpy(hyp).to(device), warn=False, **kw)
+        assert exp.shape == tuple(act.shape) and np.array_equal(exp, act.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["edit_distance", "prefix_edit_distances", "error_rate"])
+def test_inexact_costs_beyond_the_register_rows(device, name):
+    """Cost-mode distances with costs that are inexact in float32 and a reference of more than 2048
+    tokens: the plain workgroup kernel replays the reference's arithmetic (csrc/lev_generic.hip).
+    (error_rate counts mistakes for such costs: the cell-by-cell kernel, at any length.)"""
+    rng = np.random.default_rng(len(name))
+    R, H, N, V = 2300, 29, 3, 6
+    ref, hyp = rng.integers(0, V, (R, N)), rng.integers(0, V, (H, N))
+    ref[R - 200, 0] = V
+    hyp[17, 1] = V
+    for kw in (dict(eos=V, ins_cost=0.1, del_cost=0.7, sub_cost=1.3),
+               dict(eos=V, include_eos=False, ins_cost=0.3, del_cost=0.1, sub_cost=0.2, norm=True),
+               dict(ins_cost=0.1, del_cost=0.7, sub_cost=1.3, batch_first=True)):  # fmt: skip
+        if name == "prefix_edit_distances":
+            kw = dict(kw, exclude_last=bool(kw.get("norm", False)))
+        r, h = (ref.T.copy(), hyp.T.copy()) if kw.get("batch_first") else (ref, hyp)
+        exp = getattr(oracle, name)(r, h, **kw)
+        act = getattr(F, name)(torch.from_numpy(r).to(device), torch.from_numpy(h).to(device), warn=False, **kw)
+        assert exp.shape == tuple(act.shape) and np.array_equal(exp, act.cpu().numpy(), equal_nan=True), (name, kw)
 
 
 def test_fill_after_eos(device):
