@@ -534,8 +534,16 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     // a tie artefact, and nothing is left to decide -- the beam stays as it is.  (float32
     // probability-space masses get there after a few hundred frames of p_max ~ 0.5, or ~1000 of
     // p_max ~ 0.9; without this exit each such frame runs the full tiers on a beam of zeros.)
-    const bool dead = readlane_f(bm.nb + bm.b, 0) == 0.0f;
-    const bool enough = dead || ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+    // (one branch, everything that depends on it inside: kept across the frame as a flag it is a
+    // scalar pair spilled to lanes and read back every frame)
+    bool enough = true;
+    if (!(readlane_f(bm.nb + bm.b, 0) == 0.0f)) {
+      enough = ctc_frame<false>(bm, slot_row(sl), s, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt, nk PDT_STAMP_ARG);
+      int *tmp = L.nxt_old;  // (a skipped frame leaves the next-token tables where they are)
+      L.nxt_old = L.nxt_new;
+      L.nxt_new = tmp;
+      Kp = W;
+    }
     // feedback to the producers: a complete selection costs the producer about what two list
     // completions cost this wave, so the balance is at one completed list in two frames: +1
     // per frame this wave had to complete a short list, -1 per frame it did not (0 .. 32);
@@ -548,13 +556,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     }
 #else
     ns = nt = nk = 0; (void)s;
+    Kp = W;
 #endif
-    if (!dead) {  // (a skipped frame leaves the next-token tables where they are)
-      int *tmp = L.nxt_old;
-      L.nxt_old = L.nxt_new;
-      L.nxt_new = tmp;
-      Kp = W;
-    }
     if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
       const int c = ((t + 1) >> a.ckpt_shift) - 1;
