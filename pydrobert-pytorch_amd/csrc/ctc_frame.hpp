@@ -675,6 +675,10 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   if (is_valid) {
     unsigned cand = 0u;
     for (unsigned m = isp_s; m; m &= m - 1u) cand |= L.chm[__builtin_ctz(m)];
+    // (an entry is a prefix of itself and never its own strict prefix: one iteration less for every
+    // lane, i.e. for the wave -- ~26 instructions of the ~300 a lean frame takes)
+    cand &= ~(1u << lane);
+    isp_new = 1u << lane;
     while (cand) {
       const int b = __builtin_ctz(cand);
       cand &= cand - 1u;
