@@ -548,7 +548,10 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
     // completions cost this wave, so the balance is at one completed list in two frames: +1
     // per frame this wave had to complete a short list, -1 per frame it did not (0 .. 32);
     // complete lists above 16, short ones again below 4
-    fail_score = enough ? max(fail_score - 1, 0) : min(fail_score + 1, 32);
+    // (through a scalar: `enough` is wave-uniform but arrives as a lane mask, and the counter and
+    // mode below would live in vector registers -- a dozen vector instructions per frame)
+    const int enough_s = __builtin_amdgcn_readfirstlane(enough ? 1 : 0);
+    fail_score = enough_s ? max(fail_score - 1, 0) : min(fail_score + 1, 32);
     const int wf = fail_score > 16 ? 1 : (fail_score < 4 ? 0 : full_mode);
     if (wf != full_mode) {
       full_mode = wf;
