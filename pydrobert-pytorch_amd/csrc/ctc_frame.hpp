@@ -229,8 +229,16 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     } else {
       for (int j = 0; j < M; ++j) jl = mt[j] == lastc ? j : jl;
     }
-    avail = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
-    if (jl >= 0) avail &= ~(1ull << jl);
+    if (!DENSE && M <= 32) {
+      // (32 entries at most: the position byte shifts the bit in directly -- 0xFF, "not listed",
+      // lands in bit 63 and falls off the low word -- instead of a 64-bit mask, a compare and
+      // two selects per frame)
+      const unsigned q = L.pos[lastc];
+      avail = (c >= 32 ? ~0u : ((1u << c) - 1u)) & ~(unsigned)(1ull << (q & 63u));
+    } else {
+      avail = c >= 64 ? ~0ull : ((1ull << c) - 1ull);
+      if (jl >= 0) avail &= ~(1ull << jl);
+    }
     u64 par = __ballot(live && (bm.isp & ~(1u << lane)) != 0u);
     while (par) {
       const int kk = (int)__builtin_ctzll(par);
