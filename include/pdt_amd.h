@@ -151,8 +151,8 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *          (the prefix trie: one (parent, token) record per frame and beam entry, the
  *          checkpoints of the output walk and, for rows beyond the LDS, the rows of the ring).
  *   width <= 32 (wider beams: one pdt_ctc_prefix_search_advance per frame).  S must be at least min(T, max lens): frames beyond S are not decoded.
- *   Rows of up to about 16 000 tokens live in LDS (one row of probabilities per ring slot);
- *   longer ones stay in the workspace (L2-resident), any V below 2^30.
+ *   Rows of up to about 10 000 tokens live in LDS (one row of probabilities per slot of a
+ *   three-slot ring); longer ones stay in the workspace (L2-resident), any V below 2^30.
  * pdt_ctc_prefix_search_plan (host only, no device work): the launch configuration the library
  *   picks for rows of V tokens and this width -- plan4 = {producer waves per utterance, ring
  *   slots, utterances per workgroup, where a row is held: 1 the producer's registers, 0 LDS,

@@ -65,9 +65,12 @@ def fill_after_eos(tokens, eos, dim=0, fill=None, value=None):
     """_string.py:30-42: positions strictly after the first eos along dim take the fill value
     (default: eos), converted to the dtype of the tensor being filled."""
     tok = _np(tokens)
-    out = (tok if value is None else _np(value)).copy()
+    out = tok if value is None else _np(value)
     hit = tok == eos
-    seen = np.cumsum(hit, axis=dim) - hit  # eos occurrences at earlier positions
+    seen = np.cumsum(hit, axis=dim) - hit  # eos occurrences at earlier positions (dim: of the TOKENS)
     fill_ = float(eos) if fill is None else fill
-    out[np.broadcast_to(seen > 0, out.shape)] = np.asarray(fill_).astype(out.dtype)
+    # masked_fill broadcasts the mask and the filled tensor against each other
+    shape = np.broadcast_shapes(out.shape, seen.shape)
+    out = np.broadcast_to(out, shape).copy()
+    out[np.broadcast_to(seen > 0, shape)] = np.asarray(fill_).astype(out.dtype)
     return out

@@ -646,12 +646,12 @@ static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream
 }
 
 // checkpoint spacing: 32 frames, doubled until the (C + 1) x W table of the output walk fits in
-// the smallest ring any launch configuration uses (2 slots)
-__host__ inline int ckpt_shift_for(int T, int V, int W) {
-  size_t ring2 = (size_t)ring_layout(V, W, 2, 1, 1).slot_bytes * 2;
-  if (ring2 > 160 * 1024) ring2 = (size_t)ring_layout(V, W, 2, 1, 1, true).slot_bytes * 2;  // rows in the workspace
+// the ring of the launch configuration that will run (the table overlays the freed ring, and the
+// ring of the workspace-row form is only nstage x 8 KiB)
+__host__ inline int ckpt_shift_for(int T, int W, const RingLayout &rl) {
+  const size_t ring = (size_t)rl.slot_bytes * rl.nstage;
   int sh = 5;
-  while (((size_t)(T >> sh) + 1) * W * sizeof(int2) > ring2) ++sh;
+  while (((size_t)(T >> sh) + 1) * W * sizeof(int2) > ring) ++sh;
   return sh;
 }
 
@@ -694,11 +694,7 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
   return *plan = CtcPlan{1, nstage, upw, 1}, PDT_OK;
 }
 
-int launch_ctc_search(CtcArgs a, hipStream_t stream) {
-  CtcPlan plan;
-  RingLayout rl;
-  const int rc = plan_ctc_search(a.V, a.W, &plan, &rl);
-  if (rc != PDT_OK) return rc;
+int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &rl, hipStream_t stream) {
   if (plan.inreg == 2) return launch_ctc_search_p<3, -1, false, true>(a, rl, stream);
   if (plan.producers == 3) return launch_ctc_search_p<3>(a, rl, stream);
   if (a.V / PDT_WAVE == 4) return launch_ctc_search_p<1, 4>(a, rl, stream);
@@ -754,9 +750,13 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   a.trie = reinterpret_cast<int2 *>(workspace);
   a.ckpt = a.trie + T * N * width;
   a.grow = reinterpret_cast<unsigned char *>(workspace) + ctc_trie_bytes(T, N, width);
-  a.ckpt_shift = pdt::ckpt_shift_for((int)T, (int)V, (int)width);
+  CtcPlan plan;
+  RingLayout rl;
+  const int rc = plan_ctc_search(a.V, a.W, &plan, &rl);
+  if (rc != PDT_OK) return rc;
+  a.ckpt_shift = ckpt_shift_for((int)T, (int)width, rl);
   a.ckpt_count = (int)(T >> a.ckpt_shift) + 1;
-  return launch_ctc_search(a, (hipStream_t)stream);
+  return launch_ctc_search(a, plan, rl, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -511,8 +511,13 @@ class CTCPrefixSearch(torch.nn.Module):
         self,
         logits: torch.Tensor,
         lens: Optional[torch.Tensor] = None,
+        prev_: Optional[Dict[str, torch.Tensor]] = None,
         initial_state: Optional[Dict[str, torch.Tensor]] = None,
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        # (``prev_`` is the reference's runtime keyword, _decoding.py:1064-1068; ``initial_state`` the
+        # name its documented call signature uses, :1053-1060 -- both are accepted)
+        if initial_state is None:
+            initial_state = prev_
         if logits.dim() != 3:
             raise RuntimeError("logits must be 3 dimensional")
         # The one-kernel search returns probabilities that are cut off from the graph.  When the
@@ -688,10 +693,15 @@ class BeamSearch(torch.nn.Module):
 
     def forward(
         self,
-        initial_state: Optional[Dict[str, torch.Tensor]] = None,
+        initial_state_: Optional[Dict[str, torch.Tensor]] = None,
         batch_size: Optional[int] = None,
         max_iters: Optional[int] = None,
+        initial_state: Optional[Dict[str, torch.Tensor]] = None,
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        # (``initial_state_`` is the reference's runtime keyword, _decoding.py:383-386;
+        # ``initial_state`` the name of its documented call signature -- both are accepted)
+        if initial_state is None:
+            initial_state = initial_state_
         prev = dict() if initial_state is None else initial_state
         device = self.device_buffer.device
         N = 1 if batch_size is None else batch_size
@@ -1086,10 +1096,15 @@ class RandomWalk(torch.nn.Module):
 
     def forward(
         self,
-        initial_state: Optional[Dict[str, torch.Tensor]] = None,
+        prev_: Optional[Dict[str, torch.Tensor]] = None,
         batch_size: Optional[int] = None,
         max_iters: Optional[int] = None,
+        initial_state: Optional[Dict[str, torch.Tensor]] = None,
     ):
+        # (``prev_``: the reference's runtime keyword, _decoding.py:1446-1449; ``initial_state``: its
+        # documented call signature -- both are accepted)
+        if initial_state is None:
+            initial_state = prev_
         prev = dict() if initial_state is None else initial_state
         device = self.device_buffer.device
         N = 1 if batch_size is None else batch_size

@@ -38,17 +38,22 @@ __all__ = [
 def _fill_after_eos_op(tokens: torch.Tensor, eos: int, dim: int, fill: float, value: torch.Tensor) -> torch.Tensor:
     """One walk along ``dim`` (reference _string.py:30-42; csrc/fill_after_eos.hip)."""
     device = _cabi.require_hip(tokens, value)
-    if value.shape != tokens.shape:  # masked_fill would broadcast; the reference's callers never do
-        value = value.expand(torch.broadcast_shapes(value.shape, tokens.shape))
-        tokens = tokens.expand(value.shape)
+    # `dim` indexes tokens' OWN shape: the reference runs cumsum(dim) on the tokens and lets
+    # masked_fill broadcast the finished mask against the value (_string.py:40-42)
     nd = tokens.dim()
     if nd == 0:
+        if dim not in (-1, 0):
+            raise IndexError("Dimension out of range (expected to be in range of [-1, 0], but got {})".format(dim))
         return value.clone()
     if dim < -nd or dim >= nd:
         raise IndexError(
             "Dimension out of range (expected to be in range of [{}, {}], but got {})".format(-nd, nd - 1, dim)
         )
     dim = dim % nd
+    if value.shape != tokens.shape:  # masked_fill would broadcast; the reference's callers never do
+        value = value.expand(torch.broadcast_shapes(value.shape, tokens.shape))
+        dim += value.dim() - nd  # leading dimensions the broadcast put in front of the tokens'
+        tokens = tokens.expand(value.shape)
     if tokens.dtype == torch.long:
         tok, eos_ = tokens.detach().contiguous(), int(eos)
     else:  # any dtype compares against eos the way ``tokens == eos`` does
@@ -211,7 +216,9 @@ def _string_matching_op(
         mode = _cabi.MODE_FINAL
     with torch.cuda.device(device):
         status = torch.zeros(1, device=device, dtype=torch.int32) if warn else None
-        ws, ws_bytes = _lev_workspace(R, H, N, device)
+        # (only the bit-parallel kernels -- uniform costs -- and the plain kernel for references
+        # beyond 2048 tokens read a workspace; every other call launches without one)
+        ws, ws_bytes = _lev_workspace(R, H, N, device) if (uniform or R > 2048) else (None, 0)
         rc = _cabi.lib().pdt_lev(
             _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
             int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),

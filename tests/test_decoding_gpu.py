@@ -104,6 +104,29 @@ def test_ctc_prefix_search_long_rows(device, V, K):
         _check_search(act, exp, (V, K, T, N, _ctc_plan(V, K)))
 
 
+def test_ctc_prefix_search_workspace_rows_long_input(device):
+    """Rows in the workspace (V beyond the three-slot LDS ring) with an input long enough that the
+    checkpoint table of the output walk, at 32-frame spacing, would not fit the 4 x 8 KiB ring of
+    that form: the spacing has to come from the ring the plan really uses."""
+    V, K, T, N = 10400, 32, 4300, 1
+    rc, plan = _ctc_plan(V, K)
+    assert rc == 0 and plan[3] == 2, plan
+    rng = np.random.default_rng(424242)
+    lg = _peaky_logits(rng, T, N, V, scale=19.0)  # p_peak ~ 0.9999: masses survive 4300 frames
+    tl = torch.from_numpy(lg).to(device)
+    act = F.ctc_prefix_search(tl, K)
+    # (the C oracle needs minutes at this size: the check is the frame-by-frame route -- dense
+    # histories, no trie, no checkpoints, itself pinned to the oracle by the tests above -- and
+    # the best path, which at this peakiness is the collapsed arg-max sequence)
+    exp = tuple(x.cpu().numpy() for x in M.CTCPrefixSearch(K)._frame_by_frame(tl, None, {}))
+    assert exp[1].max() > 4100  # prefixes nearly as long as the input: the walk crosses every checkpoint
+    _check_search(act, exp, (V, K, T, N, plan))
+    best = lg[:, 0].argmax(1)
+    keep = np.concatenate([[True], best[1:] != best[:-1]]) & (best != V)
+    y, yl = act[0].cpu().numpy(), act[1].cpu().numpy()
+    assert yl[0, 0] == keep.sum() and np.array_equal(y[: yl[0, 0], 0, 0], best[keep])
+
+
 def test_ctc_plan_covers_every_vocabulary():
     """Every row length has a configuration (rows beyond the LDS: plan[3] == 2, the workspace)."""
     for V in (1, 64, 65, 511, 512, 5000, 16000, 16200, 100000, 1 << 20):

@@ -49,6 +49,40 @@ def test_defaults_match_reference_signatures():
         "log_probs_t", "width", "log_probs_prev", "y_prev", "y_prev_lens"]  # fmt: skip
 
 
+def test_calls_written_against_the_reference_bind():
+    """tests/golden/signatures.json (made from the live reference by make_signatures.py) lists the
+    parameters of every mirrored function, Module constructor and ``forward``: each must exist
+    here under the same name, in the same positional order, with a default where the reference
+    has one -- so positional AND keyword calls written against the reference bind unchanged
+    (e.g. ``BeamSearch.forward(initial_state_=...)``, ``CTCPrefixSearch.forward(prev_=...)``)."""
+    import inspect
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "signatures.json")) as f:
+        sig = json.load(f)
+
+    def check(what, fn, ref_params):
+        fn = getattr(fn, "__wrapped__", fn)
+        mine = [p for p in inspect.signature(fn).parameters.values() if p.name != "self"]
+        names = [p.name for p in mine]
+        assert names[: len(ref_params)] == [r[0] for r in ref_params], (what, names, ref_params)
+        for p, (name, has_default, kind) in zip(mine, ref_params):
+            assert p.kind.name == kind, (what, name)
+            if has_default:
+                assert p.default is not inspect.Parameter.empty, (what, name)
+        for p in mine[len(ref_params):]:  # extras must not be required
+            assert p.default is not inspect.Parameter.empty or p.kind.name.startswith("VAR"), (what, p.name)
+
+    assert len(sig["functional"]) >= 22 and len(sig["modules"]) >= 27
+    for name, ref_params in sig["functional"].items():
+        check(name, getattr(F, name), ref_params)
+    for name, d in sig["modules"].items():
+        cls = getattr(M, name)
+        check(name + ".__init__", cls.__init__, d["__init__"])
+        check(name + ".forward", cls.forward, d["forward"])
+
+
 def test_argcheck_contract():
     assert argcheck.is_int(3, "x") == 3 and argcheck.is_float(2, "x") == 2.0
     assert argcheck.is_int(None, "x", True) is None

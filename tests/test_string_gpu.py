@@ -360,6 +360,17 @@ def test_fill_after_eos(device):
                 exp = oracle.fill_after_eos(tk, 2, dim, 3.0, v)
                 act = F.fill_after_eos(torch.from_numpy(tk).to(device), 2, dim, 3.0, torch.from_numpy(v).to(device))
                 assert act.dtype == torch.from_numpy(v).dtype and np.array_equal(act.cpu().numpy(), exp), (shape, dim, dt)
+    # tokens and value of different shapes: `dim` counts the TOKENS' dimensions (the reference's
+    # cumsum runs on the tokens; masked_fill then broadcasts the mask, _string.py:40-42)
+    for tshape, vshape in [((7,), (5, 7)), ((7,), (3, 5, 7)), ((5, 1), (5, 6)), ((4, 1, 6), (3, 6)), ((3, 6), (4, 1, 6))]:
+        tk = rng.integers(0, 3, tshape)
+        v = rng.normal(size=vshape).astype(np.float32)
+        for dim in range(-len(tshape), len(tshape)):
+            exp = oracle.fill_after_eos(tk, 2, dim, -1.0, v)
+            act = F.fill_after_eos(torch.from_numpy(tk).to(device), 2, dim, -1.0, torch.from_numpy(v).to(device))
+            assert np.array_equal(act.cpu().numpy(), exp), (tshape, vshape, dim)
+        with pytest.raises(IndexError):
+            F.fill_after_eos(torch.from_numpy(tk).to(device), 2, len(tshape), -1.0, torch.from_numpy(v).to(device))
     # non-int64 tokens and a strided (transposed) view
     tk = rng.integers(0, 4, (33, 9))
     tt = torch.from_numpy(np.ascontiguousarray(tk.T)).to(device).t()
