@@ -1,0 +1,101 @@
+// Pieces shared by the two forms of the fused CTC prefix search (ctc_search.hip: one consumer wave
+// per utterance; ctc_packed.hip: four utterances per consumer wave): tuning constants, the softmax
+// numerator, and the LDS ring slot that producer and consumer waves of an utterance share.
+#pragma once
+#include "ctc_frame.hpp"
+
+#ifndef PDT_SHORT_MIN  // window and target of the short lists' survivor count
+#define PDT_SHORT_MIN 8
+#define PDT_SHORT_LO 14
+#define PDT_SHORT_HI 26
+#define PDT_SHORT_PROBE 18
+#endif
+#ifndef PDT_SPIN_SLEEP
+#define PDT_SPIN_SLEEP 2
+#endif
+#ifndef PDT_UTT_PER_WG  // one-producer form: utterances per workgroup and ring depth (LDS permitting)
+#define PDT_UTT_PER_WG 2
+#define PDT_RING_STAGES 4
+#endif
+#ifndef PDT_CONSUMER_PRIO
+#define PDT_CONSUMER_PRIO 3
+#endif
+
+namespace pdt {
+
+// exp(x) for x <= 0 (softmax numerators): OCML's expf without its overflow / underflow guards --
+// the same hi/lo range reduction around v_exp_f32; v_ldexp_f32 flushes what underflows.
+// Arguments below -200 (masked vocabulary entries: -inf logits) are clamped first: the result
+// underflows to 0 either way, but -inf would turn the rounding-error term into inf - inf.
+__device__ __forceinline__ float exp_nonpos(float x) {
+  x = fmaxf(x, -200.0f);
+  const float t = x * 0x1.715476p+0f;                       // x * log2(e), rounded
+  const float lo = __builtin_fmaf(x, 0x1.715476p+0f, -t);   // its rounding error
+  const float n = __builtin_rintf(t);
+  const float f = (t - n) + __builtin_fmaf(x, 0x1.4ae0bep-26f, lo);  // + x * (log2(e) - fl(log2(e)))
+  return __builtin_ldexpf(__builtin_amdgcn_exp2f(f), (int)n);
+}
+
+// max of two floats without the input canonicalisation fmaxf() has to add for values that come
+// straight from memory (NaN logits are outside the contract either way)
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+  float r;
+  asm("v_max_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// two at a time: the multiplies / fmas / adds of the range reduction as packed fp32 (one
+// instruction for both); identical arithmetic per element, so identical results
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x) {
+  const f32x2 L = {0x1.715476p+0f, 0x1.715476p+0f}, L2 = {0x1.4ae0bep-26f, 0x1.4ae0bep-26f};
+  x = __builtin_elementwise_max(x, f32x2{-200.0f, -200.0f});
+  const f32x2 t = x * L;
+  const f32x2 lo = __builtin_elementwise_fma(x, L, -t);
+  const f32x2 n = {__builtin_rintf(t.x), __builtin_rintf(t.y)};
+  const f32x2 f = (t - n) + __builtin_elementwise_fma(x, L2, lo);
+  return f32x2{__builtin_ldexpf(__builtin_amdgcn_exp2f(f.x), (int)n.x),
+               __builtin_ldexpf(__builtin_amdgcn_exp2f(f.y), (int)n.y)};
+}
+
+// LDS ring slot shared by the producer and consumer waves of one utterance.
+struct RingLayout {
+  int row_floats;   // V + 1 padded to 4
+  int pos_bytes;    // V padded to 16
+  int slot_bytes;
+  int nstage;
+  int utt_bytes;    // ring + consumer scratch + producer scratch + flags
+  int utt_per_wg;
+  int producers;    // producer waves per utterance
+  // rows too long for any LDS ring: the row of probabilities and the token -> list-position table
+  // of every slot live in the HBM workspace instead (g_slot_bytes per slot, L2-resident); the LDS
+  // slot keeps the list and the header
+  int row_global, g_slot_bytes;
+};
+
+__host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int utt_per_wg,
+                                                  int producers, bool row_global = false) {
+  RingLayout r;
+  r.row_floats = (V + 1 + 3) & ~3;
+  r.pos_bytes = (V + 15) & ~15;
+  r.row_global = row_global ? 1 : 0;
+  r.g_slot_bytes = row_global ? r.row_floats * 4 + r.pos_bytes : 0;
+  // (8 KiB per slot at least in that form: the freed ring holds the checkpoint table of the
+  // output walk)
+  r.slot_bytes = row_global ? 8192 : r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
+  r.nstage = nstage;
+  const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
+  r.utt_bytes = (r.slot_bytes * nstage + consumer + producers * PDT_SURV_CAP * 8 + 32 + 15) & ~15;
+  r.utt_per_wg = utt_per_wg;
+  r.producers = producers;
+  return r;
+}
+
+// the four-utterances-per-consumer-wave form (ctc_packed.hip): beams of up to 16 prefixes over rows
+// of up to 511 tokens
+struct PackedLayout;
+bool ctc_packed_applies(int V, int W);
+int launch_ctc_search_packed(CtcArgs a, hipStream_t stream);
+int ctc_packed_ring_slots(int V);
+
+}  // namespace pdt
