@@ -1,0 +1,24 @@
+"""Per-phase cycles of the packed CTC consumer (diagnostic build: profiles/tools/build_var.sh
+stamps ctc_packed.hip -DPDT_STAMPS; run with PDT_AMD_LIB=<that lib>)."""
+import os, sys, ctypes, torch
+os.environ.setdefault("PDT_AMD_LIB", os.path.abspath("pydrobert-pytorch_amd/csrc/build/variants/stamps/lib.so"))
+sys.path.insert(0, "."); sys.path.insert(0, "pydrobert-pytorch_amd")
+from pydrobert_amd import functional as F, _cabi
+dev = torch.device("cuda:0")
+T, N, V, K = 512, int(os.environ.get("N", 4096)), int(os.environ.get("V", 256)), 16
+g = torch.Generator(device=dev).manual_seed(3)
+logits = torch.randn((T, N, V + 1), device=dev, generator=g)
+peak = torch.randint(0, V + 1, (T, N, 1), device=dev, generator=g)
+logits.scatter_add_(2, peak, torch.full((T, N, 1), 12.0, device=dev))
+L = _cabi.lib()
+buf = (ctypes.c_ulonglong * 16)()
+F.ctc_prefix_search(logits, K); torch.cuda.synchronize()
+L.pdt_debug_read_stamps(buf, 1)
+F.ctc_prefix_search(logits, K); torch.cuda.synchronize()
+L.pdt_debug_read_stamps(buf, 1)
+tot = sum(buf[i] for i in range(14))
+names = ["wait ready", "reads+merge", "candidates", "sort", "winners+state", "is-prefix/nxt", "fallback rows", "flags+ckpt"]
+W = N // 4
+for i, nm in enumerate(names):
+    print("%-14s %8.1f cycles/frame  %5.1f%%" % (nm, buf[i] / (W * T), 100.0 * buf[i] / tot))
+print("total %.1f cycles/frame/wave" % (tot / (W * T)))

@@ -96,6 +96,6 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
 struct PackedLayout;
 bool ctc_packed_applies(int V, int W);
 int launch_ctc_search_packed(CtcArgs a, hipStream_t stream);
-int ctc_packed_ring_slots(int V);
+int ctc_packed_ring_slots(int V, int W);
 
 }  // namespace pdt

@@ -645,7 +645,7 @@ int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4) {
   if (rc != PDT_OK) return rc;
   plan4[0] = plan.producers; plan4[1] = plan.nstage; plan4[2] = plan.utt_per_wg; plan4[3] = plan.inreg;
   if (pdt::ctc_packed_applies((int)V, (int)width)) {  // four utterances per consumer wave
-    plan4[1] = pdt::ctc_packed_ring_slots((int)V);
+    plan4[1] = pdt::ctc_packed_ring_slots((int)V, (int)width);
     plan4[2] = 4;
   }
   return PDT_OK;

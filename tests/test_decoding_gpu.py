@@ -27,7 +27,7 @@ def ctc_form(request, monkeypatch):
     """Both forms of the one-kernel search: four utterances per consumer wave (beams of up to 16
     prefixes, rows of up to 511 tokens; csrc/ctc_packed.hip) and one (csrc/ctc_search.hip, which
     also serves everything beyond).  PDT_CTC_PACKED is read at every call."""
-    monkeypatch.setenv("PDT_CTC_PACKED", "1" if request.param == "packed" else "0")
+    monkeypatch.setenv("PDT_CTC_PACKED", "1" if request.param == "packed" else "0")  # (default: the one-utterance form)
     return request.param
 
 
