@@ -315,6 +315,137 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
     return out
 
 
+def synthetic_bigram_lm(M, V, device, successors=20, seed=0x5EED0007):
+    """A back-off bigram LookupLanguageModel over V tokens (+ an out-of-vocabulary sos): every
+    token a unigram, `successors` random explicit bigrams per context token."""
+    rng = np.random.default_rng(seed)
+    uni = rng.normal(size=V + 1) - np.log(V)
+    bo = rng.normal(size=V + 1) * 0.1 - 0.5
+    d1 = {v: (float(uni[v]), float(bo[v])) for v in range(V + 1)}
+    d2 = {}
+    for a in range(V + 1):
+        for b_ in rng.choice(V, successors, replace=False):
+            d2[(a, int(b_))] = float(rng.normal() - 3.0)
+    return M.LookupLanguageModel(V, V, [d1, d2]).to(device)
+
+
+def make_gru_lm(M, V, hidden=256):
+    class GruLM(M.MixableSequentialLanguageModel):
+        """1-layer GRU-cell model, hidden 256 -> Linear(256, V): the dense logit GEMM of SURVEY 8(d)."""
+
+        def __init__(self, V, hidden=256):
+            super().__init__(V)
+            self.hidden = hidden
+            self.embed = torch.nn.Embedding(V + 1, hidden)
+            self.cell = torch.nn.GRUCell(hidden, hidden)
+            self.out = torch.nn.Linear(hidden, V)
+
+        def update_input(self, prev, hist):
+            if "hidden" not in prev:
+                prev = {"hidden": torch.zeros((hist.size(1), self.hidden), device=hist.device)}
+            return prev
+
+        def calc_idx_log_probs(self, hist, prev, idx):
+            Vv, Np = self.vocab_size, hist.size(1)
+            if idx.dim() == 0:
+                idx = idx.expand(Np)
+            tok = torch.full((Np,), Vv, dtype=torch.long, device=hist.device)
+            if hist.size(0):
+                lastt = hist.gather(0, (idx - 1).clamp(min=0).unsqueeze(0)).squeeze(0).clamp(0, Vv - 1)
+                tok = torch.where(idx > 0, lastt, tok)
+            h = self.cell(self.embed(tok), prev["hidden"])
+            return self.out(h).log_softmax(-1), {"hidden": h}
+
+        def extract_by_src(self, prev, src):
+            return {"hidden": prev["hidden"].index_select(0, src)}
+
+        def mix_by_mask(self, prev_true, prev_false, mask):
+            return {"hidden": torch.where(mask.unsqueeze(1), prev_true["hidden"], prev_false["hidden"])}
+
+    return GruLM(V, hidden)
+
+
+def lm_configs(F, M, device, args, ref, hyp):
+    """The runs SURVEY section 8(d) asks for besides the headline step: C2 with ragged lengths, the
+    step with the reference's default warn=True, C3 with a language model in the loop (the shipped
+    n-gram model; a GRU-cell model whose logit layer is the path's only GEMM), BeamSearch end to end."""
+    out = {}
+    T, N, V = args.T, args.N, args.V
+    # C2 ragged: eos = V written at len ~ U{T/2 .. T}
+    g = torch.Generator(device=device).manual_seed(11)
+    rr, hh = ref.clone(), hyp.clone()
+    for x in (rr, hh):
+        lens = torch.randint(T // 2, T + 1, (N,), device=device, generator=g)
+        x[lens.clamp(max=T - 1), torch.arange(N, device=device)] = V
+    rag = {}
+    for name in ("error_rate", "prefix_error_rates", "optimal_completion"):
+        fn = getattr(F, name)
+        rag[name + "_ms"] = event_ms(lambda: fn(rr, hh, eos=V, warn=False), reps=3, warm=1)
+    C = F.optimal_completion(rr, hh, eos=V, warn=False).shape[-1]
+    rag["optimal_completion_C"] = C
+    rag["optimal_completion_GBs"] = 8 * (T + 1) * C * N / rag["optimal_completion_ms"] / 1e6
+    rag["ms"] = rag["error_rate_ms"] + rag["prefix_error_rates_ms"] + rag["optimal_completion_ms"]
+    rag["workload"] = "C2 shapes, eos={} at len ~ U{{T/2..T}} in ref and hyp".format(V)
+    out["C2_ragged"] = rag
+    # the string operators of the step with the reference's default arguments (warn=True: one host
+    # read of the status word per call, like the reference's own .any() checks)
+    def strings_default():
+        F.error_rate(ref, hyp)
+        F.prefix_error_rates(ref, hyp)
+        F.optimal_completion(ref, hyp)
+
+    def strings_nowarn():
+        F.error_rate(ref, hyp, warn=False)
+        F.prefix_error_rates(ref, hyp, warn=False)
+        F.optimal_completion(ref, hyp, warn=False)
+
+    out["step_default_warn"] = {
+        "workload": "error_rate + prefix_error_rates + optimal_completion of the step, default arguments (warn=True)",
+        "ms": event_ms(strings_default, reps=5, warm=1), "ms_warn_false": event_ms(strings_nowarn, reps=5, warm=1),
+    }
+    # C3 with the shipped n-gram model in the loop (shallow fusion)
+    T3, N3, V3, K = 1000, 1024, 1000, 16
+    lg = peaky_logits(T3, N3, V3, device, 0x5EED0003)
+    lm = synthetic_bigram_lm(M, V3, device)
+    search = M.CTCPrefixSearch(K, 0.2, lm)
+    with torch.no_grad():
+        search(lg[:8])
+        ms = event_ms(lambda: search(lg), reps=1, warm=0)
+    out["C3_search_lookup_lm"] = {
+        "workload": "CTCPrefixSearch(16, beta=0.2, LookupLanguageModel bigram, 20 explicit successors per token), "
+                    "N=1024 T=1000 V=1000", "ms": ms, "ms_per_frame": ms / T3, "utt_per_s": N3 / ms * 1e3,
+        "GBs": lg.numel() * 4 / ms / 1e6,
+    }
+
+    torch.manual_seed(5)
+    gru = make_gru_lm(M, V3).to(device)
+    search = M.CTCPrefixSearch(K, 0.2, gru)
+    with torch.no_grad():
+        search(lg[:8])
+        ms = event_ms(lambda: search(lg), reps=1, warm=0)
+        h = torch.randn((N3 * K, 256), device=device)
+        gemm_ms = event_ms(lambda: gru.out(h), reps=5, warm=2)
+    out["C3_search_gru_lm"] = {
+        "workload": "CTCPrefixSearch(16, beta=0.2, GRU-cell LM hidden 256 -> Linear(256, 1000)), N=1024 T=1000 V=1000",
+        "ms": ms, "ms_per_frame": ms / T3, "utt_per_s": N3 / ms * 1e3, "GBs": lg.numel() * 4 / ms / 1e6,
+        "logit_gemm_ms_per_frame": gemm_ms, "logit_gemm_share": gemm_ms * T3 / ms,
+        "logit_gemm_TFLOPs": 2.0 * N3 * K * 256 * V3 / gemm_ms / 1e9,
+        "gemm_kernel": "hipBLASLt / rocBLAS through torch.nn.Linear (kernel name: profiles/r03_gru_lm_kernel_stats.csv)",
+    }
+    del lg
+    # BeamSearch end to end: N=1024 paths x 16, V=1000, 100 iterations of the n-gram model
+    bs = M.BeamSearch(lm, K, eos=0)
+    with torch.no_grad():
+        bs(None, 8, 4)
+        ms = event_ms(lambda: bs(None, N3, 100), reps=1, warm=0)
+    out["BeamSearch_end_to_end"] = {
+        "workload": "BeamSearch(LookupLanguageModel bigram, width 16, eos=0), batch 1024, 100 iterations, V=1000",
+        "ms": ms, "ms_per_iteration": ms / 100, "paths_per_s": N3 * K / ms * 1e3,
+        "GBs": 4.0 * N3 * K * V3 * 100 / ms / 1e6,
+    }
+    return out
+
+
 def ctc_kernel_name(V, W):
     """The instantiation the library launches for this row length (include/pdt_amd.h)."""
     from pydrobert_amd import _cabi
@@ -522,6 +653,9 @@ def run_rank(args):
     if not args.no_extra and have_decode:
         extra = other_configs(F, M, device, world, rank, dist, gather_check)
         say("other configs done")
+        if rank == 0:
+            extra.update(lm_configs(F, M, device, args, ref, hyp))
+            say("ragged / default-argument / language-model configs done")
 
     if rank == 0:
         out = {

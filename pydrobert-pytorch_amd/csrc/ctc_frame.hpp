@@ -48,6 +48,10 @@ struct CtcArgs {
   unsigned char *grow;  // rows of the ring for vocabularies beyond the LDS (ctc_search.hip: RingLayout)
   int ckpt_shift, ckpt_count;
   int lds_per_wave, waves_per_wg;
+  // PDT_CTC_EXACT_DIV=1: probabilities as the IEEE quotient e / sum (a division per element of
+  // the row) instead of e * (1 / sum) -- slower; lets a caller see which disagreements with a
+  // reference are the reciprocal's ("Near ties")
+  int exact_div;
 };
 
 struct Beam {

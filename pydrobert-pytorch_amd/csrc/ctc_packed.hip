@@ -334,7 +334,12 @@ __device__ __forceinline__ void packed_producer(const CtcArgs &a, const PackedLa
     wave_sync();
     const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
     const float inv0 = __builtin_amdgcn_rcpf(s);
-    const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+    float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+    if (a.exact_div) {  // the quotient itself, element by element (CtcArgs::exact_div)
+      for (int v = lane; v <= V; v += PDT_WAVE) p[v] = p[v] / s;
+      wave_sync();
+      inv = 1.0f;
+    }
     int Ml = M;
     if (short_ok && nshort >= kShortMin && nshort <= kShortMax) {
       PDT_STAT(1);

@@ -31,6 +31,8 @@
 // leaves ties unspecified); parity is defined on tie-free inputs.
 #include "ctc_ring.hpp"
 
+#include <cstdlib>
+
 namespace pdt {
 
 // Workgroup = utt_per_wg x (P producer waves + one consumer wave).  A producer streams the
@@ -349,7 +351,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
       // reciprocal of the normaliser: v_rcp_f32 + one Newton step (within 1 ulp of the quotient;
       // the IEEE division sequence is 12 VALU instructions)
       const float inv0 = __builtin_amdgcn_rcpf(s);
-      const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+      float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+      if (a.exact_div) {  // the quotient itself, element by element (CtcArgs::exact_div)
+        for (int v = lane; v <= V; v += PDT_WAVE) p[v] = p[v] / s;
+        wave_sync();
+        inv = 1.0f;
+      }
       int Ml = M;
       if (short_ok && nshort >= kShortMin && nshort <= kShortMax) {
         PDT_STAT(1);
@@ -669,6 +676,10 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   a.trie = reinterpret_cast<int2 *>(workspace);
   a.ckpt = a.trie + T * N * width;
   a.grow = reinterpret_cast<unsigned char *>(workspace) + ctc_trie_bytes(T, N, width);
+  {
+    const char *e = std::getenv("PDT_CTC_EXACT_DIV");
+    a.exact_div = (e && e[0] == '1') ? 1 : 0;
+  }
   if (ctc_packed_applies(a.V, a.W)) return launch_ctc_search_packed(a, (hipStream_t)stream);
   CtcPlan plan;
   RingLayout rl;

@@ -52,6 +52,8 @@ def _fill_after_eos_op(tokens: torch.Tensor, eos: int, dim: int, fill: float, va
     dim = dim % nd
     if value.shape != tokens.shape:  # masked_fill would broadcast; the reference's callers never do
         value = value.expand(torch.broadcast_shapes(value.shape, tokens.shape))
+        if tokens.size(dim) == 1:  # one token along the walk: nothing comes after it, whatever it broadcasts to
+            return value.clone(memory_format=torch.contiguous_format)
         dim += value.dim() - nd  # leading dimensions the broadcast put in front of the tokens'
         tokens = tokens.expand(value.shape)
     if tokens.dtype == torch.long:

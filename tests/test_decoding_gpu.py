@@ -600,27 +600,46 @@ def test_ctc_prefix_search_exact_ties(device, ctc_form):
         _check_search(act, exp, ("ties", V, K))
 
 
+_NEAR_TIE_CASE = {}
+
+
+def _near_tie_case():
+    """2048 utterances of moderately peaky logits and the oracle's beams (computed once)."""
+    if not _NEAR_TIE_CASE:
+        from concurrent.futures import ThreadPoolExecutor
+
+        rng = np.random.default_rng(123)
+        T, N, V, K = 120, 2048, 40, 8
+        lg = _peaky_logits(rng, T, N, V, scale=5.0)
+
+        def one(i):
+            return oracle.ctc_prefix_search(np.ascontiguousarray(lg[:, i : i + 64]), K)
+
+        with ThreadPoolExecutor(16) as ex:
+            parts = list(ex.map(one, range(0, N, 64)))
+        _NEAR_TIE_CASE.update(
+            lg=lg, K=K, ey=np.concatenate([p[0] for p in parts], 1),
+            eyl=np.concatenate([p[1] for p in parts]), eyp=np.concatenate([p[2] for p in parts]),
+        )
+    c = _NEAR_TIE_CASE
+    return c["lg"], c["K"], c["ey"], c["eyl"], c["eyp"]
+
+
+def _disagreeing(y, yl, ey, eyl):
+    return [n for n in range(y.shape[1]) if not (np.array_equal(yl[n], eyl[n]) and np.array_equal(y[:, n], ey[:, n]))]
+
+
 def test_ctc_prefix_search_near_ties_are_the_only_disagreements(device, ctc_form):
     """Probabilities are p * (1 / sum) with a guard-free exp: within an ulp or two of the
     reference's quotient.  That can swap two beam entries whose masses agree to ~1e-6 (measured by
     the fuzz scripts: ~4 utterances in 100 000).  Bound it: wherever the beams of kernel and oracle
     differ, they hold the same prefixes up to entries whose probabilities are within 1e-5 of a
     neighbour's, and the sorted probabilities agree to 1e-5 everywhere."""
-    rng = np.random.default_rng(123)
-    T, N, V, K = 120, 2048, 40, 8
-    lg = _peaky_logits(rng, T, N, V, scale=5.0)
+    lg, K, ey, eyl, eyp = _near_tie_case()
+    N = lg.shape[1]
     y, yl, yp = (x.cpu().numpy() for x in F.ctc_prefix_search(torch.from_numpy(lg).to(device), K))
-    from concurrent.futures import ThreadPoolExecutor
-
-    def one(i):
-        return oracle.ctc_prefix_search(np.ascontiguousarray(lg[:, i : i + 64]), K)
-
-    with ThreadPoolExecutor(16) as ex:
-        parts = list(ex.map(one, range(0, N, 64)))
-    ey = np.concatenate([p[0] for p in parts], 1)
-    eyl, eyp = np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
     assert np.allclose(yp, eyp, rtol=1e-5, atol=0.0)  # sorted masses agree whatever the order of near-equal entries
-    bad = [n for n in range(N) if not (np.array_equal(yl[n], eyl[n]) and np.array_equal(y[:, n], ey[:, n]))]
+    bad = _disagreeing(y, yl, ey, eyl)
     assert len(bad) <= 4, len(bad)  # a handful in 2048 at most
     for n in bad:
         mine = {tuple(y[: yl[n, k], n, k].tolist()) for k in range(K)}
@@ -628,3 +647,20 @@ def test_ctc_prefix_search_near_ties_are_the_only_disagreements(device, ctc_form
         gap = np.abs(eyp[n, 1:] / eyp[n, :-1] - 1.0).min()
         # same prefixes in another order, or the K-th / (K+1)-th candidates were near-equal
         assert mine == theirs or gap < 1e-5, (n, gap)
+
+
+def test_ctc_prefix_search_exact_division_switch(device, ctc_form, monkeypatch):
+    """PDT_CTC_EXACT_DIV=1 makes the search form every probability as the IEEE quotient e / sum (what
+    the reference's softmax does) instead of e * (1 / sum).  Same beams up to near ties either way;
+    with the quotient the masses sit no further from the oracle's and no more utterances disagree --
+    the switch a caller uses to tell the reciprocal's disagreements from real ones."""
+    lg, K, ey, eyl, eyp = _near_tie_case()
+    tl = torch.from_numpy(lg).to(device)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PDT_CTC_EXACT_DIV", mode)
+        y, yl, yp = (x.cpu().numpy() for x in F.ctc_prefix_search(tl, K))
+        assert np.allclose(yp, eyp, rtol=1e-5, atol=0.0)
+        res[mode] = (len(_disagreeing(y, yl, ey, eyl)), float(np.abs(yp / eyp - 1.0).max()))
+    assert res["1"][0] <= res["0"][0] and res["1"][0] <= 4, res
+    assert res["1"][1] <= res["0"][1] * 1.5 + 1e-7, res

@@ -182,7 +182,7 @@ def test_search_sweep_with_language_model(device):
             None if lens[0] == -1 else torch.from_numpy(lens).to(device),
         )
         assert torch.equal(yl.cpu(), torch.from_numpy(g[tag + "y_lens"])), tag
-        assert np.allclose(g[tag + "y_probs"], yp.cpu().numpy(), rtol=2e-5, atol=1e-30), tag
+        assert np.allclose(g[tag + "y_probs"], yp.cpu().numpy(), rtol=1e-5, atol=1e-30), (tag, np.abs(yp.cpu().numpy() / g[tag + "y_probs"] - 1).max())
         mask = torch.arange(y.shape[0], device=device).view(-1, 1, 1) < yl.unsqueeze(0)
         assert torch.equal(torch.where(mask, y, torch.zeros_like(y)).cpu(), torch.from_numpy(g[tag + "y"])), tag
     for i in range(24):
