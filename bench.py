@@ -434,7 +434,7 @@ def lm_configs(F, M, device, args, ref, hyp):
     }
     del lg
     # BeamSearch end to end: N=1024 paths x 16, V=1000, 100 iterations of the n-gram model
-    bs = M.BeamSearch(lm, K, eos=0)
+    bs = M.BeamSearch(lm, K, eos=0).to(device)
     with torch.no_grad():
         bs(None, 8, 4)
         ms = event_ms(lambda: bs(None, N3, 100), reps=1, warm=0)

@@ -71,6 +71,22 @@ int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
             int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status, void *workspace,
             int64_t workspace_bytes, void *stream);
 
+/* The same call for inputs a previous pdt_lev has already classified into `workspace`: same ref /
+ * hyp contents, shapes and strides, same eos / include_eos, same workspace bytes untouched since,
+ * issued on the same stream (or ordered after it).  On the bit-parallel path (unit costs) the
+ * lengths, token classes and match tables are then read from the workspace instead of being rebuilt
+ * -- half the work of a call; error_rate followed by prefix_error_rates on one (ref, hyp) pair is
+ * the case (the Python host keeps the last workspace for exactly that, _string.py).  The warning
+ * bits are those the classifying call reported; `status` is not written.  Everywhere else it is
+ * pdt_lev. */
+int pdt_lev_classified(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
+                       const int64_t *hyp, int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N,
+                       int has_eos, int64_t eos, int include_eos, float ins_cost, float del_cost,
+                       float sub_cost, int norm, int mode, int exclude_last, float padding,
+                       int return_mistakes, float *out, int64_t out_sh, int64_t out_sn,
+                       int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status, void *workspace,
+                       int64_t workspace_bytes, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * fill_after_eos (_string.py:30-42): out = value, except that every position strictly after
  * the first `eos` along the sequence dimension holds the fill value.
@@ -207,6 +223,33 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
                             int64_t yp_sk, const int64_t *y_prev_lens, int64_t le_sn,
                             int64_t le_sk, int64_t S_out, int64_t *y_next, int64_t *y_next_lens,
                             float *log_probs_next, int64_t *next_src, void *stream);
+/* ---------------------------------------------------------------------------------------
+ * One iteration of BeamSearch.forward (_decoding.py:410-486 with the default
+ * update_log_probs_for_step) as one kernel: eos bookkeeping, log_softmax of the language model's
+ * scores (not materialised), eos-mass reallocation of ended paths, beam_search_advance, lengths
+ * that do not grow for ended sources, finished batch elements keeping their beam.
+ *   scores (N, Kp, V) float32 through element strides: the LM's output, any normalisation;
+ *   log_probs_prev (N, Kp); y_prev (S, N, Kp) int64 with every token in [0, V - 1] (the clamped
+ *   history the reference hands its LM, :434); y_prev_lens (N, Kp).
+ *   has_eos / eos in [0, V); finish_all_paths; pad_value (written clamped, see pad_from).
+ *   y_next (S + 1, N, width) int64 contiguous, y_next_lens / next_src (N, width) int64,
+ *   log_probs_next (N, width) float32.
+ *   active [1] int32: incremented once per batch element that was NOT finished at the start of this
+ *   iteration (the caller zeroes it; reading 0 means the reference would have left its loop before
+ *   this iteration -- every later row of y is padding).
+ *   pad_from (N,) int32, INT32_MAX initially: the first row of y that is padding for a finished
+ *   element; the caller writes pad_value into rows >= pad_from[n] at the end.
+ *   width, Kp <= 64.
+ * ------------------------------------------------------------------------------------- */
+int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, int64_t N,
+                         int64_t Kp, int64_t V, int64_t width, const float *log_probs_prev,
+                         int64_t lp_sn, int64_t lp_sk, const int64_t *y_prev, int64_t S,
+                         int64_t yp_ss, int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_lens,
+                         int64_t le_sn, int64_t le_sk, int has_eos, int64_t eos, int finish_all_paths,
+                         int64_t pad_value, int64_t *y_next, int64_t *y_next_lens,
+                         float *log_probs_next, int64_t *next_src, int32_t *active,
+                         int32_t *pad_from, void *stream);
+
 
 /* ---------------------------------------------------------------------------------------
  * ctc_greedy_search (reference _decoding.py:507-558).  logits (T, N, V) through element

@@ -417,7 +417,7 @@ static int set_lds(const void *kern, size_t smem) {
 }
 
 // LevArgs -> the three launches.  `ws` must hold plan.total bytes.
-int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream) {
+int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream, bool classified) {
   BitparArgs a{};
   a.ref = la.ref; a.hyp = la.hyp;
   a.ref_st = la.ref_st; a.ref_sn = la.ref_sn; a.hyp_st = la.hyp_st; a.hyp_sn = la.hyp_sn;
@@ -435,11 +435,14 @@ int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStrea
   a.yh = reinterpret_cast<uint2 *>(w + p.off_yh);
   a.msk = reinterpret_cast<uint32_t *>(w + p.off_msk);
 
-  auto ck = a.X <= 8 * PDT_WAVE ? lev_classify_kernel<8> : lev_classify_kernel<16>;
-  int rc = set_lds(reinterpret_cast<const void *>(ck), p.lds_classify * 4);
-  if (rc) return rc;
-  hipLaunchKernelGGL(ck, dim3((unsigned)((a.N + 3) / 4)), dim3(256), p.lds_classify * 4,
-                     stream, a, (int)p.lds_classify);
+  int rc = 0;
+  if (!classified) {  // (pdt_lev_classified: the workspace holds these inputs' tables already)
+    auto ck = a.X <= 8 * PDT_WAVE ? lev_classify_kernel<8> : lev_classify_kernel<16>;
+    rc = set_lds(reinterpret_cast<const void *>(ck), p.lds_classify * 4);
+    if (rc) return rc;
+    hipLaunchKernelGGL(ck, dim3((unsigned)((a.N + 3) / 4)), dim3(256), p.lds_classify * 4,
+                       stream, a, (int)p.lds_classify);
+  }
   const size_t smem = p.lds_sub * p.upw + p.lds_tail;
   const unsigned grid = (unsigned)((a.N + p.upw - 1) / p.upw);
   auto kern = lev_bitpar_kernel;

@@ -10,7 +10,7 @@
 namespace pdt {
 int launch_lev_skewed(LevArgs a, hipStream_t stream);
 int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream);
-int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream);
+int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream, bool classified);
 int launch_oc_mask_generic(const LevArgs &a, bool inexact, void *ws, int64_t ws_bytes, hipStream_t stream);
 int launch_oc_expand_generic(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
                              int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
@@ -74,7 +74,8 @@ extern "C" {
 
 // 2: pdt_ctc_prefix_search_workspace_bytes takes V; 3: pdt_lev takes a workspace;
 // 4: pdt_lookup_lm_log_probs takes the forward index of the trie's second level
-int pdt_amd_abi_version(void) { return 4; }
+// 5: pdt_lev_classified
+int pdt_amd_abi_version(void) { return 5; }
 
 int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {
   if (R < 0 || H < 0 || N <= 0) return 0;
@@ -89,12 +90,12 @@ int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {
   return need;
 }
 
-int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
-            int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,
-            int include_eos, float ins_cost, float del_cost, float sub_cost, int norm, int mode,
-            int exclude_last, float padding, int return_mistakes, float *out, int64_t out_sh,
-            int64_t out_sn, int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status,
-            void *workspace, int64_t workspace_bytes, void *stream) {
+static int lev_entry(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
+                     int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,
+                     int include_eos, float ins_cost, float del_cost, float sub_cost, int norm, int mode,
+                     int exclude_last, float padding, int return_mistakes, float *out, int64_t out_sh,
+                     int64_t out_sn, int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status,
+                     void *workspace, int64_t workspace_bytes, void *stream, bool classified) {
   using namespace pdt;
   if (mode != PDT_MODE_FINAL && mode != PDT_MODE_PREFIX) return PDT_E_ARG;
   if (exclude_last && mode != PDT_MODE_PREFIX) return PDT_E_ARG;  // _string.py:165
@@ -126,9 +127,31 @@ int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const
       bitpar_enabled()) {
     const BitparPlan p = plan_bitpar(H, R, N);
     if (p.ok && (int64_t)p.total <= workspace_bytes)
-      return launch_lev_bitpar(a, p, workspace, (hipStream_t)stream);
+      return launch_lev_bitpar(a, p, workspace, (hipStream_t)stream, classified);
   }
   return launch_lev_skewed(a, (hipStream_t)stream);
+}
+
+int pdt_lev(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
+            int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,
+            int include_eos, float ins_cost, float del_cost, float sub_cost, int norm, int mode,
+            int exclude_last, float padding, int return_mistakes, float *out, int64_t out_sh,
+            int64_t out_sn, int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status,
+            void *workspace, int64_t workspace_bytes, void *stream) {
+  return lev_entry(ref, R, ref_st, ref_sn, hyp, H, hyp_st, hyp_sn, N, has_eos, eos, include_eos, ins_cost,
+                   del_cost, sub_cost, norm, mode, exclude_last, padding, return_mistakes, out, out_sh, out_sn,
+                   ref_lens_out, hyp_lens_out, status, workspace, workspace_bytes, stream, false);
+}
+
+int pdt_lev_classified(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, const int64_t *hyp,
+                       int64_t H, int64_t hyp_st, int64_t hyp_sn, int64_t N, int has_eos, int64_t eos,
+                       int include_eos, float ins_cost, float del_cost, float sub_cost, int norm, int mode,
+                       int exclude_last, float padding, int return_mistakes, float *out, int64_t out_sh,
+                       int64_t out_sn, int64_t *ref_lens_out, int64_t *hyp_lens_out, int32_t *status,
+                       void *workspace, int64_t workspace_bytes, void *stream) {
+  return lev_entry(ref, R, ref_st, ref_sn, hyp, H, hyp_st, hyp_sn, N, has_eos, eos, include_eos, ins_cost,
+                   del_cost, sub_cost, norm, mode, exclude_last, padding, return_mistakes, out, out_sh, out_sn,
+                   ref_lens_out, hyp_lens_out, status, workspace, workspace_bytes, stream, true);
 }
 
 int64_t pdt_oc_mask_words(int64_t R) { return R <= 0 ? 1 : (R + 31) / 32; }

@@ -258,15 +258,22 @@ __device__ __forceinline__ float wave_sum_f(float x) {
 // BIAS: the ranked values are bias + x[v] (one float32 add, as the caller's own arithmetic forms
 // them; + 0.0f turns a -0.0 sum into +0.0 so the two zeros tie as in a float compare): elements whose sums round to the same float tie and come out lowest index first, even
 // when their x differ.
-template <bool LONG = false, bool NONNEG = false, bool BIAS = false>
+// SOFT (with BIAS): the ranked values are bias + ((x[v] - soft_max) - soft_lse) -- a row of raw
+// scores seen through its log-softmax, the three float32 operations in the order
+// log_softmax(-1) followed by the caller's addition performs them.
+template <bool LONG = false, bool NONNEG = false, bool BIAS = false, bool SOFT = false>
 __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const int64_t sx, int V,
                                                        int M, u64 *surv,
                                                        const unsigned *lmax_in = nullptr,
                                                        unsigned *probe = nullptr,
-                                                       int probe_rank = 1, float bias = 0.0f) {
+                                                       int probe_rank = 1, float bias = 0.0f,
+                                                       float soft_max = 0.0f, float soft_lse = 0.0f) {
   int lane = lane_id();
   asm volatile("" : "+v"(lane));  // nothing lane-derived is hoisted out of the caller's frame loop
-  auto X = [&](int v) { return BIAS ? (bias + xb[(int64_t)v * sx]) + 0.0f : xb[(int64_t)v * sx]; };
+  auto X = [&](int v) {
+    if (SOFT) return (bias + ((xb[(int64_t)v * sx] - soft_max) - soft_lse)) + 0.0f;
+    return BIAS ? (bias + xb[(int64_t)v * sx]) + 0.0f : xb[(int64_t)v * sx];
+  };
   auto fkey = [](float f) { return NONNEG ? fkey_nonneg(f) : pdt::fkey(f); };
   if (V <= PDT_WAVE) {
     const u64 k = lane < V ? pack_key(fkey(X(lane)), (unsigned)lane) : 0ull;

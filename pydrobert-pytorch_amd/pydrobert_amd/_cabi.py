@@ -33,6 +33,11 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
         + [_INT, _INT, _INT, _F, _INT, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
     ),
+    "pdt_lev_classified": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]
+        + [_INT, _INT, _INT, _F, _INT, _P, _I64, _I64, _P, _P, _P, _P, _I64, _P],
+    ),
     "pdt_lev_workspace_bytes": (_I64, [_I64, _I64, _I64]),
     "pdt_fill_after_eos": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P]),
     "pdt_oc_mask_words": (_I64, [_I64]),
@@ -59,6 +64,11 @@ SIGNATURES = {
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
         + [_P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
+    ),
+    "pdt_beam_search_step": (
+        _INT,
+        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
+        + [_P, _I64, _I64, _INT, _I64, _INT, _I64, _P, _P, _P, _P, _P, _P, _P],
     ),
     "pdt_ctc_greedy_search": (
         _INT, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _INT, _P, _P, _I64, _I64, _P, _P],

@@ -8,6 +8,7 @@ Host-side mirror of the reference's ``_decoding.py`` for the operators on the ho
 user-supplied language model.
 """
 import math
+import os
 from typing import Any, Dict, Optional, Tuple
 
 import torch
@@ -691,6 +692,110 @@ class BeamSearch(torch.nn.Module):
             lens = lens.gather(1, src)
         return y, log_probs, lens
 
+    @torch.jit.unused
+    def _check_growth(self, lens: torch.Tensor, hist: torch.Tensor) -> None:
+        if os.environ.get("PDT_CHECK_INVARIANTS", "0") == "1" and lens.numel():
+            if int(lens.max()) < hist.size(0):
+                raise RuntimeError("BeamSearch: no path is as long as the history ({} < {}): the step must not "
+                                   "grow y".format(int(lens.max()), hist.size(0)))
+
+    @torch.jit.unused
+    def _forward_fused(
+        self, prev: Dict[str, torch.Tensor], batch_size: Optional[int], max_iters: Optional[int]
+    ) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
+        """The search with every iteration's bookkeeping in ONE kernel (csrc/beam_step.hip) around the
+        language model's forward: no ``log_softmax`` / ``masked_fill`` / ``where`` passes over
+        ``(N, K, V)``, no per-iteration clamp of the history, and the number of unfinished batch
+        elements is read from the device every eighth iteration instead of every one (iterations run
+        past the end only append padding, which is cut off again).  Taken when the step hook is the
+        default one (a subclass that overrides ``update_log_probs_for_step`` must see the tensors),
+        nothing wants gradients and the beam fits a wave; returns ``None`` otherwise."""
+        if type(self).update_log_probs_for_step is not BeamSearch.update_log_probs_for_step:
+            return None
+        if self.width > 64 or os.environ.get("PDT_BEAM_FUSED", "1") == "0":
+            return None
+        if torch.is_grad_enabled() and (
+            any(p.requires_grad for p in self.lm.parameters())
+            or any(torch.is_tensor(v) and v.requires_grad for v in prev.values())
+        ):
+            return None
+        device = self.device_buffer.device
+        if device.type != "cuda":
+            return None
+        N = 1 if batch_size is None else batch_size
+        V, W = self.lm.vocab_size, self.width
+        if max_iters is None:
+            if self.eos is None:
+                raise RuntimeError("max_iters must be set when eos is unset")
+            max_iters = 1073741824
+        elif max_iters < 0:
+            raise RuntimeError("max_iters must be non-negative, got {}".format(max_iters))
+        L = _cabi.lib()
+        has_eos = self.eos is not None
+        y = torch.empty((0, N), dtype=torch.long, device=device)
+        prev = self.lm.update_input(prev, y)
+        y = y.unsqueeze(2)
+        log_probs = torch.zeros((N, 1), device=device)
+        lens = torch.zeros((N, 1), dtype=torch.long, device=device)
+        check_every = 8
+        counts = torch.zeros((check_every,), dtype=torch.int32, device=device)
+        pad_from = torch.full((N,), 2147483647, dtype=torch.int32, device=device)
+        steps = torch.arange(0, 1024, device=device)
+        row_base = {1: torch.zeros((N, 1), dtype=torch.long, device=device),
+                    W: torch.arange(0, W * N, W, device=device).unsqueeze(1)}
+        Kp, t, t_stop = 1, 0, -1
+        out_dtype = torch.float
+        while t < max_iters:
+            if t and t % 1024 == 0:
+                steps = torch.arange(t, t + 1024, device=device)
+            scores, state_next = self.lm.calc_idx_log_probs(y.flatten(1), prev, steps[t % 1024])
+            if torch.is_grad_enabled() and scores.requires_grad:
+                if t == 0:  # (a model whose weights are no registered parameters: the differentiable loop)
+                    return None
+                raise RuntimeError("BeamSearch: the language model's output wants gradients inside a search "
+                                   "that was started without any (set PDT_BEAM_FUSED=0)")
+            out_dtype = scores.dtype
+            scores = _f32(scores).reshape(N, Kp, V)
+            with torch.cuda.device(device):
+                y_new = torch.empty((t + 1, N, W), dtype=torch.long, device=device)
+                lens_new = torch.empty((N, W), dtype=torch.long, device=device)
+                lp_new = torch.empty((N, W), device=device)
+                src = torch.empty((N, W), dtype=torch.long, device=device)
+                rc = L.pdt_beam_search_step(
+                    _cabi.ptr(scores), scores.stride(0), scores.stride(1), scores.stride(2), N, Kp, V, W,
+                    _cabi.ptr(log_probs), log_probs.stride(0), log_probs.stride(1),
+                    _cabi.ptr(y), t, y.stride(0), y.stride(1), y.stride(2),
+                    _cabi.ptr(lens), lens.stride(0), lens.stride(1), int(has_eos), int(self.eos or 0),
+                    int(self.finish_all_paths), int(self.pad_value), _cabi.ptr(y_new), _cabi.ptr(lens_new),
+                    _cabi.ptr(lp_new), _cabi.ptr(src), counts.data_ptr() + 4 * (t % check_every),
+                    _cabi.ptr(pad_from), _cabi.stream_ptr(device),
+                )  # fmt: skip
+            _cabi.check(rc, "pdt_beam_search_step")
+            prev = self.lm.extract_by_src(state_next, (src + row_base[Kp]).flatten())
+            y, lens, log_probs, Kp = y_new, lens_new, lp_new, W
+            t += 1
+            if has_eos and (t % check_every == 0 or t == max_iters):
+                # the one host read per `check_every` iterations: an iteration that started with every
+                # batch element finished is where the reference leaves its loop (:426)
+                seen = counts.tolist()
+                lo = t - ((t - 1) % check_every + 1)
+                for i in range(lo, t):
+                    if i > 0 and seen[i % check_every] == 0:
+                        t_stop = i
+                        break
+                if t_stop >= 0:
+                    break
+                counts.zero_()
+        if t_stop >= 0:  # the iterations from t_stop on only appended padding
+            y = y[:t_stop]
+        if has_eos and y.size(0):  # finished elements: pad_value from their first padding row on
+            rows = torch.arange(y.size(0), device=device).view(-1, 1, 1)
+            y = torch.where(rows >= pad_from.view(1, N, 1), y.new_full((), self.pad_value), y)
+        y, log_probs, lens = self._to_width(y, log_probs.to(out_dtype), lens)
+        if batch_size is None:
+            y, lens, log_probs = y.squeeze(1), lens.squeeze(0), log_probs.squeeze(0)
+        return y, lens, log_probs
+
     def forward(
         self,
         initial_state_: Optional[Dict[str, torch.Tensor]] = None,
@@ -706,6 +811,10 @@ class BeamSearch(torch.nn.Module):
         device = self.device_buffer.device
         N = 1 if batch_size is None else batch_size
         V, W = self.lm.vocab_size, self.width
+        if not torch.jit.is_scripting():
+            fused = self._forward_fused(prev, batch_size, max_iters)
+            if fused is not None:
+                return fused
         Kp = 1
         y = torch.empty((0, N), dtype=torch.long, device=device)
         prev = self.lm.update_input(prev, y)
@@ -744,6 +853,9 @@ class BeamSearch(torch.nn.Module):
                 lp_t = torch.where(ended.unsqueeze(2), only_eos, lp_t)
             # some path is as long as the history whenever the loop gets here (a live element has
             # a live path of t tokens), so y grows by a row: no read-back of the lengths
+            # (PDT_CHECK_INVARIANTS=1 reads them back and checks)
+            if not torch.jit.is_scripting():
+                self._check_growth(lens, hist)
             y_new, lens_new, lp_new, src = torch.ops.pydrobert_amd.beam_search_advance(
                 lp_t, W, log_probs, hist, lens, True
             )

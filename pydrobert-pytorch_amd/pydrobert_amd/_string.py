@@ -6,6 +6,7 @@ runs in ``csrc/lev_skewed.hip`` / ``csrc/lev_rowsync.hip`` through ``pdt_lev``,
 ``pdt_oc_mask`` and ``pdt_oc_expand`` (``include/pdt_amd.h``).
 """
 
+import os
 import warnings
 from typing import Optional, Tuple
 
@@ -179,6 +180,20 @@ def _lev_workspace(R: int, H: int, N: int, device):
     return torch.empty(nbytes, device=device, dtype=torch.uint8), nbytes
 
 
+# The last classification of a (ref, hyp) pair per device: error_rate followed by
+# prefix_error_rates on the same tensors (the usual pairing) builds lengths, token classes and match
+# tables once (include/pdt_amd.h: pdt_lev_classified).  An entry keeps the two token tensors alive --
+# their addresses cannot be handed to other tensors while it stands -- and is matched on address,
+# version counter, geometry, eos handling and stream.  PDT_LEV_CACHE=0 turns it off.
+_CLASSIFIED = {}
+
+
+def _classified_key(ref, hyp, geom, eos, include_eos, norm, stream):
+    # (without an eos every sequence has its full length: include_eos changes nothing)
+    return (ref.data_ptr(), ref._version, hyp.data_ptr(), hyp._version, geom, eos,
+            bool(include_eos) and eos is not None, bool(norm), stream)
+
+
 @custom_op("pydrobert_amd::string_matching", mutates_args=())
 def _string_matching_op(
     ref: torch.Tensor,
@@ -220,8 +235,20 @@ def _string_matching_op(
         status = torch.zeros(1, device=device, dtype=torch.int32) if warn else None
         # (only the bit-parallel kernels -- uniform costs -- and the plain kernel for references
         # beyond 2048 tokens read a workspace; every other call launches without one)
-        ws, ws_bytes = _lev_workspace(R, H, N, device) if (uniform or R > 2048) else (None, 0)
-        rc = _cabi.lib().pdt_lev(
+        ws, ws_bytes = None, 0
+        entry = pdt_lev = _cabi.lib().pdt_lev
+        key = None
+        if uniform and os.environ.get("PDT_LEV_CACHE", "1") != "0":
+            stream = _cabi.stream_ptr(device)
+            key = _classified_key(ref, hyp, (R, rst, rsn, H, hst, hsn, N), eos, include_eos, norm,
+                                  stream if isinstance(stream, int) else getattr(stream, "value", None))
+            hit = _CLASSIFIED.get(device.index)
+            if hit is not None and hit[0] == key and (hit[4] is not None or not warn):
+                ws, ws_bytes, status = hit[3], hit[3].numel(), hit[4]  # (the warning bits of the classifying call)
+                entry = _cabi.lib().pdt_lev_classified
+        if entry is pdt_lev and (uniform or R > 2048):
+            ws, ws_bytes = _lev_workspace(R, H, N, device)
+        rc = entry(
             _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,
             int(eos is not None), int(eos) if eos is not None else 0, int(include_eos),
             float(ins_cost), float(del_cost), float(sub_cost), int(norm), mode,
@@ -230,6 +257,11 @@ def _string_matching_op(
             _cabi.stream_ptr(device),
         )  # fmt: skip
     _cabi.check(rc, "pdt_lev")
+    if key is not None and ws is not None:
+        if entry is pdt_lev:
+            _CLASSIFIED[device.index] = (key, ref, hyp, ws, status)
+    elif key is not None:
+        _CLASSIFIED.pop(device.index, None)
     if warn:
         flags = int(status.item())
         if flags:

@@ -664,3 +664,62 @@ def test_ctc_prefix_search_exact_division_switch(device, ctc_form, monkeypatch):
         res[mode] = (len(_disagreeing(y, yl, ey, eyl)), float(np.abs(yp / eyp - 1.0).max()))
     assert res["1"][0] <= res["0"][0] and res["1"][0] <= 4, res
     assert res["1"][1] <= res["0"][1] * 1.5 + 1e-7, res
+
+
+@pytest.mark.parametrize("finish_all", [False, True])
+def test_beam_search_fused_iterations_equal_the_step_by_step_loop(device, finish_all, monkeypatch):
+    """BeamSearch with every iteration in one kernel (csrc/beam_step.hip; the number of unfinished
+    batch elements read every eighth iteration) against the loop of reference-shaped torch ops around
+    beam_search_advance (PDT_BEAM_FUSED=0): same paths, lengths and padding, log-probabilities to 1e-5;
+    searches that end by eos at iterations that are no multiple of eight, by max_iters, at once."""
+    from _toy_lm import BigramLM
+
+    class PositionalBigramLM(BigramLM):
+        """Bigram scores plus a per-position offset: two orders of the same transitions no longer
+        add up to the same log-probability (with the plain bigram table such paths tie up to the
+        rounding of the sums and the two loops may order them differently)."""
+
+        def __init__(self, table, pos):
+            super().__init__(table)
+            self.register_buffer("pos", pos)
+
+        def calc_idx_log_probs(self, hist, prev, idx):
+            lp, prev = super().calc_idx_log_probs(hist, prev, idx)
+            return lp + self.pos[idx.clamp(max=self.pos.shape[0] - 1)], prev
+
+    rng = np.random.default_rng(2024 + int(finish_all))
+    for V, W, N, iters, eos_bias in [(9, 4, 5, 30, 1.5), (30, 8, 3, 21, 2.5), (6, 5, 7, 8, 0.0), (12, 3, 2, 0, 0.0),
+                                     (40, 16, 33, 50, 3.0), (5, 8, 4, 12, 1.0)]:
+        table = rng.normal(size=(V + 1, V)).astype(np.float32)
+        table[:, 1] += eos_bias  # eos = 1 wins often enough to end paths at different iterations
+        pos = rng.normal(size=(64, V)).astype(np.float32)
+        lm = PositionalBigramLM(torch.from_numpy(table).to(device), torch.from_numpy(pos).to(device))
+        for eos in (1, None):
+            mod = M.BeamSearch(lm, W, eos, finish_all, -5).to(device)
+            monkeypatch.setenv("PDT_BEAM_FUSED", "0")
+            monkeypatch.setenv("PDT_CHECK_INVARIANTS", "1")  # (the loop's "y grows every iteration" is checked)
+            ey, eyl, elp = mod(None, N, iters)
+            monkeypatch.setenv("PDT_BEAM_FUSED", "1")
+            y, yl, lp = mod(None, N, iters)
+            what = (V, W, N, iters, eos, finish_all)
+            assert y.shape == ey.shape and torch.equal(yl, eyl), (what, y.shape, ey.shape)
+            assert torch.allclose(lp, elp, rtol=1e-5, atol=1e-6), what
+            S = y.shape[0]
+            mask = torch.arange(S, device=device).view(S, 1, 1) < eyl.unsqueeze(0)
+            assert torch.equal(torch.where(mask, y, ey), ey), what  # tokens within the lengths
+            if eos is not None and S:
+                # padding of finished elements: identical wherever the step-by-step loop wrote pad_value
+                assert torch.equal((y == -5).all(2), (ey == -5).all(2)), what
+    # batch_size None (no batch dimension) and the hook: a subclass that overrides it keeps the loop
+    mod = M.BeamSearch(lm, 3, 1).to(device)
+    y, yl, lp = mod(None, None, 6)
+    assert y.dim() == 2 and yl.shape == (3,) and lp.shape == (3,)
+
+    class Hooked(M.BeamSearch):
+        def update_log_probs_for_step(self, log_probs_prev, log_probs_t, y_prev, y_prev_lens, eos_mask):
+            self.calls = getattr(self, "calls", 0) + 1
+            return log_probs_prev, log_probs_t
+
+    hooked = Hooked(lm, 3, 1).to(device)
+    hy, hyl, hlp = hooked(None, 2, 5)
+    assert hooked.calls >= 1 and hy.shape[1:] == (2, 3)

@@ -491,6 +491,55 @@ def test_lev_workspace_is_optional(device):
     assert np.array_equal(exp, outs[0].numpy())
 
 
+def test_classification_is_reused_only_for_the_same_inputs(device):
+    """error_rate followed by prefix_error_rates on one (ref, hyp) pair classifies once
+    (pdt_lev_classified through the host's one-entry cache).  The entry must not outlive its inputs'
+    CONTENTS: in-place edits, other eos handling, other tensors at recycled addresses, another
+    stream -- every call against the oracle; warnings repeat with the cached bits."""
+    import warnings
+
+    from pydrobert_amd import _string
+
+    rng = np.random.default_rng(31)
+    R, H, N, V = 70, 66, 9, 5
+
+    def check(tr, th, **kw):
+        r, h = tr.cpu().numpy(), th.cpu().numpy()
+        assert np.array_equal(F.error_rate(tr, th, warn=False, **kw).cpu().numpy(), oracle.error_rate(r, h, **kw))
+        assert np.array_equal(
+            F.prefix_error_rates(tr, th, warn=False, **kw).cpu().numpy(), oracle.prefix_error_rates(r, h, **kw)
+        )
+        assert np.array_equal(F.edit_distance(tr, th, warn=False, **kw).cpu().numpy(), oracle.edit_distance(r, h, **kw))
+
+    tr = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
+    th = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
+    check(tr, th, eos=4, include_eos=True)
+    assert _string._CLASSIFIED[device.index][0][0] == tr.data_ptr()  # an entry stands
+    check(tr, th, eos=4, include_eos=False)  # other length rule: not the cached tables
+    th[3] = (th[3] + 1) % V  # in-place edit: same address, new version
+    check(tr, th, eos=4, include_eos=False)
+    tr.add_(1).remainder_(V)
+    check(tr, th, eos=4, include_eos=False)
+    for _ in range(6):  # fresh tensors, freed every round: the allocator recycles their addresses
+        a = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
+        b = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
+        check(a, b, eos=None)
+        del a, b
+    side = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        check(tr, th, eos=2, include_eos=True)
+    side.synchronize()
+    check(tr, th, eos=2, include_eos=True)
+    # warnings: the second call of a pair reports what the classifying call found
+    nr = torch.full((R, N), 1, device=device)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        F.error_rate(nr, th, eos=4, include_eos=True, norm=True)
+        n1 = len(w)
+        F.prefix_error_rates(nr, th, eos=4, include_eos=True, norm=True)
+    assert n1 >= 1 and len(w) == 2 * n1, [str(x.message)[:40] for x in w]
+
+
 def test_bitpar_empty_sequences(device):
     """No hypothesis tokens / no reference tokens at all (zero-length dimensions), one utterance."""
     rng = np.random.default_rng(9)
