@@ -672,6 +672,118 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
 }
 }
 
+// Sparse warp, the common shape (bilinear, forward, no flow output, at most kWarpFastM spline
+// centres -- SpecAugment-style calls have 3 + 4 pinned): image_warp_kernel's per-pixel work with
+//   * the centres and weights in SCALAR registers (wave-uniform; image_warp_kernel re-reads them
+//     from LDS for every pixel: 34 broadcast reads),
+//   * kWarpPix pixels per lane, 256 apart (a wave's lanes stay on consecutive pixels: coalesced taps
+//     and stores), evaluated side by side -- independent chains that hide v_log_f32 and the taps'
+//     latency behind each other,
+//   * the spline sum in fused multiply-adds (one rounding per term instead of two; the results
+//     differ from image_warp_kernel's in the last bits, far inside the 1e-4 the spline is good to).
+constexpr int kWarpFastM = 8;
+constexpr int kWarpPix = 4;
+template <int ORDER, int PADDING>
+__global__ void __launch_bounds__(256) sparse_warp_fast_kernel(const WarpArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float *lk = reinterpret_cast<float *>(smem);
+  float *lw = lk + 2 * a.M;
+  const int64_t n = blockIdx.y;
+  const int H = a.H, W = a.W, M = a.M;
+  for (int i = (int)threadIdx.x; i < 2 * M; i += 256) lk[i] = a.knots[n * 2 * M + i];
+  for (int i = (int)threadIdx.x; i < 2 * (M + 3); i += 256) lw[i] = a.wv[n * 2 * (M + 3) + i];
+  __syncthreads();
+  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  float kx[kWarpFastM], ky[kWarpFastM], wx[kWarpFastM], wy[kWarpFastM];
+#pragma unroll
+  for (int m = 0; m < kWarpFastM; ++m) {
+    const bool in = m < M;
+    kx[m] = uni(in ? lk[2 * m] : 0.0f);
+    ky[m] = uni(in ? lk[2 * m + 1] : 0.0f);
+    wx[m] = uni(in ? lw[2 * m] : 0.0f);
+    wy[m] = uni(in ? lw[2 * m + 1] : 0.0f);
+  }
+  const float ax = uni(lw[2 * M]), ay = uni(lw[2 * M + 1]), bx = uni(lw[2 * (M + 1)]), by = uni(lw[2 * (M + 1) + 1]);
+  const float cx = uni(lw[2 * (M + 2)]), cy = uni(lw[2 * (M + 2) + 1]);
+  const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
+  const int HW = H * W;
+  const int base = (int)(blockIdx.x * (256 * kWarpPix) + threadIdx.x);
+  float x[kWarpPix], y[kWarpPix], sx[kWarpPix], sy[kWarpPix];
+#pragma unroll
+  for (int j = 0; j < kWarpPix; ++j) {
+    const int pix = min(base + j * 256, HW - 1);  // (beyond the image: a duplicate of the last pixel, not stored)
+    int h = (int)(((float)pix + 0.5f) * inv_w), w = pix - h * W;  // (H * W < 2^23: checked by the launcher)
+    if (w < 0) { --h; w += W; }
+    if (w >= W) { ++h; w -= W; }
+    x[j] = (float)w;
+    y[j] = (float)h;
+    sx[j] = __builtin_fmaf(ax, x[j], __builtin_fmaf(bx, y[j], cx));
+    sy[j] = __builtin_fmaf(ay, x[j], __builtin_fmaf(by, y[j], cy));
+  }
+#pragma unroll
+  for (int m = 0; m < kWarpFastM; ++m) {
+    if (m < M) {  // (wave-uniform)
+#pragma unroll
+      for (int j = 0; j < kWarpPix; ++j) {
+        const float dx = x[j] - kx[m], dy = y[j] - ky[m];
+        const float p = phi_from_d2<ORDER>(__builtin_fmaf(dx, dx, dy * dy), a.order);
+        sx[j] = __builtin_fmaf(p, wx[m], sx[j]);
+        sy[j] = __builtin_fmaf(p, wy[m], sy[j]);
+      }
+    }
+  }
+  float ix[kWarpPix], iy[kWarpPix];
+#pragma unroll
+  for (int j = 0; j < kWarpPix; ++j) {
+    float gx, gy;
+    if (a.as_grid) {
+      gx = sx[j];
+      gy = sy[j];
+    } else {
+      gx = (2.0f * x[j] - 2.0f * sx[j] + 1.0f) * inv_w - 1.0f;  // _img.py:432
+      gy = (2.0f * y[j] - 2.0f * sy[j] + 1.0f) * inv_h - 1.0f;
+    }
+    ix[j] = source_index(gx, W, PADDING);
+    iy[j] = source_index(gy, H, PADDING);
+  }
+  float x0f[kWarpPix], y0f[kWarpPix];
+#pragma unroll
+  for (int j = 0; j < kWarpPix; ++j) {
+    x0f[j] = floorf(ix[j]);
+    y0f[j] = floorf(iy[j]);
+  }
+  for (int c = 0; c < a.C; ++c) {
+    const float *pl = a.image + (n * a.C + c) * (int64_t)HW;
+    float t00[kWarpPix], t01[kWarpPix], t10[kWarpPix], t11[kWarpPix];
+#pragma unroll
+    for (int j = 0; j < kWarpPix; ++j) {  // all the taps in flight (taps outside the image: any valid address)
+      const int x0 = (int)x0f[j], y0 = (int)y0f[j];
+      // (border / reflection padding: the coordinates are inside [0, size - 1] already)
+      const int xc0 = PADDING == PAD_ZEROS ? min(max(x0, 0), W - 1) : x0, xc1 = min(max(x0 + 1, 0), W - 1);
+      const int yc0 = (PADDING == PAD_ZEROS ? min(max(y0, 0), H - 1) : y0) * W, yc1 = min(max(y0 + 1, 0), H - 1) * W;
+      t00[j] = pl[yc0 + xc0];
+      t01[j] = pl[yc0 + xc1];
+      t10[j] = pl[yc1 + xc0];
+      t11[j] = pl[yc1 + xc1];
+    }
+#pragma unroll
+    for (int j = 0; j < kWarpPix; ++j) {
+      const int x0 = (int)x0f[j], y0 = (int)y0f[j], x1 = x0 + 1, y1 = y0 + 1;
+      const float wx1 = ix[j] - x0f[j], wy1 = iy[j] - y0f[j], wx0 = (x0f[j] + 1.0f) - ix[j], wy0 = (y0f[j] + 1.0f) - iy[j];
+      const bool vx0 = PADDING != PAD_ZEROS || (x0 >= 0 && x0 < W), vx1 = x1 >= 0 && x1 < W;
+      const bool vy0 = PADDING != PAD_ZEROS || (y0 >= 0 && y0 < H), vy1 = y1 >= 0 && y1 < H;
+      // (a tap outside the image is left out, as image_warp_kernel does -- a select, not a product
+      // with 0: that would turn an inf / NaN pixel into NaN)
+      float acc = (vx0 && vy0) ? t00[j] * (wx0 * wy0) : 0.0f;
+      acc += (vx1 && vy0) ? t01[j] * (wx1 * wy0) : 0.0f;
+      acc += (vx0 && vy1) ? t10[j] * (wx0 * wy1) : 0.0f;
+      acc += (vx1 && vy1) ? t11[j] * (wx1 * wy1) : 0.0f;
+      const int pix = base + j * 256;
+      if (pix < HW) a.out[(n * a.C + c) * (int64_t)HW + pix] = acc;
+    }
+  }
+}
+
 // copy the double solution into float (w, v) laid out (N, M+3, 2) for image_warp_kernel
 __global__ void cast_wv_kernel(const double *__restrict__ wv, float *__restrict__ out, int64_t total) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -897,6 +1009,20 @@ static int sparse_warp_launch(const float *image, const float *train_points,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
+  } else if (mode == INTERP_BILINEAR && !flow_out && M <= kWarpFastM && H * W < (1 << 23)) {
+    // several pixels per lane, centres in scalar registers (sparse_warp_fast_kernel)
+    const int per_wg = 256 * kWarpPix;
+    const dim3 gf((unsigned)((H * W + per_wg - 1) / per_wg), (unsigned)N);
+    auto go = [&](auto ord) {
+      constexpr int O = decltype(ord)::value;
+      if (padding == PAD_BORDER) hipLaunchKernelGGL((sparse_warp_fast_kernel<O, PAD_BORDER>), gf, dim3(256), smem, (hipStream_t)stream, a);
+      else if (padding == PAD_ZEROS) hipLaunchKernelGGL((sparse_warp_fast_kernel<O, PAD_ZEROS>), gf, dim3(256), smem, (hipStream_t)stream, a);
+      else hipLaunchKernelGGL((sparse_warp_fast_kernel<O, PAD_REFLECTION>), gf, dim3(256), smem, (hipStream_t)stream, a);
+    };
+    if (order == 2) go(std::integral_constant<int, 2>{});
+    else if (order == 1) go(std::integral_constant<int, 1>{});
+    else if (order == 3) go(std::integral_constant<int, 3>{});
+    else go(std::integral_constant<int, 0>{});
   } else {
     hipLaunchKernelGGL(image_warp_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
   }
