@@ -81,6 +81,22 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
     rnext[j] = (cbase + j) < ref_len ? nxt : -1;
   }
   const int rank0 = __builtin_amdgcn_readfirstlane(rid[0]);  // class of ref[0]
+  // where column j's class bit lives and which lanes have one at all: the same for every row, so
+  // the mask phase of a row is a compare, a scalar AND and one LDS OR per column
+  // (up to 8 columns per lane: beyond, the hoisted values would not fit the register files)
+  constexpr bool kHoistMask = CPL <= 8;
+  constexpr int HC = kHoistMask ? CPL : 1;
+  unsigned bm_bit[HC];
+  int bm_word[HC];
+  u64 has_next[HC];
+  if (kHoistMask) {
+#pragma unroll
+    for (int j = 0; j < HC; ++j) {
+      bm_bit[j] = 1u << (rnext[j] & 31);
+      bm_word[j] = max(rnext[j], 0) >> 5;
+      has_next[j] = __ballot(rnext[j] >= 0);
+    }
+  }
   if (EXACT) {
     for (int c = lane; c <= ref_len; c += PDT_WAVE) row0_l[c] = (float)c * del;
   }
@@ -159,8 +175,13 @@ __device__ __forceinline__ void rowsync_body(const LevArgs &a, const int64_t n, 
       m = wave_min(m);  // :333
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        if (prev[j] == m && rnext[j] >= 0)  // :334 and the r < ref_len cut of :349-354
+        // :334 and the r < ref_len cut of :349-354
+        if (kHoistMask) {
+          if (__builtin_amdgcn_inverse_ballot_w64(__ballot(prev[j] == m) & has_next[j < HC ? j : 0]))
+            atomicOr(&bm[bm_word[j < HC ? j : 0]], bm_bit[j < HC ? j : 0]);
+        } else if (prev[j] == m && rnext[j] >= 0) {
           atomicOr(&bm[rnext[j] >> 5], 1u << (rnext[j] & 31));
+        }
       }
       if (lane == 0 && col0 == m && ref_len > 0) atomicOr(&bm[rank0 >> 5], 1u << (rank0 & 31));
       // (no wait here or below: the LDS serves one wave's instructions in order -- the read sees
