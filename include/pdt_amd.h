@@ -241,6 +241,29 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
  *   element; the caller writes pad_value into rows >= pad_from[n] at the end.
  *   width, Kp <= 64.
  * ------------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------
+ * One frame of CTCPrefixSearch with a LookupLanguageModel in the loop as one kernel
+ * (_decoding.py:1110-1163 around :636-934; scores: _lm.py:403-515): the back-off n-gram scores of
+ * every prefix's context (its last max_ngram - 1 tokens, read from y_prev), shallow fusion
+ * (valid_mixture = 0: ext = p_ctc * exp(beta * log_softmax(lm))) or the valid mixture, the
+ * per-prefix sorted lists and the prefix step.  State arguments and outputs are those of
+ * pdt_ctc_prefix_search_advance (without ext); the model's buffers are those of
+ * pdt_lookup_lm_log_probs (the forward index is required); max_ngram >= 2.
+ * width, Kp <= 32; max_ngram <= 16.  Same bits as pdt_lookup_lm_log_probs -> pdt_fusion_ext ->
+ * pdt_ctc_prefix_search_advance.
+ * ------------------------------------------------------------------------------------- */
+int pdt_ctc_lookup_lm_advance(
+    const float *nonext, int64_t ne_sn, int64_t ne_sv, const float *blank, int64_t bl_sn, int64_t N, int64_t Kp,
+    int64_t V, int64_t width, const float *nb_prev, int64_t nb_sn, int64_t nb_sk, const float *b_prev,
+    int64_t b_sn, int64_t b_sk, const int64_t *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn, int64_t yp_sk,
+    const int64_t *y_prev_last, int64_t la_sn, int64_t la_sk, const int64_t *y_prev_lens, int64_t le_sn,
+    int64_t le_sk, const uint8_t *prev_is_prefix, int64_t ip_sn, int64_t ip_sa, int64_t ip_sb,
+    const float *logps, const float *logbs, const int32_t *child_start, const int32_t *ids,
+    const int32_t *succ_start, const int32_t *succ_tok, const int32_t *succ_node, int64_t max_ngram, int64_t U,
+    int64_t sos, float beta, int valid_mixture, int64_t *y_next, int64_t *y_next_last, int64_t *y_next_lens,
+    float *nb_next, float *b_next, uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext,
+    void *stream);
+
 int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, int64_t N,
                          int64_t Kp, int64_t V, int64_t width, const float *log_probs_prev,
                          int64_t lp_sn, int64_t lp_sk, const int64_t *y_prev, int64_t S,

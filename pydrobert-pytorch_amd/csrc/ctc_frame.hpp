@@ -91,6 +91,11 @@ struct DenseCtx {
   int64_t yp_ss, yp_sk;
   int S;
   int lists_ready;       // the per-prefix lists are in L.tl_tok / L.tl_p already (built by the caller's waves)
+  // Instead of whole rows of extension probabilities: the K' x K' entries the frame reads besides
+  // the lists -- etab[k * etab_stride + j] = ext[k, clamp(last token of prefix j)] (a caller that
+  // forms each row on the fly and keeps only its list: beam_advance.hip, the n-gram fused step)
+  const float *etab = nullptr;
+  int etab_stride = 0;
 };
 
 // ints per next-token table: W * W, but at least 128 so that the table not in use (nxt_new
@@ -214,7 +219,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   const float p_blank = p[V] * inv;
   const int lastc = min(max(bm.last, 0), V - 1);
   const float pl = p[lastc] * inv;  // non-extension probability of my last token
-  const float e_last = DENSE ? dc.ext[me * dc.ext_sk + lastc * dc.ext_sv] : pl;
+  const float e_last = DENSE ? (dc.etab ? dc.etab[me * dc.etab_stride + me] : dc.ext[me * dc.ext_sk + lastc * dc.ext_sv]) : pl;
   const float tot = bm.nb + bm.b;
   const float B = tot * p_blank;
   float NB = bm.nb * pl;
@@ -271,7 +276,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
         if (child) {
           // to_match = the last token of the child (whose length is len_kk + 1)
           const float w = (lastc == last_kk ? 0.0f : nb_kk) + b_kk;
-          const float e = DENSE ? dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv] : pl;
+          const float e = DENSE ? (dc.etab ? dc.etab[kk * dc.etab_stride + me] : dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv]) : pl;
           add += w * e;
         }
       }

@@ -65,6 +65,12 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
         + [_P, _I64, _I64, _I64, _P, _P, _P, _P, _P],
     ),
+    "pdt_ctc_lookup_lm_advance": (
+        _INT,
+        [_P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
+        + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64]
+        + [_F, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    ),
     "pdt_beam_search_step": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]

@@ -15,7 +15,7 @@ import torch
 from torch.library import custom_op, register_autograd
 
 from . import _cabi, argcheck, config
-from ._lm import ExtractableSequentialLanguageModel, MixableSequentialLanguageModel
+from ._lm import ExtractableSequentialLanguageModel, LookupLanguageModel, MixableSequentialLanguageModel
 
 __all__ = [
     "BeamSearch",
@@ -544,6 +544,61 @@ class CTCPrefixSearch(torch.nn.Module):
                 return ctc_prefix_search(logits, self.width, lens)
             return self._frame_by_frame(logits, lens, prev)
 
+    @torch.jit.unused
+    def _fuses_lookup_lm(self, logits: torch.Tensor) -> bool:
+        """Whether a frame with the language model in the loop can run as ONE kernel
+        (csrc/ctc_lm_step.hip): the model is this package's n-gram LookupLanguageModel with its own
+        scoring methods (a subclass that overrides them must be called), of order two or more with its
+        forward index built, the beam fits the frame routine and nothing wants gradients."""
+        lm = self.lm
+        if type(lm) is not LookupLanguageModel or os.environ.get("PDT_CTC_LM_FUSED", "1") == "0":
+            return False
+        if lm.max_ngram < 2 or self.width > 32 or self.beta == 0.0:
+            return False
+        shift = 0 if (0 <= lm.sos < lm.vocab_size) else 1
+        if lm.succ_start.numel() != lm.vocab_size + shift + 2 or lm.logps.device != logits.device:
+            return False
+        return not (torch.is_grad_enabled() and logits.requires_grad)
+
+    @torch.jit.unused
+    def _lookup_lm_frame(
+        self, nonext: torch.Tensor, blank: torch.Tensor, nb: torch.Tensor, b: torch.Tensor, y: torch.Tensor,
+        y_last: torch.Tensor, y_lens: torch.Tensor, is_prefix: torch.Tensor,
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Scores of the n-gram model, the mix with the frame's probabilities and the prefix step in one
+        launch (include/pdt_amd.h: pdt_ctc_lookup_lm_advance)."""
+        lm, W = self.lm, self.width
+        N, V = nonext.shape
+        Kp, S = nb.size(1), y.size(0)
+        device = nonext.device
+        nonext, blank, nb, b = (_f32(x) for x in (nonext, blank, nb, b))
+        shift = 0 if (0 <= lm.sos < V) else 1
+        with torch.cuda.device(device):
+            y_next = torch.empty((S + 1, N, W), device=device, dtype=torch.long)
+            o_last = torch.empty((N, W), device=device, dtype=torch.long)
+            o_lens = torch.empty((N, W), device=device, dtype=torch.long)
+            o_src = torch.empty((N, W), device=device, dtype=torch.long)
+            o_nb = torch.empty((N, W), device=device, dtype=torch.float)
+            o_b = torch.empty((N, W), device=device, dtype=torch.float)
+            o_isp = torch.empty((N, W, W), device=device, dtype=torch.bool)
+            o_non = torch.empty((N, W), device=device, dtype=torch.bool)
+            if N:
+                rc = _cabi.lib().pdt_ctc_lookup_lm_advance(
+                    _cabi.ptr(nonext), nonext.stride(0), nonext.stride(1), _cabi.ptr(blank), blank.stride(0),
+                    N, Kp, V, W, _cabi.ptr(nb), nb.stride(0), nb.stride(1), _cabi.ptr(b), b.stride(0), b.stride(1),
+                    _cabi.ptr(y), S, y.stride(0), y.stride(1), y.stride(2),
+                    _cabi.ptr(y_last), y_last.stride(0), y_last.stride(1),
+                    _cabi.ptr(y_lens), y_lens.stride(0), y_lens.stride(1),
+                    _cabi.ptr(is_prefix), is_prefix.stride(0), is_prefix.stride(1), is_prefix.stride(2),
+                    _cabi.ptr(lm.logps), _cabi.ptr(lm.logbs), _cabi.ptr(lm.child_start), _cabi.ptr(lm.ids_wide),
+                    _cabi.ptr(lm.succ_start), _cabi.ptr(lm.succ_tok), _cabi.ptr(lm.succ_node),
+                    lm.max_ngram, V + shift + 1, lm.sos, float(self.beta), int(self.valid_mixture),
+                    _cabi.ptr(y_next), _cabi.ptr(o_last), _cabi.ptr(o_lens), _cabi.ptr(o_nb), _cabi.ptr(o_b),
+                    _cabi.ptr(o_isp), _cabi.ptr(o_src), _cabi.ptr(o_non), _cabi.stream_ptr(device),
+                )  # fmt: skip
+                _cabi.check(rc, "pdt_ctc_lookup_lm_advance")
+        return y_next, o_last, o_lens, o_nb, o_b, o_isp
+
     def _frame_by_frame(
         self, logits: torch.Tensor, lens: Optional[torch.Tensor], state: Dict[str, torch.Tensor]
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -569,8 +624,11 @@ class CTCPrefixSearch(torch.nn.Module):
         y_last = y_lens
         is_prefix = torch.ones((N, 1, 1), device=device, dtype=torch.bool)
         fuse = self.beta != 0.0
+        one_kernel = False  # the n-gram model scored inside the step kernel (csrc/ctc_lm_step.hip)
         if self.lm is not None:
             if fuse:
+                if not torch.jit.is_scripting():
+                    one_kernel = self._fuses_lookup_lm(logits) and dtype == torch.float
                 state = self.lm.update_input(state, y)
         Kp = 1
         # row of batch element n's first prefix in the flattened (N * K') LM state, before and after
@@ -581,6 +639,23 @@ class CTCPrefixSearch(torch.nn.Module):
             nonext_t, blank_t = probs[t, :, :V], probs[t, :, V]
             ext_t = nonext_t.unsqueeze(1).expand(N, Kp, V)
             state_next: Dict[str, torch.Tensor] = dict()
+            if one_kernel:
+                # (the model keeps no state between frames: nothing to extract or mix afterwards)
+                y_new, last_new, lens_new, nb_new, b_new, is_prefix = self._lookup_lm_frame(
+                    nonext_t, blank_t, nb, b, y, y_last, y_lens, is_prefix
+                )
+                if lens is not None:
+                    live = (lens > t).unsqueeze(1)
+                    if Kp < W:
+                        absent = nb.new_full((N, W - Kp), -float("inf"))
+                        nb, b = torch.cat([nb, absent], 1), torch.cat([b, absent], 1)
+                        y, y_lens = y.expand(-1, -1, W), y_lens.expand(-1, W)
+                    y_old = torch.cat([y, y.new_zeros((1, N, W))], 0)
+                    y_new = torch.where(live.unsqueeze(0), y_new, y_old)
+                    lens_new = torch.where(live, lens_new, y_lens)
+                    nb_new, b_new = torch.where(live, nb_new, nb), torch.where(live, b_new, b)
+                y, y_last, y_lens, nb, b, Kp = y_new, last_new, lens_new, nb_new, b_new, W
+                continue
             if self.lm is not None:
                 if fuse:
                     lm_lp, state_next = self.lm.calc_idx_log_probs(y.flatten(1), state, y_lens.flatten())

@@ -139,6 +139,38 @@ def test_ctc_prefix_search_with_lookup_lm_fusion():
     assert np.allclose(g["ctc_y_probs"], yp.cpu().numpy(), rtol=1e-5, atol=1e-30)
 
 
+@pytest.mark.parametrize("order", [2, 3, 4])
+def test_one_kernel_frames_equal_the_three_kernel_route(order, monkeypatch):
+    """A frame of CTCPrefixSearch with the n-gram model in the loop as ONE kernel
+    (csrc/ctc_lm_step.hip: scores, mix, lists, prefix step) against the route through
+    lookup_lm_log_probs -> fusion_ext -> ctc_prefix_search_advance (PDT_CTC_LM_FUSED=0): the same
+    arithmetic in the same order, so the same bits -- shallow fusion and valid mixture, ragged lens,
+    sos in and outside the vocabulary, widths below and above the number of tokens."""
+    rng = np.random.default_rng(700 + order)
+    big = 40 if order == 2 else 12
+    for V, W, T, N, sos, vm, beta in [(9, 4, 14, 5, -1, False, 0.3), (6, 8, 9, 3, 2, True, 0.6),
+                                      (big, 16, 25, 4, -1, False, 0.2), (10, 5, 12, 6, 0, True, 0.25)]:
+        dicts = random_dicts(rng, V, order, 0.5 if V ** order < 3000 else 0.1, sos if sos < 0 else None)
+        for v in range(V):  # (every token a unigram: a vocabulary entry without one scores -inf everywhere)
+            dicts[0].setdefault(v, (float(rng.normal()), float(rng.normal())) if order > 1 else float(rng.normal()))
+        lm = M.LookupLanguageModel(V, sos, dicts, destructive=True).to(DEV)
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        np.put_along_axis(lg, rng.integers(0, V + 1, (T, N, 1)), 5.0, 2)
+        lens = rng.integers(0, T + 1, N)
+        search = M.CTCPrefixSearch(W, beta, lm, valid_mixture=vm)
+        for ln in (None, torch.from_numpy(lens).to(DEV)):
+            monkeypatch.setenv("PDT_CTC_LM_FUSED", "0")
+            ey, eyl, eyp = search(_t(lg), ln)
+            monkeypatch.setenv("PDT_CTC_LM_FUSED", "1")
+            assert search._fuses_lookup_lm(_t(lg))
+            y, yl, yp = search(_t(lg), ln)
+            what = (order, V, W, vm, ln is None)
+            assert torch.isfinite(eyp[:, 0]).all(), what
+            assert torch.equal(yl, eyl) and torch.equal(yp, eyp), what
+            mask = torch.arange(y.shape[0], device=DEV).view(-1, 1, 1) < yl.unsqueeze(0)
+            assert torch.equal(torch.where(mask, y, ey), ey), what
+
+
 def test_beam_search_with_lookup_lm():
     g = golden()
     V, sos, N, dicts = dicts_from_golden(g, "C")
