@@ -249,19 +249,29 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
  * per-prefix sorted lists and the prefix step.  State arguments and outputs are those of
  * pdt_ctc_prefix_search_advance (without ext); the model's buffers are those of
  * pdt_lookup_lm_log_probs (the forward index is required); max_ngram >= 2.
+ * history_bytes: 8 -- y_prev / y_next hold int64 tokens, as the step functions exchange them; 2 --
+ * int16 tokens (V <= 32767): a caller that runs frame after frame keeps the (t, N, K) history in
+ * this narrow form between its frames (copying it is what a long search pays per frame).
+ * yn_ss / yn_sn / yn_sk: element strides of y_next, rows 0 .. S written ((S + 1, N, width) contiguous is
+ * N * width, width, 1; a frame loop that keeps token-contiguous (N, width, Smax) int16 histories --
+ * strides 1, width * Smax, Smax, Smax a multiple of 8 -- has them copied 16 bytes at a time).
+ * frame_lens (N,) int64 or NULL, frame: a batch element with frame_lens[n] <= frame has no such frame
+ * and keeps its beam -- y / lens / nb / b as they were (brought to `width`), one more row of zeros
+ * (_decoding.py:1165-1181); its last tokens and is-prefix outputs are unspecified.
  * width, Kp <= 32; max_ngram <= 16.  Same bits as pdt_lookup_lm_log_probs -> pdt_fusion_ext ->
  * pdt_ctc_prefix_search_advance.
  * ------------------------------------------------------------------------------------- */
 int pdt_ctc_lookup_lm_advance(
     const float *nonext, int64_t ne_sn, int64_t ne_sv, const float *blank, int64_t bl_sn, int64_t N, int64_t Kp,
     int64_t V, int64_t width, const float *nb_prev, int64_t nb_sn, int64_t nb_sk, const float *b_prev,
-    int64_t b_sn, int64_t b_sk, const int64_t *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn, int64_t yp_sk,
+    int64_t b_sn, int64_t b_sk, const void *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn, int64_t yp_sk,
     const int64_t *y_prev_last, int64_t la_sn, int64_t la_sk, const int64_t *y_prev_lens, int64_t le_sn,
     int64_t le_sk, const uint8_t *prev_is_prefix, int64_t ip_sn, int64_t ip_sa, int64_t ip_sb,
     const float *logps, const float *logbs, const int32_t *child_start, const int32_t *ids,
     const int32_t *succ_start, const int32_t *succ_tok, const int32_t *succ_node, int64_t max_ngram, int64_t U,
-    int64_t sos, float beta, int valid_mixture, int64_t *y_next, int64_t *y_next_last, int64_t *y_next_lens,
+    int64_t sos, float beta, int valid_mixture, void *y_next, int64_t *y_next_last, int64_t *y_next_lens,
     float *nb_next, float *b_next, uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext,
+    int history_bytes, const int64_t *frame_lens, int64_t frame, int64_t yn_ss, int64_t yn_sn, int64_t yn_sk,
     void *stream);
 
 int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, int64_t N,

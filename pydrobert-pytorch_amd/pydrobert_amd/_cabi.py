@@ -69,7 +69,7 @@ SIGNATURES = {
         _INT,
         [_P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
         + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64]
-        + [_F, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+        + [_F, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _I64, _I64, _I64, _I64, _P],
     ),
     "pdt_beam_search_step": (
         _INT,

@@ -9,7 +9,7 @@ user-supplied language model.
 """
 import math
 import os
-from typing import Any, Dict, Optional, Tuple
+from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 from torch.library import custom_op, register_autograd
@@ -563,10 +563,12 @@ class CTCPrefixSearch(torch.nn.Module):
     @torch.jit.unused
     def _lookup_lm_frame(
         self, nonext: torch.Tensor, blank: torch.Tensor, nb: torch.Tensor, b: torch.Tensor, y: torch.Tensor,
-        y_last: torch.Tensor, y_lens: torch.Tensor, is_prefix: torch.Tensor,
-    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+        y_last: torch.Tensor, y_lens: torch.Tensor, is_prefix: torch.Tensor, y_next: torch.Tensor,
+        lens: Optional[torch.Tensor], t: int,
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
         """Scores of the n-gram model, the mix with the frame's probabilities and the prefix step in one
-        launch (include/pdt_amd.h: pdt_ctc_lookup_lm_advance)."""
+        launch (include/pdt_amd.h: pdt_ctc_lookup_lm_advance).  ``y_next`` (t + 1, N, W) is written in
+        place (the caller alternates between two buffers); utterances with ``lens <= t`` keep their beam."""
         lm, W = self.lm, self.width
         N, V = nonext.shape
         Kp, S = nb.size(1), y.size(0)
@@ -574,7 +576,6 @@ class CTCPrefixSearch(torch.nn.Module):
         nonext, blank, nb, b = (_f32(x) for x in (nonext, blank, nb, b))
         shift = 0 if (0 <= lm.sos < V) else 1
         with torch.cuda.device(device):
-            y_next = torch.empty((S + 1, N, W), device=device, dtype=torch.long)
             o_last = torch.empty((N, W), device=device, dtype=torch.long)
             o_lens = torch.empty((N, W), device=device, dtype=torch.long)
             o_src = torch.empty((N, W), device=device, dtype=torch.long)
@@ -594,10 +595,12 @@ class CTCPrefixSearch(torch.nn.Module):
                     _cabi.ptr(lm.succ_start), _cabi.ptr(lm.succ_tok), _cabi.ptr(lm.succ_node),
                     lm.max_ngram, V + shift + 1, lm.sos, float(self.beta), int(self.valid_mixture),
                     _cabi.ptr(y_next), _cabi.ptr(o_last), _cabi.ptr(o_lens), _cabi.ptr(o_nb), _cabi.ptr(o_b),
-                    _cabi.ptr(o_isp), _cabi.ptr(o_src), _cabi.ptr(o_non), _cabi.stream_ptr(device),
+                    _cabi.ptr(o_isp), _cabi.ptr(o_src), _cabi.ptr(o_non), y.element_size(),
+                    _cabi.ptr(lens), t, y_next.stride(0), y_next.stride(1), y_next.stride(2),
+                    _cabi.stream_ptr(device),
                 )  # fmt: skip
                 _cabi.check(rc, "pdt_ctc_lookup_lm_advance")
-        return y_next, o_last, o_lens, o_nb, o_b, o_isp
+        return o_last, o_lens, o_nb, o_b, o_isp
 
     def _frame_by_frame(
         self, logits: torch.Tensor, lens: Optional[torch.Tensor], state: Dict[str, torch.Tensor]
@@ -625,11 +628,23 @@ class CTCPrefixSearch(torch.nn.Module):
         is_prefix = torch.ones((N, 1, 1), device=device, dtype=torch.bool)
         fuse = self.beta != 0.0
         one_kernel = False  # the n-gram model scored inside the step kernel (csrc/ctc_lm_step.hip)
+        hist_pair: List[torch.Tensor] = []
+        lens_dev: Optional[torch.Tensor] = None
         if self.lm is not None:
             if fuse:
                 if not torch.jit.is_scripting():
                     one_kernel = self._fuses_lookup_lm(logits) and dtype == torch.float
                 state = self.lm.update_input(state, y)
+                if one_kernel:
+                    # the history as 16-bit tokens between the frames (copying the (t, N, K) tensor is what a
+                    # long search pays per frame), in two buffers of the final size used in turn
+                    # ... each history token-contiguous -- (N, W, S) storage seen as (S, N, W) -- so that a
+                    # column of the new beam is a plain 16-byte-at-a-time copy of its source's
+                    y = y.to(torch.int16 if V <= 32767 else torch.long)
+                    s_max = (n_frames + 7) // 8 * 8
+                    hist_pair = [torch.empty((N, W, s_max), dtype=y.dtype, device=device).permute(2, 0, 1)
+                                 for _ in range(2)]
+                    lens_dev = None if lens is None else _i64(lens).contiguous()
         Kp = 1
         # row of batch element n's first prefix in the flattened (N * K') LM state, before and after
         # the beam has its full width
@@ -640,21 +655,13 @@ class CTCPrefixSearch(torch.nn.Module):
             ext_t = nonext_t.unsqueeze(1).expand(N, Kp, V)
             state_next: Dict[str, torch.Tensor] = dict()
             if one_kernel:
-                # (the model keeps no state between frames: nothing to extract or mix afterwards)
-                y_new, last_new, lens_new, nb_new, b_new, is_prefix = self._lookup_lm_frame(
-                    nonext_t, blank_t, nb, b, y, y_last, y_lens, is_prefix
+                # (the model keeps no state between frames: nothing to extract or mix afterwards; the
+                # history alternates between two buffers of the final size: no allocation per frame)
+                y_new = hist_pair[t % 2][: t + 1]
+                y_last, y_lens, nb, b, is_prefix = self._lookup_lm_frame(
+                    nonext_t, blank_t, nb, b, y, y_last, y_lens, is_prefix, y_new, lens_dev, t
                 )
-                if lens is not None:
-                    live = (lens > t).unsqueeze(1)
-                    if Kp < W:
-                        absent = nb.new_full((N, W - Kp), -float("inf"))
-                        nb, b = torch.cat([nb, absent], 1), torch.cat([b, absent], 1)
-                        y, y_lens = y.expand(-1, -1, W), y_lens.expand(-1, W)
-                    y_old = torch.cat([y, y.new_zeros((1, N, W))], 0)
-                    y_new = torch.where(live.unsqueeze(0), y_new, y_old)
-                    lens_new = torch.where(live, lens_new, y_lens)
-                    nb_new, b_new = torch.where(live, nb_new, nb), torch.where(live, b_new, b)
-                y, y_last, y_lens, nb, b, Kp = y_new, last_new, lens_new, nb_new, b_new, W
+                y, Kp = y_new, W
                 continue
             if self.lm is not None:
                 if fuse:
@@ -690,6 +697,8 @@ class CTCPrefixSearch(torch.nn.Module):
                 lens_new = torch.where(live, lens_new, y_lens)
                 nb_new, b_new = torch.where(live, nb_new, nb), torch.where(live, b_new, b)
             y, y_last, y_lens, nb, b, Kp = y_new, last_new, lens_new, nb_new, b_new, W
+        if y.dtype != torch.long or not y.is_contiguous():
+            y = y.long().contiguous()
         total = nb + b
         if Kp < W:  # no frame at all: fill the beam with absent entries (:1190-1200)
             y, y_lens = y.repeat(1, 1, W), y_lens.repeat(1, W)
