@@ -116,6 +116,20 @@ __device__ __forceinline__ u64 xor_shfl(u64 v) {
 // larger key.  B = top set bit of X.
 template <int X, int B, typename T>
 __device__ __forceinline__ T cmpx_stage(T key) {
+#ifndef PDT_NO_BANK_STAGES
+  if constexpr (sizeof(T) == 4 && (X == 4 || X == 7 || X == 8 || X == 15)) {
+    // partners a DPP row operation reaches AND "keep the larger" lanes that are whole 4-lane banks
+    // (B = 4: banks 0 and 2; B = 8: banks 0 and 1): the bank mask of the DPP operand does the
+    // selection -- max over the lower banks, min over the upper ones, both from the stage's input:
+    // 2 VALU, no lane predicate (l ^ 4 went through the LDS crossbar before: 4 instructions)
+    constexpr int LO = B == 4 ? 0x5 : 0x3, HI = 0xf & ~LO;
+    constexpr int C_LO = X == 4 ? 0x104 /* row_shl:4 */ : (X == 7 ? 0x141 : (X == 8 ? 0x128 : 0x140));
+    constexpr int C_HI = X == 4 ? 0x114 /* row_shr:4 */ : C_LO;
+    const unsigned k = (unsigned)key;
+    const unsigned t = max(k, (unsigned)__builtin_amdgcn_update_dpp(0, (int)k, C_LO, 0xf, LO, false));
+    return (T)min(t, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)k, C_HI, 0xf, HI, false));
+  }
+#endif
   const T other = xor_shfl<X>(key);
   const bool lower = lane_predicate<lanes_with_bit_clear(B)>();
   if constexpr (sizeof(T) == 4 && xor_is_dpp<X>()) {
