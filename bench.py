@@ -621,14 +621,14 @@ def run_rank(args):
     achieved = alg_bytes[dom] * N / (op_ms[dom] * 1e-3) / 1e9
     kernel_names = {
         "error_rate": "pdt::lev_classify_kernel<8> + pdt::lev_bitpar_kernel",
-        "prefix_error_rates": "pdt::lev_classify_kernel<8> + pdt::lev_bitpar_kernel",
+        "prefix_error_rates": "pdt::lev_bitpar_kernel (tables of the error_rate call reused)",
         "optimal_completion": "pdt::lev_rowsync_kernel<false, false> + pdt::oc_expand_tiles_kernel<8>",
         "ctc_prefix_search": ctc_kernel_name(args.V, args.beam),
     }
     # HBM bytes per launch and instruction counts from the rocprofv3 PMC passes (profiles/), only
     # when they were collected for this very configuration
     traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "r02_ctc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r03_ctc_traffic.json")
     if dom == "ctc_prefix_search" and os.path.exists(tpath):
         rec = json.load(open(tpath))
         if rec.get("config") == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
@@ -640,7 +640,7 @@ def run_rank(args):
                     "wave_insts_per_launch": insts,
                     "issue_cycles_per_wave_inst": cyc,
                     "pipe_busy_frac": None if cyc is None else insts * cyc / (1024 * 2.4e9 * op_ms[dom] * 1e-3),
-                    "source": "profiles/r02_kernels.json (SQ_INSTS_VALU), profiles/r02_valu_issue.json "
+                    "source": "profiles/r03_ctc_traffic.json (SQ_INSTS_VALU: profiles/collect_r03.sh), profiles/r02_valu_issue.json "
                               "(measured issue cycles per wave64 VALU instruction at 8 waves/SIMD)",
                 }
 
@@ -689,6 +689,9 @@ def run_rank(args):
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "traffic_source": None if traffic is None else
+                    "profiles/r03_ctc_traffic.json: FETCH_SIZE / WRITE_SIZE PMC passes of profiles/collect_r03.sh over this "
+                    "configuration (2 x FETCH + WRITE), a committed record -- not collected in this run",
                 "valu": valu,
                 "note": "priced against HBM as the contract asks; the kernel's own limiter is the "
                         "consumer wave's dependent instruction chain (DESIGN.md section 4.3)",
