@@ -32,6 +32,10 @@
 
 #include "lev_classes.hpp"
 
+#ifndef PDT_OC_GROUP
+#define PDT_OC_GROUP 4  // columns per table look-up of the optimal-completion block minima
+#endif
+
 namespace pdt {
 
 struct BitparArgs {
@@ -51,6 +55,10 @@ struct BitparArgs {
   int32_t *lens;   // [N][2]     ref_len, hyp_len
   uint2 *yh;       // [N][Y]     (block presence, offset) of the class of Y[j]; (0, 0) = no match
   uint32_t *msk;   // [N][X + 1] packed match-mask words
+  // optimal-completion form (oc_bitpar_kernel): bit-vectors along the REFERENCE, hypothesis consumed
+  int oc;
+  int64_t *class_tokens;  // [N][R]  the distinct reference tokens, ascending (pdt_oc_mask's output)
+  uint16_t *xcls;         // [N][X]  class of every reference position
 };
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -129,19 +137,29 @@ __global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, c
   }
   int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;  // rows that are updated (:286-288)
   if (Heff < 0) Heff = 0;
-  // bit-vectors along the hypothesis (only its first Heff tokens matter), reference consumed
-  const int64_t *x = a.hyp, *y = a.ref;
-  const int64_t x_st = a.hyp_st, y_st = a.ref_st, xoff = hoff, yoff = roff;
-  const int x_len = Heff, y_len = ref_len;
+  // bit-vectors along the hypothesis (only its first Heff tokens matter), reference consumed;
+  // the other way round for optimal completion, whose row minima run along the reference
+  const bool oc = a.oc != 0;
+  const int64_t *x = oc ? a.ref : a.hyp, *y = oc ? a.hyp : a.ref;
+  const int64_t x_st = oc ? a.ref_st : a.hyp_st, y_st = oc ? a.hyp_st : a.ref_st;
+  const int64_t xoff = oc ? roff : hoff, yoff = oc ? hoff : roff;
+  const int x_len = oc ? ref_len : Heff, y_len = oc ? Heff : ref_len;
 
   // ---- distinct tokens of X in ascending order (lev_classes.hpp) ---------------------------
   int64_t xt[NR];
   const int U = distinct_sorted<NR>(x, x_len, x_st, xoff, xt, ctok);
   wave_sync();
   for (int k = lane; k < U; k += PDT_WAVE) po[k] = make_uint2(0u, 0u);
+  if (oc)
+    for (int k = lane; k < U; k += PDT_WAVE) a.class_tokens[n * (int64_t)a.R + k] = ctok[k];
   const int lgP = search_depth(U);
   int xc[NR];  // classes of X[lane + 64 q]
   classes_of<NR>(ctok, U, lgP, xt, xc);
+  if (oc) {
+#pragma unroll
+    for (int q = 0; q < NR; ++q)
+      if (lane + q * PDT_WAVE < x_len) a.xcls[n * (int64_t)X + lane + q * PDT_WAVE] = (uint16_t)xc[q];
+  }
   for (int j0 = 0; j0 < y_len; j0 += 8 * PDT_WAVE) {
     int64_t yt[8];
     int c[8];
@@ -449,6 +467,455 @@ int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStrea
   rc = set_lds(reinterpret_cast<const void *>(kern), smem);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(128), smem, stream, a, (int)p.lds_sub, (int)(p.lds_sub * p.upw));
+  return (int)hipGetLastError();
+}
+
+// ---- optimal completion: the arg-min sets of every row, bit-parallel --------------------------
+// (reference _string.py:271-278, :333-354: after hypothesis token h, the set of reference tokens
+// ref[c] over the columns c < ref_len where D[h][c] is the row minimum.)
+//
+// Bit-vectors run along the REFERENCE here: after h hypothesis tokens Pv / Mv hold
+// D[h][c] - D[h][c-1] for every column, so the row's profile relative to D[h][0] is a prefix sum of
+// +1 / -1 bits and the row minimum needs no DP value at all.  16 lanes (one DPP row) per utterance,
+// four utterances per wave, lane b owns columns 32 b + 1 .. 32 b + 32, every lane on the SAME row:
+//   * the 512-bit addition of Myers' step is 16 word additions whose carries are resolved on the
+//     scalar unit -- generate / propagate lane masks, one 64-bit add (Gm << 1) + Pm, xor;
+//   * the shifts take the neighbour's word through a row_shr:1 and one v_alignbit;
+//   * a block's (total, min prefix, arg-min bits) come from a table over G columns at a time
+//     (index = G plus-bits | G minus-bits), block starts from a 4-step row scan, the row minimum
+//     from a 4-step row all-reduce;
+//   * the arg-min bits are turned into class bits by LDS ORs (class of ref[c] per column, staged),
+//     and the row's W words leave with one exchange each.
+// Utterances whose hypothesis has ended write empty sets.
+#ifndef PDT_OC_CHUNK
+#define PDT_OC_CHUNK 8
+#endif
+constexpr int kOcChunk = PDT_OC_CHUNK;  // rows per pass of oc_bitpar_kernel
+
+struct OcBitArgs {
+  int N, X, Y, W, Hout, exclude_last;
+  const int32_t *lens;
+  const uint2 *yh;
+  const uint32_t *msk;
+  const uint16_t *xcls;
+  uint32_t *bitmask;
+  int32_t *max_count;
+};
+
+#define PDT_DPP_QUAD_XOR1 0xB1
+#define PDT_DPP_QUAD_XOR2 0x4E
+#define PDT_DPP_ROW_HALF_MIRROR 0x141
+#define PDT_DPP_ROW_MIRROR 0x140
+
+// entry: (sum + G) | (min prefix + G) << 4 | arg-min bits << 8 over G columns
+template <int G>
+__device__ __forceinline__ void oc_build_table(uint16_t *tab) {
+  for (int idx = (int)threadIdx.x; idx < (1 << (2 * G)); idx += (int)blockDim.x) {
+    const int p = idx & ((1 << G) - 1), m = idx >> G;
+    int run = 0, mn = 99, am = 0;
+    for (int j = 0; j < G; ++j) {
+      run += ((p >> j) & 1) - ((m >> j) & 1);
+      if (run < mn) {
+        mn = run;
+        am = 1 << j;
+      } else if (run == mn) {
+        am |= 1 << j;
+      }
+    }
+    tab[idx] = (uint16_t)((run + G) | ((mn + G) << 4) | (am << 8));
+  }
+}
+
+// total of the block's deltas, its minimum prefix (over the prefixes of length >= 1) and the
+// columns that reach it
+// byte `I` of z, times two (one SDWA shift: the table's byte offset)
+template <int I>
+__device__ __forceinline__ unsigned byte_times2(const unsigned z, const unsigned one) {
+  unsigned r;
+  if (I == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(one), "v"(z));
+  if (I == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(one), "v"(z));
+  if (I == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(one), "v"(z));
+  if (I == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(one), "v"(z));
+  return r;
+}
+
+// the eight table entries of a block: index = plus nibble | minus nibble << 4, a byte of one of two
+// interleaved words
+__device__ __forceinline__ void oc_table_reads(const uint16_t *tab, const unsigned pv, const unsigned mv,
+                                               unsigned (&e)[8]) {
+  const unsigned ze = (pv & 0x0f0f0f0fu) | ((mv << 4) & 0xf0f0f0f0u);  // nibbles 0, 2, 4, 6
+  const unsigned zo = ((pv >> 4) & 0x0f0f0f0fu) | (mv & 0xf0f0f0f0u);  // nibbles 1, 3, 5, 7
+  unsigned one = 1u;
+  asm volatile("" : "+v"(one));
+  const unsigned char *t = reinterpret_cast<const unsigned char *>(tab);
+  e[0] = *reinterpret_cast<const uint16_t *>(t + byte_times2<0>(ze, one));
+  e[1] = *reinterpret_cast<const uint16_t *>(t + byte_times2<0>(zo, one));
+  e[2] = *reinterpret_cast<const uint16_t *>(t + byte_times2<1>(ze, one));
+  e[3] = *reinterpret_cast<const uint16_t *>(t + byte_times2<1>(zo, one));
+  e[4] = *reinterpret_cast<const uint16_t *>(t + byte_times2<2>(ze, one));
+  e[5] = *reinterpret_cast<const uint16_t *>(t + byte_times2<2>(zo, one));
+  e[6] = *reinterpret_cast<const uint16_t *>(t + byte_times2<3>(ze, one));
+  e[7] = *reinterpret_cast<const uint16_t *>(t + byte_times2<3>(zo, one));
+}
+
+// total of the block's deltas, its minimum prefix (over the prefixes of length >= 1) and the
+// columns that reach it
+__device__ __forceinline__ void oc_block_decode(const unsigned (&e)[8], int &total, int &best, unsigned &am) {
+  constexpr int G = 4, NG = 8;
+  int run = 0, cand[NG];
+  best = 1 << 20;
+#pragma unroll
+  for (int k = 0; k < NG; ++k) {
+    cand[k] = run + (int)((e[k] >> 4) & 15u) - G * (k + 1);
+    best = min(best, cand[k]);
+    run += (int)(e[k] & 15u);
+  }
+  am = 0u;
+#pragma unroll
+  for (int k = 0; k < NG; ++k) am |= cand[k] == best ? (e[k] >> 8) << (G * k) : 0u;
+  total = run - G * NG;
+}
+
+// min over the 16 lanes of a DPP row, in every lane (written out: left to the compiler every
+// stage is two moves, the DPP move and the v_min)
+__device__ __forceinline__ int row_all_min(int v) {
+  asm volatile(
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_min_i32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
+// The arg-min columns of a row come in runs (a dozen neighbouring columns at the bench shape), i.e.
+// in ONE lane's word, and turning a bit into a class bit is a dependent LDS read + LDS OR.  Four
+// exchange stages (partner lanes l^8, l^7, l^2, l^1 inside the DPP row; keep half of the bits, take
+// the partner's other half rotated by the stage's distance) permute the 512 bits of an utterance so
+// that any 16 neighbouring columns end up in 16 different lanes.  Which column a (lane, bit) pair
+// holds afterwards is found once per kernel by sending the nine bit-planes of the column index
+// through the same network; the class table is staged in that order.
+struct OcSpread {
+  unsigned keep[4];  // bits this lane keeps at each stage
+  unsigned amt[4];   // v_alignbit shift that rotates the partner's word the right way
+};
+__device__ __forceinline__ OcSpread oc_spread_setup(const int b) {
+  OcSpread sp;
+  const unsigned clear[4] = {0x00ff00ffu, 0x0f0f0f0fu, 0x33333333u, 0x55555555u};  // bit d of the position clear
+  const int dist[4] = {8, 4, 2, 1};
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const bool hi = (b & dist[s]) != 0;
+    sp.keep[s] = hi ? ~clear[s] : clear[s];
+    sp.amt[s] = hi ? (unsigned)dist[s] : (unsigned)(32 - dist[s]);  // alignbit(x, x, k) rotates right by k
+  }
+  return sp;
+}
+__device__ __forceinline__ unsigned oc_spread(const OcSpread &sp, unsigned x) {
+  unsigned p, t;
+  auto bfi = [](const unsigned mask, const unsigned a, const unsigned b) {  // (mask & a) | (~mask & b)
+    unsigned r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+  };
+  p = (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0x128 /* row_ror:8 */, 0xf, 0xf, true);
+  t = __builtin_amdgcn_alignbit(p, p, sp.amt[0]);
+  x = bfi(sp.keep[0], x, t);
+  p = (unsigned)__builtin_amdgcn_mov_dpp((int)x, PDT_DPP_ROW_HALF_MIRROR, 0xf, 0xf, true);
+  t = __builtin_amdgcn_alignbit(p, p, sp.amt[1]);
+  x = bfi(sp.keep[1], x, t);
+  p = (unsigned)__builtin_amdgcn_mov_dpp((int)x, PDT_DPP_QUAD_XOR2, 0xf, 0xf, true);
+  t = __builtin_amdgcn_alignbit(p, p, sp.amt[2]);
+  x = bfi(sp.keep[2], x, t);
+  p = (unsigned)__builtin_amdgcn_mov_dpp((int)x, PDT_DPP_QUAD_XOR1, 0xf, 0xf, true);
+  t = __builtin_amdgcn_alignbit(p, p, sp.amt[3]);
+  x = bfi(sp.keep[3], x, t);
+  return x;
+}
+
+template <int G>
+__global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const int lds_per_sub) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
+  oc_build_table<G>(tab);
+  const int lane = lane_id();
+  const int wave = (int)(threadIdx.x >> 6), nwave = (int)(blockDim.x >> 6);
+  const int q = lane >> 4, b = lane & 15;
+  const int64_t n_raw = ((int64_t)blockIdx.x * nwave + wave) * 4 + q;
+  const bool valid = n_raw < a.N;
+  const int64_t n = valid ? n_raw : (int64_t)a.N - 1;
+  const int X = a.X > 0 ? a.X : 1, Y = a.Y > 0 ? a.Y : 1;
+  unsigned char *base = smem + ((size_t)2 << (2 * G)) + (size_t)(wave * 4 + q) * lds_per_sub;
+  uint2 *yh_l = reinterpret_cast<uint2 *>(base);
+  unsigned *msk_l = reinterpret_cast<unsigned *>(yh_l + Y);
+  unsigned *bm = msk_l + X + 1;
+  uint16_t *xc_l = reinterpret_cast<uint16_t *>(bm + 16 * kOcChunk);  // (bm: one 16-word row per row of a pass)
+
+  const int ref_len = valid ? a.lens[2 * n] : 0, hyp_len = valid ? a.lens[2 * n + 1] : 0;
+  int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;
+  if (Heff < 0) Heff = 0;
+
+  {  // this utterance's tables: 16 lanes, eight loads in flight each
+    const uint2 *src = a.yh + n * (int64_t)Y;
+    for (int j0 = b; j0 < Heff; j0 += 8 * 16) {
+      uint2 v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = j0 + r * 16 < Heff ? src[j0 + r * 16] : make_uint2(0u, 0u);
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (j0 + r * 16 < Heff) yh_l[j0 + r * 16] = make_uint2(v[r].x, v[r].y * 4u);  // (byte offset of the class's words)
+    }
+    if (Heff == 0 && b == 0) yh_l[0] = make_uint2(0u, 0u);
+    const unsigned *msrc = a.msk + n * (int64_t)(X + 1);
+    for (int i0 = b; i0 <= ref_len; i0 += 8 * 16) {
+      unsigned v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = i0 + r * 16 <= ref_len ? msrc[i0 + r * 16] : 0u;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+        if (i0 + r * 16 <= ref_len) msk_l[i0 + r * 16] = v[r];
+    }
+    for (int r = 0; r < kOcChunk; ++r) bm[16 * r + b] = 0u;
+  }
+  const OcSpread sp = oc_spread_setup(b);
+  int rank0;  // class of ref[0]
+  {  // xc_l[32 b + t] = class of ref[c] for the column c that the network leaves in bit t of lane b
+    unsigned plane[9];
+    const unsigned low[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) plane[k] = oc_spread(sp, k < 5 ? low[k] : (((b >> (k - 5)) & 1) ? 0xffffffffu : 0u));
+    const uint16_t *csrc = a.xcls + n * (int64_t)X;
+    rank0 = ref_len > 0 ? (int)csrc[0] : 0;
+    for (int t0 = 0; t0 < 32; t0 += 8) {
+      uint16_t v[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        int c = 1;  // column = (bit index of the unspread layout) + 1
+#pragma unroll
+        for (int k = 0; k < 9; ++k) c += (int)((plane[k] >> (t0 + r)) & 1u) << k;
+        v[r] = c < ref_len ? csrc[c] : (uint16_t)0;
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) xc_l[32 * b + t0 + r] = v[r];
+    }
+  }
+  __syncthreads();
+
+  const int W = a.W;
+  int max_cnt = 0;
+  if (valid && b < W) {  // h = 0: only column 0 (:271-278)
+    unsigned w = 0u;
+    if (ref_len > 0 && (rank0 >> 5) == b) w = 1u << (rank0 & 31);
+    a.bitmask[((int64_t)0 * a.N + n) * W + b] = w;
+  }
+  if (ref_len > 0) max_cnt = 1;
+
+  // columns of this block that exist (<= ref_len) and those that have a next token (< ref_len)
+  const int nvalid = min(max(ref_len - 32 * b, 0), 32), nnext = min(max(ref_len - 1 - 32 * b, 0), 32);
+  const unsigned vmask = nvalid == 32 ? 0xffffffffu : (1u << nvalid) - 1u;
+  const unsigned nmask = nnext == 32 ? 0xffffffffu : (1u << nnext) - 1u;
+  const unsigned lowmask = (1u << b) - 1u, bbit = 1u << b;
+  const int jcap = Heff > 0 ? Heff - 1 : 0;
+  int hmax = Heff;
+#pragma unroll
+  for (int t = 16; t < PDT_WAVE; t <<= 1) hmax = max(hmax, __shfl_xor(hmax, t));
+  hmax = __builtin_amdgcn_readfirstlane(hmax);
+
+  uint32_t *out_row = a.bitmask + n * (int64_t)W + b;  // row 0 of this lane's word
+  const int64_t row_stride = (int64_t)a.N * W;
+  unsigned Pv = 0xffffffffu, Mv = 0u;  // row 0: D[0][c] = c
+  unsigned xp = b == 0 ? 0x80000000u : 0u, xm = 0u;  // (lane 0 of a row keeps D[h][0] - D[h-1][0] = +1)
+  u64 notop = 0x7fff7fff7fff7fffull;  // carries stay inside an utterance's 16 lanes
+  asm volatile("" : "+s"(notop));     // (in a register pair: the literal would split every AND in two)
+  // Four rows per pass, phase by phase, so that the LDS round trips of a phase (match words, table
+  // entries, classes, the rows' words) overlap across the four rows instead of adding up per row:
+  // only the 20-instruction recurrence depends on the row before.
+  constexpr int kChunk = kOcChunk;
+  constexpr int NG = 8;
+  for (int h0 = 0; h0 < hmax; h0 += kChunk) {
+    unsigned eq[kChunk];
+    {
+      uint2 hq[kChunk];
+#pragma unroll
+      for (int r = 0; r < kChunk; ++r) hq[r] = yh_l[min(h0 + r, jcap)];
+#pragma unroll
+      for (int r = 0; r < kChunk; ++r)
+        eq[r] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(msk_l) + hq[r].y +
+                                                    4u * (unsigned)__popc(hq[r].x & lowmask));
+#pragma unroll
+      for (int r = 0; r < kChunk; ++r) eq[r] = (hq[r].x & bbit) ? eq[r] : 0u;
+    }
+    unsigned e[kChunk][NG];
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) {
+      {  // Myers' step on the 512-bit column
+        const unsigned Eq = eq[r];
+        const unsigned Xv = Eq | Mv;
+        const unsigned A = Eq & Pv;
+        unsigned sum;
+        u64 Gm;
+        asm volatile("v_add_co_u32 %0, %1, %2, %3" : "=v"(sum), "=s"(Gm) : "v"(A), "v"(Pv));
+        Gm &= notop;
+        const u64 Pm = __ballot(sum == 0xffffffffu) & notop;
+        const u64 C = ((Gm << 1) + Pm) ^ Pm;
+        asm volatile("v_addc_co_u32 %0, %1, 0, %2, %3" : "=v"(sum), "=s"(Gm) : "v"(sum), "s"(C));
+        const unsigned Xh = (sum ^ Pv) | Eq;
+        const unsigned Phw = Mv | ~(Xh | Pv);
+        const unsigned Mhw = Pv & Xh;
+        xp = (unsigned)__builtin_amdgcn_update_dpp((int)xp, (int)Phw, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
+        xm = (unsigned)__builtin_amdgcn_update_dpp((int)xm, (int)Mhw, PDT_DPP_ROW_SHR(1), 0xf, 0xf, false);
+        const unsigned Ph = __builtin_amdgcn_alignbit(Phw, xp, 31);
+        const unsigned Mh = __builtin_amdgcn_alignbit(Mhw, xm, 31);
+        Pv = Mh | ~(Xv | Ph);
+        Mv = Ph & Xv;
+      }
+      oc_table_reads(tab, Pv & vmask, Mv & vmask, e[r]);
+    }
+    unsigned rest[kChunk], or0[kChunk], or1[kChunk];
+    int c0[kChunk], c1[kChunk];
+    bool zero_min[kChunk];
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) {
+      const bool active = h0 + r + 1 <= Heff;
+      int total, best;
+      unsigned am;
+      oc_block_decode(e[r], total, best, am);
+      int incl = total;  // D[h][32 b + 32] - D[h][0]
+      incl += dpp_or<PDT_DPP_ROW_SHR(1)>(incl, 0);
+      incl += dpp_or<PDT_DPP_ROW_SHR(2)>(incl, 0);
+      incl += dpp_or<PDT_DPP_ROW_SHR(4), 0xf, 0xe>(incl, 0);
+      incl += dpp_or<PDT_DPP_ROW_SHR(8), 0xf, 0xc>(incl, 0);
+      const int cand = incl - total + best;
+      const int m = row_all_min(min(cand, 0));  // (0: column 0)
+      zero_min[r] = active && m == 0;
+      unsigned bits = (active && cand == m) ? am & nmask : 0u;  // :334 and the c < ref_len cut of :349-354
+      bits = oc_spread(sp, bits);
+      // the first two bits of a lane go the short way (a lane rarely holds more)
+      const int j0 = bits ? __builtin_ctz(bits) : 0;
+      or0[r] = bits ? 1u : 0u;
+      bits &= bits - 1u;
+      const int j1 = bits ? __builtin_ctz(bits) : 0;
+      or1[r] = bits ? 1u : 0u;
+      bits &= bits - 1u;
+      rest[r] = bits;
+      c0[r] = xc_l[32 * b + j0];
+      c1[r] = xc_l[32 * b + j1];
+    }
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) {  // (an OR of 0 where there is no bit: no branches)
+      unsigned *bmr = bm + 16 * r;
+      atomicOr(&bmr[c0[r] >> 5], or0[r] << (c0[r] & 31));
+      atomicOr(&bmr[c1[r] >> 5], or1[r] << (c1[r] & 31));
+      if (b == 0) atomicOr(&bmr[rank0 >> 5], (zero_min[r] && ref_len > 0) ? 1u << (rank0 & 31) : 0u);
+    }
+    unsigned any_rest = 0u;
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) any_rest |= rest[r];
+    if (__ballot(any_rest != 0u)) {
+#pragma unroll
+      for (int r = 0; r < kChunk; ++r) {
+        unsigned bits = rest[r];
+        while (__ballot(bits != 0u)) {
+          if (bits) {
+            const int cls = xc_l[32 * b + __builtin_ctz(bits)];
+            bits &= bits - 1u;
+            atomicOr(&bm[16 * r + (cls >> 5)], 1u << (cls & 31));
+          }
+        }
+      }
+    }
+    // (the LDS serves one wave's instructions in order: the exchanges see every lane's OR)
+    __builtin_amdgcn_wave_barrier();
+    unsigned w[kChunk];
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r)
+      w[r] = __hip_atomic_exchange(&bm[16 * r + b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_wave_barrier();
+    if (valid && b < W) {
+#pragma unroll
+      for (int r = 0; r < kChunk; ++r)
+        if (h0 + r + 1 <= hmax && h0 + r + 1 < a.Hout) out_row[(h0 + r + 1) * row_stride] = w[r];
+    }
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) {
+      int cnt = __popc(w[r]);
+      cnt += dpp_or<PDT_DPP_QUAD_XOR1>(cnt, 0);
+      cnt += dpp_or<PDT_DPP_QUAD_XOR2>(cnt, 0);
+      cnt += dpp_or<PDT_DPP_ROW_HALF_MIRROR>(cnt, 0);
+      cnt += dpp_or<PDT_DPP_ROW_MIRROR>(cnt, 0);
+      max_cnt = max(max_cnt, cnt);
+    }
+  }
+  // rows nobody in the wave reaches (`& not_done`, :334)
+  for (int h = hmax + 1; h < a.Hout; ++h)
+    if (valid && b < W) a.bitmask[((int64_t)h * a.N + n) * W + b] = 0u;
+  if (valid && b == 0 && a.max_count && max_cnt > 0) atomicMax(a.max_count, max_cnt);
+}
+
+// per-utterance LDS of oc_bitpar_kernel
+static size_t oc_bitpar_lds_sub(int X, int Y) {
+  const size_t Xs = (size_t)(X > 0 ? X : 1), Ys = (size_t)(Y > 0 ? Y : 1);
+  return align_up(Ys * 8 + (Xs + 1) * 4 + 64 * kOcChunk + 512 * 2, 16);  // (the class table is staged in spread order: 16 x 32 entries)
+}
+
+constexpr int64_t kOcBitparMaxR = 512;  // 16 lanes of 32 columns
+
+int64_t oc_bitpar_workspace_bytes(int64_t R, int64_t H, int64_t N) {
+  if (R > kOcBitparMaxR || H < 0 || N <= 0) return 0;
+  const BitparPlan p = plan_bitpar(R, H, N);
+  if (!p.ok) return 0;
+  return (int64_t)(p.total + align_up((size_t)N * (size_t)(R > 0 ? R : 1) * 2, 256));
+}
+
+// Unit costs only.  Returns -1 when the shape is not served (the caller falls back to
+// lev_rowsync.hip), else the launch status.
+int launch_oc_mask_bitpar(const LevArgs &la, void *ws, int64_t ws_bytes, hipStream_t stream) {
+  if (la.R > kOcBitparMaxR || !ws) return -1;
+  const BitparPlan p = plan_bitpar(la.R, la.H, la.N);
+  const int64_t need = oc_bitpar_workspace_bytes(la.R, la.H, la.N);
+  if (!p.ok || need == 0 || need > ws_bytes) return -1;
+  BitparArgs a{};
+  a.ref = la.ref; a.hyp = la.hyp;
+  a.ref_st = la.ref_st; a.ref_sn = la.ref_sn; a.hyp_st = la.hyp_st; a.hyp_sn = la.hyp_sn;
+  a.R = la.R; a.H = la.H; a.N = la.N;
+  a.has_eos = la.has_eos; a.include_eos = la.include_eos; a.eos = la.eos;
+  a.exclude_last = la.exclude_last; a.norm = 0; a.mode = -1;
+  a.status = la.status;
+  a.X = la.R;
+  a.Y = la.H;
+  a.lgL = 4; a.upw = 4;
+  unsigned char *w = reinterpret_cast<unsigned char *>(ws);
+  a.lens = reinterpret_cast<int32_t *>(w + p.off_lens);
+  a.yh = reinterpret_cast<uint2 *>(w + p.off_yh);
+  a.msk = reinterpret_cast<uint32_t *>(w + p.off_msk);
+  a.oc = 1;
+  a.class_tokens = la.class_tokens;
+  a.xcls = reinterpret_cast<uint16_t *>(w + p.total);
+  auto ck = lev_classify_kernel<8>;
+  int rc = set_lds(reinterpret_cast<const void *>(ck), p.lds_classify * 4);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ck, dim3((unsigned)((a.N + 3) / 4)), dim3(256), p.lds_classify * 4, stream, a,
+                     (int)p.lds_classify);
+
+  OcBitArgs o{};
+  o.N = la.N; o.X = la.R; o.Y = la.H; o.W = la.W;
+  o.Hout = la.H + (la.exclude_last ? 0 : 1);
+  o.exclude_last = la.exclude_last;
+  o.lens = a.lens; o.yh = a.yh; o.msk = a.msk; o.xcls = a.xcls;
+  o.bitmask = la.bitmask; o.max_count = la.max_count;
+  constexpr int G = PDT_OC_GROUP;
+  const size_t sub = oc_bitpar_lds_sub(o.X, o.Y);
+  const size_t tab_bytes = (size_t)2 << (2 * G);
+  int nwave = 4;  // waves per workgroup: the table is shared, the utterances' tables are not
+  while (nwave > 1 && (tab_bytes + sub * 4 * nwave > (size_t)150 * 1024 || (int64_t)nwave * 4 * 256 > la.N)) nwave >>= 1;
+  const size_t smem = tab_bytes + sub * 4 * nwave;
+  if (smem > (size_t)150 * 1024) return -1;
+  auto kern = oc_bitpar_kernel<G>;
+  rc = set_lds(reinterpret_cast<const void *>(kern), smem);
+  if (rc) return rc;
+  const int64_t per_wg = 4 * nwave;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((la.N + per_wg - 1) / per_wg)), dim3(64 * nwave), smem, stream, o, (int)sub);
   return (int)hipGetLastError();
 }
 

@@ -12,6 +12,8 @@ int launch_lev_skewed(LevArgs a, hipStream_t stream);
 int launch_lev_rowsync(LevArgs a, bool exact, hipStream_t stream);
 int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStream_t stream, bool classified);
 int launch_oc_mask_generic(const LevArgs &a, bool inexact, void *ws, int64_t ws_bytes, hipStream_t stream);
+int launch_oc_mask_bitpar(const LevArgs &a, void *ws, int64_t ws_bytes, hipStream_t stream);
+int64_t oc_bitpar_workspace_bytes(int64_t R, int64_t H, int64_t N);
 int launch_oc_expand_generic(const uint32_t *bitmask, const int64_t *class_tokens, int R, int Hout,
                              int64_t N, int C, int64_t padding, int64_t *targets, int64_t tgt_sh,
                              int64_t tgt_sn, hipStream_t stream);
@@ -52,6 +54,13 @@ static bool bitpar_enabled() {
     return !(e && e[0] == '0');
   }();
   return on;
+}
+
+// PDT_OC_BITPAR=0 keeps optimal completion on the row-synchronous kernel (read at every call:
+// the tests run both in one process).
+static bool oc_bitpar_enabled() {
+  const char *e = std::getenv("PDT_OC_BITPAR");
+  return !(e && e[0] == '0');
 }
 
 static int fill_common(LevArgs &a, const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
@@ -157,7 +166,9 @@ int pdt_lev_classified(const int64_t *ref, int64_t R, int64_t ref_st, int64_t re
 int64_t pdt_oc_mask_words(int64_t R) { return R <= 0 ? 1 : (R + 31) / 32; }
 
 int64_t pdt_oc_mask_workspace_bytes(int64_t R, int64_t H, int64_t N) {
-  if (R <= 64 * 32 || H < 0 || N <= 0) return 0;  // (the register-resident kernel needs none)
+  if (H < 0 || N <= 0) return 0;
+  if (R <= 64 * 32)  // the bit-parallel kernel's tables (unit costs, up to 512 columns); the
+    return pdt::oc_bitpar_enabled() ? pdt::oc_bitpar_workspace_bytes(R, H, N) : 0;  // register-resident kernel needs none
   return pdt::generic_oc_ws_per_utt(R, H, nullptr) * N;
 }
 
@@ -186,6 +197,10 @@ int pdt_oc_mask(const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn, c
   const bool exact = !costs_exact_in_f32(ins_cost, del_cost, sub_cost, R, H);
   if (a.W > 64) {  // beyond the 2048 columns the row-synchronous kernel holds: the plain formulation
     return launch_oc_mask_generic(a, exact, workspace, workspace_bytes, (hipStream_t)stream);
+  }
+  if (ins_cost == 1.0f && del_cost == 1.0f && sub_cost == 1.0f && oc_bitpar_enabled()) {
+    rc = launch_oc_mask_bitpar(a, workspace, workspace_bytes, (hipStream_t)stream);
+    if (rc >= 0) return rc;  // (-1: shape not served)
   }
   return launch_lev_rowsync(a, exact, (hipStream_t)stream);
 }

@@ -468,7 +468,10 @@ def _oc_mask(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_co
         bitmask = torch.empty((Hout, N, W), device=device, dtype=torch.int32)
         class_tokens = torch.empty((N, max(R, 1)), device=device, dtype=torch.long)
         scal = torch.zeros(3, device=device, dtype=torch.int32)  # [max_count, status, aux status]
-        ws_bytes = int(L.pdt_oc_mask_workspace_bytes(R, H, N))  # (references beyond 2048 tokens only)
+        # the bit-parallel kernel's tables (uniform costs, R <= 512) or the plain formulation's rows
+        # (R > 2048); everything else runs out of registers
+        uniform = float(ins_cost) == float(del_cost) == float(sub_cost) and float(sub_cost) > 0.0
+        ws_bytes = int(L.pdt_oc_mask_workspace_bytes(R, H, N)) if (uniform or R > 2048) else 0
         ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8) if ws_bytes > 0 else None
         rc = L.pdt_oc_mask(
             _cabi.ptr(ref), R, rst, rsn, _cabi.ptr(hyp), H, hst, hsn, N,

@@ -403,6 +403,37 @@ def test_optimal_completion_shape_sweep(device):
             assert act.shape == exp.shape and np.array_equal(act.cpu().numpy(), exp), (N, R, H, V, kw)
 
 
+@pytest.mark.parametrize("R", [1, 2, 31, 32, 33, 63, 64, 65, 200, 480, 511, 512])
+def test_optimal_completion_bit_parallel_rows(device, R, monkeypatch):
+    """Uniform costs and references of up to 512 tokens take the bit-parallel mask kernel
+    (csrc/lev_bitpar.hip, oc_bitpar_kernel): one case per number of 32-column blocks in use, ragged
+    lengths on both sides (eos anywhere, including position 0), vocabularies from two tokens (every
+    row minimum tied many times) to more tokens than positions, batches that leave utterance slots
+    of the last wave empty.  Checked against the oracle on a slice and against the row-synchronous
+    kernel (PDT_OC_BITPAR=0) on everything."""
+    rng = np.random.default_rng(9000 + R)
+    for it, H in enumerate((1, max(1, R - 1), R + 37 if R < 300 else 90)):
+        N = int(rng.integers(1, 11))
+        V = int(rng.choice([2, 3, 7, 50, 2000]))
+        ref = rng.integers(0, V, (R, N))
+        hyp = rng.integers(0, V, (H, N))
+        if it == 1 and R > 2:  # long common runs: carries that ripple through many blocks
+            hyp[: min(R, H)] = ref[: min(R, H)]
+            hyp[rng.integers(0, H, 3), rng.integers(0, N, 3)] = V
+        for kw in (dict(), dict(eos=0), dict(eos=V - 1, include_eos=False, exclude_last=True),
+                   dict(batch_first=True, ins_cost=2.5, del_cost=2.5, sub_cost=2.5)):
+            a, b = (ref.T.copy(), hyp.T.copy()) if kw.get("batch_first") else (ref, hyp)
+            ta, tb = torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)
+            monkeypatch.setenv("PDT_OC_BITPAR", "1")
+            act = F.optimal_completion(ta, tb, warn=False, **kw)
+            monkeypatch.setenv("PDT_OC_BITPAR", "0")
+            row = F.optimal_completion(ta, tb, warn=False, **kw)
+            assert act.shape == row.shape and torch.equal(act, row), (R, H, N, V, kw)
+            if R * H * N <= 40000:
+                exp = oracle.optimal_completion(a, b, faithful=False, **kw)
+                assert np.array_equal(act.cpu().numpy(), exp), (R, H, N, V, kw)
+
+
 # ---- bit-parallel unit-cost kernels (csrc/lev_bitpar.hip) ------------------------------------
 _BITPAR_OPS = ["error_rate", "edit_distance", "prefix_error_rates", "prefix_edit_distances"]
 
