@@ -23,18 +23,17 @@
 //                        for every h: all prefix distances come out of one final prefix sum.
 // (With X = hyp the transposed table is computed; unit costs make it the same table.)
 //
-// Optimal completion stays on lev_rowsync.hip: a form of this pipeline that dumped every column's
-// (Pv, Mv) words and searched them for the arg-min rows (nibble-table block minima, bounds from
-// popcounts, one lane per column) measured 0.48 ms against 0.51 -- its cost is the arg-min sets
-// (13 rows per column at the bench shape, each a class look-up), not the recurrence.
+// Optimal completion (unit costs, references of up to 512 tokens) has its own kernel at the end of
+// this file, oc_bitpar_kernel, with the bit-vectors along the REFERENCE: a row's profile is then a
+// prefix sum of the vector's +1 / -1 bits and the arg-min columns come from table look-ups.  (A form
+// of the hypothesis-major pipeline above that dumped every column's (Pv, Mv) words and searched them
+// for the arg-min rows measured 0.48 ms against the row-synchronous kernel's 0.51; the
+// reference-major kernel runs the C2 shape in 0.24 ms.)
 #include <algorithm>
 #include <type_traits>
 
 #include "lev_classes.hpp"
 
-#ifndef PDT_OC_GROUP
-#define PDT_OC_GROUP 4  // columns per table look-up of the optimal-completion block minima
-#endif
 
 namespace pdt {
 
@@ -475,20 +474,35 @@ int launch_lev_bitpar(const LevArgs &la, const BitparPlan &p, void *ws, hipStrea
 // ref[c] over the columns c < ref_len where D[h][c] is the row minimum.)
 //
 // Bit-vectors run along the REFERENCE here: after h hypothesis tokens Pv / Mv hold
-// D[h][c] - D[h][c-1] for every column, so the row's profile relative to D[h][0] is a prefix sum of
-// +1 / -1 bits and the row minimum needs no DP value at all.  16 lanes (one DPP row) per utterance,
-// four utterances per wave, lane b owns columns 32 b + 1 .. 32 b + 32, every lane on the SAME row:
+// D[h][c] - D[h][c-1] for every column, so the row's profile relative to D[h][0] = h is a prefix sum
+// of +1 / -1 bits and the row minimum needs no DP value at all.  16 lanes (one DPP row) per
+// utterance, four utterances per wave, lane b owns columns 32 b + 1 .. 32 b + 32, every lane on the
+// SAME row:
 //   * the 512-bit addition of Myers' step is 16 word additions whose carries are resolved on the
-//     scalar unit -- generate / propagate lane masks, one 64-bit add (Gm << 1) + Pm, xor;
+//     scalar unit -- generate / propagate lane masks (v_add_co's carry mask, one v_cmp), one 64-bit
+//     add (Gm << 1) + Pm, xor, and a v_addc_co that takes the result as its carry-in mask;
 //   * the shifts take the neighbour's word through a row_shr:1 and one v_alignbit;
-//   * a block's (total, min prefix, arg-min bits) come from a table over G columns at a time
-//     (index = G plus-bits | G minus-bits), block starts from a 4-step row scan, the row minimum
-//     from a 4-step row all-reduce;
-//   * the arg-min bits are turned into class bits by LDS ORs (class of ref[c] per column, staged),
-//     and the row's W words leave with one exchange each.
+//   * a block's (total, min prefix, arg-min bits) come from a 256-entry table over 4 columns at a
+//     time (index = plus nibble | minus nibble << 4), block starts from a 4-step row scan, the row
+//     minimum from a 4-step row all-reduce;
+//   * the arg-min bits are permuted so that neighbouring columns sit in different lanes (oc_spread)
+//     and turned into class bits by LDS ORs; the row's W words leave with one exchange each.
 // Utterances whose hypothesis has ended write empty sets.
+//
+// What bounds it (profiles/r03_oc_*): the four utterances of a SIMD are one wave's worth of
+// lanes, and a lone wave issues an instruction every ~5.5 cycles.  One wave doing everything took
+// 0.375 ms (0.46 before the rows of a pass were processed phase by phase); splitting the rows'
+// independent part over consumer waves (below) 0.24 ms, at which point the SIMDs' vector issue is
+// ~80 % busy (profiles/tools/micro/valu_cost.hip: with several waves per SIMD most integer
+// instructions other than add / sub / and / or / xor / right shifts issue at half rate).
 #ifndef PDT_OC_CHUNK
-#define PDT_OC_CHUNK 8
+#define PDT_OC_CHUNK 4
+#endif
+#ifndef PDT_OC_SLOTS
+#define PDT_OC_SLOTS(nc) (2 * (nc))  // ring slots (passes in flight) per workgroup
+#endif
+#ifndef PDT_OC_CONSUMERS
+#define PDT_OC_CONSUMERS 3  // consumer waves per workgroup of oc_bitpar_kernel
 #endif
 constexpr int kOcChunk = PDT_OC_CHUNK;  // rows per pass of oc_bitpar_kernel
 
@@ -634,39 +648,59 @@ __device__ __forceinline__ unsigned oc_spread(const OcSpread &sp, unsigned x) {
   return x;
 }
 
-template <int G>
-__global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const int lds_per_sub) {
+// Workgroup = four utterances (one per DPP row of every wave) and 1 + NC waves.  The recurrence is
+// the only part of a row that depends on the row before and it is a tenth of the row's
+// instructions, so ONE wave (the producer) runs it and leaves each row's masked (Pv, Mv) words in an
+// LDS ring, a pass of kOcChunk rows per slot; NC consumer waves take passes in turn and do the rest
+// (block minima, row minimum, spreading, class bits, the store).  A lone wave issues an instruction
+// every ~5.5 cycles; with the waves of four such workgroups on a CU every SIMD has several to pick
+// from.  Roles rotate with the workgroup index so that producers do not all land on one SIMD.
+struct OcLds {
+  size_t flags, ring, bm, sub, total;  // byte offsets; sub = first utterance's tables
+  size_t per_sub;
+};
+static __host__ __device__ inline OcLds oc_lds(const int X, const int NC) {
+  OcLds l;
+  const size_t Xs = (size_t)(X > 0 ? X : 1);
+  const int S = PDT_OC_SLOTS(NC);
+  l.flags = 512;                                           // after the 256-entry table
+  l.ring = l.flags + 256;                                  // ready[S], done[S]
+  l.bm = l.ring + (size_t)S * kOcChunk * PDT_WAVE * 8;     // a slot: kOcChunk rows of (Pv, Mv) per lane
+  l.sub = l.bm + (size_t)NC * kOcChunk * PDT_WAVE * 4;     // per consumer: kOcChunk rows of 16 words per utterance
+  l.per_sub = ((Xs + 1) * 4 + 15) / 16 * 16 + 256 + 512 * 2;  // match words; 2 x 16 look-ups; classes in spread order
+  l.total = l.sub + 4 * l.per_sub;
+  return l;
+}
+
+template <int NC>
+__global__ void __launch_bounds__(64 * (NC + 1)) oc_bitpar_kernel(const OcBitArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int S = PDT_OC_SLOTS(NC), kChunk = kOcChunk, NG = 8;
   uint16_t *tab = reinterpret_cast<uint16_t *>(smem);
-  oc_build_table<G>(tab);
+  oc_build_table<4>(tab);
+  const OcLds L = oc_lds(a.X, NC);
+  int *ready = reinterpret_cast<int *>(smem + L.flags), *done = ready + S;
+  uint2 *ring = reinterpret_cast<uint2 *>(smem + L.ring);
   const int lane = lane_id();
-  const int wave = (int)(threadIdx.x >> 6), nwave = (int)(blockDim.x >> 6);
+  const int wave = (int)(threadIdx.x >> 6);
+  const int role = (wave + (int)blockIdx.x) % (NC + 1);  // 0: producer, 1 .. NC: consumers
   const int q = lane >> 4, b = lane & 15;
-  const int64_t n_raw = ((int64_t)blockIdx.x * nwave + wave) * 4 + q;
+  const int64_t n_raw = (int64_t)blockIdx.x * 4 + q;
   const bool valid = n_raw < a.N;
   const int64_t n = valid ? n_raw : (int64_t)a.N - 1;
   const int X = a.X > 0 ? a.X : 1, Y = a.Y > 0 ? a.Y : 1;
-  unsigned char *base = smem + ((size_t)2 << (2 * G)) + (size_t)(wave * 4 + q) * lds_per_sub;
-  uint2 *yh_l = reinterpret_cast<uint2 *>(base);
-  unsigned *msk_l = reinterpret_cast<unsigned *>(yh_l + Y);
-  unsigned *bm = msk_l + X + 1;
-  uint16_t *xc_l = reinterpret_cast<uint16_t *>(bm + 16 * kOcChunk);  // (bm: one 16-word row per row of a pass)
+  unsigned char *base = smem + L.sub + (size_t)q * L.per_sub;
+  unsigned *msk_l = reinterpret_cast<unsigned *>(base);
+  uint16_t *xc_l = reinterpret_cast<uint16_t *>(base + L.per_sub - 1024);
 
   const int ref_len = valid ? a.lens[2 * n] : 0, hyp_len = valid ? a.lens[2 * n + 1] : 0;
   int Heff = a.exclude_last ? hyp_len - 1 : hyp_len;
   if (Heff < 0) Heff = 0;
-
-  {  // this utterance's tables: 16 lanes, eight loads in flight each
-    const uint2 *src = a.yh + n * (int64_t)Y;
-    for (int j0 = b; j0 < Heff; j0 += 8 * 16) {
-      uint2 v[8];
-#pragma unroll
-      for (int r = 0; r < 8; ++r) v[r] = j0 + r * 16 < Heff ? src[j0 + r * 16] : make_uint2(0u, 0u);
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-        if (j0 + r * 16 < Heff) yh_l[j0 + r * 16] = make_uint2(v[r].x, v[r].y * 4u);  // (byte offset of the class's words)
-    }
-    if (Heff == 0 && b == 0) yh_l[0] = make_uint2(0u, 0u);
+  if (threadIdx.x < 2 * S) ready[threadIdx.x] = 0;
+  const OcSpread sp = oc_spread_setup(b);
+  const uint16_t *csrc = a.xcls + n * (int64_t)X;
+  const int rank0 = ref_len > 0 ? (int)csrc[0] : 0;  // class of ref[0]
+  if (role == 0) {  // the match words of this utterance: 16 lanes, eight loads in flight each
     const unsigned *msrc = a.msk + n * (int64_t)(X + 1);
     for (int i0 = b; i0 <= ref_len; i0 += 8 * 16) {
       unsigned v[8];
@@ -676,18 +710,15 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
       for (int r = 0; r < 8; ++r)
         if (i0 + r * 16 <= ref_len) msk_l[i0 + r * 16] = v[r];
     }
-    for (int r = 0; r < kOcChunk; ++r) bm[16 * r + b] = 0u;
-  }
-  const OcSpread sp = oc_spread_setup(b);
-  int rank0;  // class of ref[0]
-  {  // xc_l[32 b + t] = class of ref[c] for the column c that the network leaves in bit t of lane b
+  } else {
+    // xc_l[32 b + t] = class of ref[c] for the column c that the network leaves in bit t of lane b
+    unsigned *bm0 = reinterpret_cast<unsigned *>(smem + L.bm) + (size_t)(role - 1) * kChunk * PDT_WAVE;
+    for (int r = 0; r < kChunk; ++r) bm0[r * PDT_WAVE + lane] = 0u;
     unsigned plane[9];
     const unsigned low[5] = {0xaaaaaaaau, 0xccccccccu, 0xf0f0f0f0u, 0xff00ff00u, 0xffff0000u};
 #pragma unroll
     for (int k = 0; k < 9; ++k) plane[k] = oc_spread(sp, k < 5 ? low[k] : (((b >> (k - 5)) & 1) ? 0xffffffffu : 0u));
-    const uint16_t *csrc = a.xcls + n * (int64_t)X;
-    rank0 = ref_len > 0 ? (int)csrc[0] : 0;
-    for (int t0 = 0; t0 < 32; t0 += 8) {
+    for (int t0 = 8 * (role - 1); t0 < 32; t0 += 8 * NC) {
       uint16_t v[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
@@ -700,56 +731,64 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
       for (int r = 0; r < 8; ++r) xc_l[32 * b + t0 + r] = v[r];
     }
   }
-  __syncthreads();
+  __syncthreads();  // (the only one: from here on the waves meet through the ring's flags)
 
   const int W = a.W;
-  int max_cnt = 0;
-  if (valid && b < W) {  // h = 0: only column 0 (:271-278)
-    unsigned w = 0u;
-    if (ref_len > 0 && (rank0 >> 5) == b) w = 1u << (rank0 & 31);
-    a.bitmask[((int64_t)0 * a.N + n) * W + b] = w;
-  }
-  if (ref_len > 0) max_cnt = 1;
-
   // columns of this block that exist (<= ref_len) and those that have a next token (< ref_len)
   const int nvalid = min(max(ref_len - 32 * b, 0), 32), nnext = min(max(ref_len - 1 - 32 * b, 0), 32);
   const unsigned vmask = nvalid == 32 ? 0xffffffffu : (1u << nvalid) - 1u;
   const unsigned nmask = nnext == 32 ? 0xffffffffu : (1u << nnext) - 1u;
-  const unsigned lowmask = (1u << b) - 1u, bbit = 1u << b;
-  const int jcap = Heff > 0 ? Heff - 1 : 0;
   int hmax = Heff;
 #pragma unroll
   for (int t = 16; t < PDT_WAVE; t <<= 1) hmax = max(hmax, __shfl_xor(hmax, t));
   hmax = __builtin_amdgcn_readfirstlane(hmax);
-
-  uint32_t *out_row = a.bitmask + n * (int64_t)W + b;  // row 0 of this lane's word
+  const int nchunks = (hmax + kChunk - 1) / kChunk;
   const int64_t row_stride = (int64_t)a.N * W;
-  unsigned Pv = 0xffffffffu, Mv = 0u;  // row 0: D[0][c] = c
-  unsigned xp = b == 0 ? 0x80000000u : 0u, xm = 0u;  // (lane 0 of a row keeps D[h][0] - D[h-1][0] = +1)
-  u64 notop = 0x7fff7fff7fff7fffull;  // carries stay inside an utterance's 16 lanes
-  asm volatile("" : "+s"(notop));     // (in a register pair: the literal would split every AND in two)
-  // Four rows per pass, phase by phase, so that the LDS round trips of a phase (match words, table
-  // entries, classes, the rows' words) overlap across the four rows instead of adding up per row:
-  // only the 20-instruction recurrence depends on the row before.
-  constexpr int kChunk = kOcChunk;
-  constexpr int NG = 8;
-  for (int h0 = 0; h0 < hmax; h0 += kChunk) {
-    unsigned eq[kChunk];
-    {
+  uint32_t *out_row = a.bitmask + n * (int64_t)W + b;  // row 0 of this lane's word
+
+  if (role == 0) {
+    // ---- producer: Myers' step on the 512-bit column, four utterances side by side ------------
+    if (valid && b < W) {  // h = 0: only column 0 (:271-278)
+      unsigned w = 0u;
+      if (ref_len > 0 && (rank0 >> 5) == b) w = 1u << (rank0 & 31);
+      out_row[0] = w;
+    }
+    // rows nobody in the workgroup reaches (`& not_done`, :334)
+    for (int h = hmax + 1; h < a.Hout; ++h)
+      if (valid && b < W) out_row[h * row_stride] = 0u;
+    const unsigned lowmask = (1u << b) - 1u, bbit = 1u << b;
+    const int jcap = Heff > 0 ? Heff - 1 : 0;
+    const uint2 *ysrc = a.yh + n * (int64_t)Y;
+    unsigned Pv = 0xffffffffu, Mv = 0u;  // row 0: D[0][c] = c
+    unsigned xp = b == 0 ? 0x80000000u : 0u, xm = 0u;  // (lane 0 of a row keeps D[h][0] - D[h-1][0] = +1)
+    u64 notop = 0x7fff7fff7fff7fffull;  // carries stay inside an utterance's 16 lanes
+    asm volatile("" : "+s"(notop));     // (in a register pair: the literal would split every AND in two)
+    // (presence, offset) of the hypothesis tokens' classes: lane b fetches row 16 k + b a block of 16
+    // rows ahead (a load per pass would cost its whole latency every pass) and leaves it in LDS
+    static_assert(16 % kChunk == 0, "a block of look-ups is a whole number of passes");
+    uint2 *ybuf = reinterpret_cast<uint2 *>(base + L.per_sub - 1024 - 256);
+    uint2 pre = Heff > 0 ? ysrc[min(b, jcap)] : make_uint2(0u, 0u);
+    for (int i = 0; i < nchunks; ++i) {
+      if ((i * kChunk) % 16 == 0) {
+        const int blk = (i * kChunk) >> 4;
+        ybuf[(blk & 1) * 16 + b] = pre;
+        pre = Heff > 0 ? ysrc[min((blk + 1) * 16 + b, jcap)] : make_uint2(0u, 0u);
+      }
       uint2 hq[kChunk];
 #pragma unroll
-      for (int r = 0; r < kChunk; ++r) hq[r] = yh_l[min(h0 + r, jcap)];
+      for (int r = 0; r < kChunk; ++r) hq[r] = ybuf[(i * kChunk + r) & 31];
+      unsigned eq[kChunk];
 #pragma unroll
-      for (int r = 0; r < kChunk; ++r)
-        eq[r] = *reinterpret_cast<const unsigned *>(reinterpret_cast<const unsigned char *>(msk_l) + hq[r].y +
-                                                    4u * (unsigned)__popc(hq[r].x & lowmask));
+      for (int r = 0; r < kChunk; ++r) eq[r] = msk_l[hq[r].y + (unsigned)__popc(hq[r].x & lowmask)];
 #pragma unroll
       for (int r = 0; r < kChunk; ++r) eq[r] = (hq[r].x & bbit) ? eq[r] : 0u;
-    }
-    unsigned e[kChunk][NG];
+      const int slot = i % S;
+      if (i >= S)
+        while (__hip_atomic_load(&done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < i - S + 1)
+          __builtin_amdgcn_s_sleep(2);
+      uint2 *dst = ring + (size_t)slot * kChunk * PDT_WAVE + lane;
 #pragma unroll
-    for (int r = 0; r < kChunk; ++r) {
-      {  // Myers' step on the 512-bit column
+      for (int r = 0; r < kChunk; ++r) {
         const unsigned Eq = eq[r];
         const unsigned Xv = Eq | Mv;
         const unsigned A = Eq & Pv;
@@ -769,9 +808,28 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
         const unsigned Mh = __builtin_amdgcn_alignbit(Mhw, xm, 31);
         Pv = Mh | ~(Xv | Ph);
         Mv = Ph & Xv;
+        dst[r * PDT_WAVE] = make_uint2(Pv & vmask, Mv & vmask);
       }
-      oc_table_reads(tab, Pv & vmask, Mv & vmask, e[r]);
+      if (lane == 0) __hip_atomic_store(&ready[slot], i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
+    return;
+  }
+
+  // ---- consumers: passes role - 1, role - 1 + NC, ... ---------------------------------------------
+  unsigned *bm = reinterpret_cast<unsigned *>(smem + L.bm) + (size_t)(role - 1) * kChunk * PDT_WAVE + 16 * q;
+  int max_cnt = (role == 1 && ref_len > 0) ? 1 : 0;  // (row 0)
+  for (int i = role - 1; i < nchunks; i += NC) {
+    const int slot = i % S, h0 = i * kChunk;
+    while (__hip_atomic_load(&ready[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < i + 1)
+      __builtin_amdgcn_s_sleep(2);
+    const uint2 *src = ring + (size_t)slot * kChunk * PDT_WAVE + lane;
+    uint2 pm[kChunk];
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) pm[r] = src[r * PDT_WAVE];
+    unsigned e[kChunk][NG];
+#pragma unroll
+    for (int r = 0; r < kChunk; ++r) oc_table_reads(tab, pm[r].x, pm[r].y, e[r]);
+    if (lane == 0) __hip_atomic_store(&done[slot], i + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     unsigned rest[kChunk], or0[kChunk], or1[kChunk];
     int c0[kChunk], c1[kChunk];
     bool zero_min[kChunk];
@@ -804,7 +862,7 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
     }
 #pragma unroll
     for (int r = 0; r < kChunk; ++r) {  // (an OR of 0 where there is no bit: no branches)
-      unsigned *bmr = bm + 16 * r;
+      unsigned *bmr = bm + PDT_WAVE * r;
       atomicOr(&bmr[c0[r] >> 5], or0[r] << (c0[r] & 31));
       atomicOr(&bmr[c1[r] >> 5], or1[r] << (c1[r] & 31));
       if (b == 0) atomicOr(&bmr[rank0 >> 5], (zero_min[r] && ref_len > 0) ? 1u << (rank0 & 31) : 0u);
@@ -820,7 +878,7 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
           if (bits) {
             const int cls = xc_l[32 * b + __builtin_ctz(bits)];
             bits &= bits - 1u;
-            atomicOr(&bm[16 * r + (cls >> 5)], 1u << (cls & 31));
+            atomicOr(&bm[PDT_WAVE * r + (cls >> 5)], 1u << (cls & 31));
           }
         }
       }
@@ -830,7 +888,7 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
     unsigned w[kChunk];
 #pragma unroll
     for (int r = 0; r < kChunk; ++r)
-      w[r] = __hip_atomic_exchange(&bm[16 * r + b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+      w[r] = __hip_atomic_exchange(&bm[PDT_WAVE * r + b], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
     __builtin_amdgcn_wave_barrier();
     if (valid && b < W) {
 #pragma unroll
@@ -847,16 +905,7 @@ __global__ void __launch_bounds__(256) oc_bitpar_kernel(const OcBitArgs a, const
       max_cnt = max(max_cnt, cnt);
     }
   }
-  // rows nobody in the wave reaches (`& not_done`, :334)
-  for (int h = hmax + 1; h < a.Hout; ++h)
-    if (valid && b < W) a.bitmask[((int64_t)h * a.N + n) * W + b] = 0u;
   if (valid && b == 0 && a.max_count && max_cnt > 0) atomicMax(a.max_count, max_cnt);
-}
-
-// per-utterance LDS of oc_bitpar_kernel
-static size_t oc_bitpar_lds_sub(int X, int Y) {
-  const size_t Xs = (size_t)(X > 0 ? X : 1), Ys = (size_t)(Y > 0 ? Y : 1);
-  return align_up(Ys * 8 + (Xs + 1) * 4 + 64 * kOcChunk + 512 * 2, 16);  // (the class table is staged in spread order: 16 x 32 entries)
 }
 
 constexpr int64_t kOcBitparMaxR = 512;  // 16 lanes of 32 columns
@@ -904,18 +953,12 @@ int launch_oc_mask_bitpar(const LevArgs &la, void *ws, int64_t ws_bytes, hipStre
   o.exclude_last = la.exclude_last;
   o.lens = a.lens; o.yh = a.yh; o.msk = a.msk; o.xcls = a.xcls;
   o.bitmask = la.bitmask; o.max_count = la.max_count;
-  constexpr int G = PDT_OC_GROUP;
-  const size_t sub = oc_bitpar_lds_sub(o.X, o.Y);
-  const size_t tab_bytes = (size_t)2 << (2 * G);
-  int nwave = 4;  // waves per workgroup: the table is shared, the utterances' tables are not
-  while (nwave > 1 && (tab_bytes + sub * 4 * nwave > (size_t)150 * 1024 || (int64_t)nwave * 4 * 256 > la.N)) nwave >>= 1;
-  const size_t smem = tab_bytes + sub * 4 * nwave;
-  if (smem > (size_t)150 * 1024) return -1;
-  auto kern = oc_bitpar_kernel<G>;
-  rc = set_lds(reinterpret_cast<const void *>(kern), smem);
+  constexpr int NC = PDT_OC_CONSUMERS;
+  const OcLds L = oc_lds(o.X, NC);
+  auto kern = oc_bitpar_kernel<NC>;
+  rc = set_lds(reinterpret_cast<const void *>(kern), L.total);
   if (rc) return rc;
-  const int64_t per_wg = 4 * nwave;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((la.N + per_wg - 1) / per_wg)), dim3(64 * nwave), smem, stream, o, (int)sub);
+  hipLaunchKernelGGL(kern, dim3((unsigned)((la.N + 3) / 4)), dim3(64 * (NC + 1)), L.total, stream, o);
   return (int)hipGetLastError();
 }
 
