@@ -274,6 +274,33 @@ int pdt_ctc_lookup_lm_advance(
     int history_bytes, const int64_t *frame_lens, int64_t frame, int64_t yn_ss, int64_t yn_sn, int64_t yn_sk,
     void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * The whole CTCPrefixSearch with a LookupLanguageModel in the loop (_decoding.py:1083-1202 with
+ * :1110-1163 per frame): the frame kernel of pdt_ctc_lookup_lm_advance launched n_frames times
+ * from this call, the beam's state kept in `workspace` between the frames.
+ *   probs (T, N, V + 1) float32 through element strides: softmax of the logits, blank last; frames
+ *   0 .. n_frames - 1 are read (n_frames >= 1).  frame_lens (N,) int64 or NULL: a batch element keeps
+ *   its beam from frame frame_lens[n] on (:1165-1181).
+ *   Histories are not copied from frame to frame: every batch element has 2 * width history slots;
+ *   a prefix that survives a frame keeps its slot, an extended prefix gets a free slot, a copy of its
+ *   source's tokens and the new token (int16 tokens when V <= 32767, int64 otherwise).
+ *   Outputs, contiguous: y (n_frames, N, width) int64, zero beyond an entry's length and for absent
+ *   entries; y_lens (N, width) int64; nb, b (N, width) float32 -- the two masses of every entry (the
+ *   module returns nb + b).  Same bits as n_frames calls of pdt_ctc_lookup_lm_advance.
+ *   The model's factor of the mix depends on the context only; for a bigram model whose table of
+ *   U rows of V floats stays below 1 GiB the workspace keeps every row once it has been computed.
+ *   workspace: pdt_ctc_lookup_lm_search_workspace_bytes(n_frames, N, V, width, max_ngram, U) bytes.
+ * width <= 32; max_ngram <= 16.
+ * ------------------------------------------------------------------------------------- */
+int64_t pdt_ctc_lookup_lm_search_workspace_bytes(int64_t n_frames, int64_t N, int64_t V, int64_t width,
+                                                 int64_t max_ngram, int64_t U);
+int pdt_ctc_lookup_lm_search(
+    const float *probs, int64_t p_st, int64_t p_sn, int64_t p_sv, const int64_t *frame_lens, int64_t n_frames,
+    int64_t N, int64_t V, int64_t width, const float *logps, const float *logbs, const int32_t *child_start,
+    const int32_t *ids, const int32_t *succ_start, const int32_t *succ_tok, const int32_t *succ_node,
+    int64_t max_ngram, int64_t U, int64_t sos, float beta, int valid_mixture, int64_t *y, int64_t *y_lens,
+    float *nb, float *b, void *workspace, int64_t workspace_bytes, void *stream);
+
 int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, int64_t N,
                          int64_t Kp, int64_t V, int64_t width, const float *log_probs_prev,
                          int64_t lp_sn, int64_t lp_sk, const int64_t *y_prev, int64_t S,

@@ -98,6 +98,7 @@ struct DenseCtx {
   int etab_stride = 0;
   // the same history as 16-bit tokens (a caller that keeps its own, narrower copy between frames)
   const int16_t *y_prev16 = nullptr;
+  const int *slot = nullptr;  // history column of old entry k (null: k itself)
 };
 
 // ints per next-token table: W * W, but at least 128 so that the table not in use (nxt_new
@@ -717,8 +718,8 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       if (nw.len > len_b) continue;
       int tok_at;  // token of new prefix b at position len_s (the length of my source prefix)
       if (lenB > len_s)
-        tok_at = DENSE ? (dc.y_prev16 ? (int)dc.y_prev16[(int64_t)len_s * dc.yp_ss + src_b * dc.yp_sk]
-                                      : (int)dc.y_prev[(int64_t)len_s * dc.yp_ss + src_b * dc.yp_sk])
+        tok_at = DENSE ? (dc.y_prev16 ? (int)dc.y_prev16[(int64_t)len_s * dc.yp_ss + (dc.slot ? dc.slot[src_b] : src_b) * dc.yp_sk]
+                                      : (int)dc.y_prev[(int64_t)len_s * dc.yp_ss + (dc.slot ? dc.slot[src_b] : src_b) * dc.yp_sk])
                        : L.nxt_old[new_src * W + src_b];
       else
         tok_at = ext_b ? tok_b : -1;  // lenB == len_s

@@ -10,6 +10,12 @@
 // One workgroup per batch element; the waves take the prefixes in turn; wave 0 runs the frame; all
 // waves copy the histories.  Scores follow lm_lookup.hip operation for operation, the mix follows
 // fusion_ext.hip: the same bits as the three-kernel route.
+#ifndef PDT_LM_TWICE
+#define PDT_LM_TWICE 0  // timing experiments (same results): 1 the cached row read twice, 2 the list selection twice
+#endif
+#ifndef PDT_LMDBG
+#define PDT_LMDBG 0  // timing experiments (results change): skip 2 list selection, 4 the frame, 8 the history copy
+#endif
 #include <cstdlib>
 
 #include "advance_args.hpp"
@@ -17,6 +23,20 @@
 #include "row_reduce.hpp"
 
 namespace pdt {
+
+#ifdef PDT_LM_STAMPS
+// per-phase cycles summed over all waves (s_memtime, 100 MHz): 0 setup, 1 LM rows, 2 statistics + mix,
+// 3 list selection, 4 waiting at the barriers, 5 the frame (wave 0), 6 slots + histories, 7 launches
+__device__ unsigned long long pdt_lm_stamp_acc[8];
+#define LM_STAMP(i)                                                          \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_readcyclecounter();            \
+    if (lane == 0) atomicAdd(&pdt_lm_stamp_acc[i], now_ - stamp_t);          \
+    stamp_t = now_;                                                          \
+  } while (0)
+#else
+#define LM_STAMP(i)
+#endif
 
 struct LmTrie {
   const float *logps, *logbs;
@@ -38,6 +58,16 @@ struct CtcLmAdvArgs {
   const int64_t *frame_lens;
   int64_t frame;
   int64_t yn_ss, yn_sn, yn_sk;  // element strides of y_next (the step functions' own: N * W, W, 1)
+  // Slot mode (pdt_ctc_lookup_lm_search): histories live in 2 W slots per utterance, s.y_prev is the
+  // slot array (token-contiguous: yp_ss = 1, yp_sk = slot length, yp_sn = 2 W slots) and beam entry k
+  // owns slot slot_prev[n * W + k].  A surviving prefix keeps its slot; an extended one gets a slot that
+  // was free before the frame, a copy of its source's tokens and the new token -- nothing else moves.
+  const int32_t *slot_prev;
+  int32_t *slot_next;
+  // factor rows of a bigram model by context token, [U][row_floats], and their state (2: ready); or null
+  float *cache;
+  int32_t *cache_flag;
+  int cache_stride;  // floats per row: V rounded up to a 128-byte line
 };
 
 __device__ __forceinline__ int lm_find_child(const LmTrie &a, int node, int tok) {
@@ -116,7 +146,7 @@ __device__ __forceinline__ void lm_score_row(const LmTrie &a, const int (&ct)[kL
 // them, or int16_t: the host's frame loop keeps its own narrow copy between frames (the copy of the
 // (t, N, K) history is what a frame costs beyond ~30 us: a quarter of the bytes)
 template <typename HT>
-__global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs A) {
+__global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvArgs A) {
   extern __shared__ __align__(16) unsigned char smem[];
   const CtcAdvArgs &a = A.s;
   const int lane = lane_id();
@@ -136,6 +166,26 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
 
   const HT *y_prev = reinterpret_cast<const HT *>(a.y_prev);
   HT *y_next = reinterpret_cast<HT *>(a.y_next);
+  const bool slots = A.slot_prev != nullptr;
+#ifdef PDT_LM_STAMPS
+  unsigned long long stamp_t = __builtin_readcyclecounter();
+  if (threadIdx.x == 0) atomicAdd(&pdt_lm_stamp_acc[7], 1ull);
+#endif
+  if (slots && A.frame_lens && A.frame_lens[n] <= A.frame) {
+    // no such frame, slot mode: the beam as it was at the full width; the histories stay where they are
+    for (int i = (int)threadIdx.x; i < W; i += NW * PDT_WAVE) {
+      const bool has = i < Kp;
+      a.nb_next[n * W + i] = has ? a.nb_prev[n * a.pb_sn + i * a.pb_sk] : -PDT_INF;
+      a.b_next[n * W + i] = has ? a.b_prev[n * a.pbb_sn + i * a.pbb_sk] : -PDT_INF;
+      a.y_next_lens[n * W + i] = has ? a.lens[n * a.le_sn + i * a.le_sk] : a.lens[n * a.le_sn];
+      a.y_next_last[n * W + i] = has ? a.last[n * a.la_sn + i * a.la_sk] : 0;
+      a.next_src[n * W + i] = has ? i : 0;
+      a.next_nonext[n * W + i] = 1;
+      A.slot_next[n * W + i] = has ? A.slot_prev[n * W + i] : -1;
+      for (int bq = 0; bq < W; ++bq) a.next_isp[(n * W + i) * W + bq] = (uint8_t)(bq == i);
+    }
+    return;
+  }
   if (A.frame_lens && A.frame_lens[n] <= A.frame) {
     // no such frame: the beam as it was, brought to the full width (absent entries: -inf, length 0),
     // one more row of zeros (what the host's where() over y / lens / nb / b amounts to; the last
@@ -169,13 +219,17 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
   // others copy (a beam of 16 usually ends in 4-8 different contexts).
   int *ctab = reinterpret_cast<int *>(row_base + (size_t)NW * A.row_floats);  // [Kp x (N - 1)] context nodes
   int *leader = ctab + Kp * (kLmMaxOrder - 1);                                 // [Kp]
+  int *slot_l = leader + Kp;                                                   // [W] slots of the old beam; then of the new
+  int *dst_l = slot_l + W;                                                     // [W] slots of the new beam
   const int NC = A.lm.N - 1;
   if ((int)threadIdx.x < Kp) {
     const int k = (int)threadIdx.x;
+    const int sl = slots ? A.slot_prev[n * W + k] : k;
+    if (slots) slot_l[k] = sl;
     const int64_t pos = a.lens[n * a.le_sn + k * a.le_sk];
     for (int j = 1; j <= NC; ++j) {  // (_lm.py:452-472: sos before the start of the prefix)
       const int64_t q = pos - j;
-      int64_t tok = q >= 0 ? (int64_t)y_prev[q * a.yp_ss + n * a.yp_sn + k * a.yp_sk] : A.lm.sos;
+      int64_t tok = (q >= 0 && sl >= 0) ? (int64_t)y_prev[q * a.yp_ss + n * a.yp_sn + sl * a.yp_sk] : A.lm.sos;
       if (A.lm.shift && tok == A.lm.sos) tok = V;
       ctab[k * NC + (j - 1)] = (tok >= 0 && tok < A.lm.U - 1) ? (int)tok : -1;
     }
@@ -192,44 +246,100 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
     leader[k] = lead;
   }
   __syncthreads();
+  // state of every leader's cached row, one load for all of them (lane = beam entry)
+  int row_state = 0;
+  if (A.cache && lane < Kp && leader[lane] == lane && ctab[lane * NC] >= 0)
+    row_state = __hip_atomic_load(&A.cache_flag[ctab[lane * NC]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int rank = 0;  // leaders before k
   for (int k = 0; k < Kp; ++k) {
     if (leader[k] != k) continue;
     const bool mine = rank % NW == wave;
     ++rank;
     if (!mine) continue;
+    LM_STAMP(0);
     int ct[kLmMaxOrder];
     for (int j = 1; j <= NC; ++j) ct[j] = ctab[k * NC + (j - 1)];
-    lm_score_row(A.lm, ct, row);
+    // The model's factor of the mix depends on the context alone: exp(x - max) / sum for the valid
+    // mixture, exp(beta (log_softmax x)) for shallow fusion.  A whole search (slot mode, bigram model)
+    // keeps one row of factors per context token in its workspace: computed by whoever needs it
+    // first (several workgroups at once write the same bits), read by everybody afterwards.
+    float *crow = nullptr;
+    bool hit = false;
+    if (A.cache && ct[1] >= 0) {
+      // (rows start on 128-byte lines and a compute unit touches a row only after it has seen the
+      // row's flag: nothing stale can sit in its L1, so the flag is read relaxed -- an acquire here
+      // is an L1 invalidation, ~1.7 us per look-up)
+      crow = A.cache + (size_t)ct[1] * A.cache_stride;
+      hit = __builtin_amdgcn_readlane(row_state, k) == 2;
+    }
+    if (hit) {
+#if (PDT_LM_TWICE & 1)
+      for (int rep = 0; rep < 2; ++rep)
+#endif
+      for (int v0 = lane; v0 < V; v0 += 8 * PDT_WAVE) {  // (eight loads in flight)
+        float f[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) f[q] = v0 + q * PDT_WAVE < V ? crow[v0 + q * PDT_WAVE] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (v0 + q * PDT_WAVE < V) row[v0 + q * PDT_WAVE] = f[q];
+      }
+      LM_STAMP(1);
+    } else {
+      lm_score_row(A.lm, ct, row);
+      LM_STAMP(1);
+      float r[16];
+      const RowStats st = row_stats<false, true, 16>(row, 1, V, r);
+      const float log_sum = logf(st.sum);
+      for (int v = lane; v < V; v += PDT_WAVE) {
+        const float xv = row[v];
+        const float f = A.valid_mixture ? expf(xv - st.mx) / st.sum : expf(A.beta * ((xv - st.mx) - log_sum));
+        row[v] = f;
+        if (crow) crow[v] = f;
+      }
+      if (crow) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&A.cache_flag[ct[1]], 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    wave_sync();
     // the mix with the frame's probabilities (fusion_ext.hip)
-    float r[16];
-    const RowStats st = row_stats<false, true, 16>(row, 1, V, r);
-    const float log_sum = logf(st.sum);
     for (int v = lane; v < V; v += PDT_WAVE) {
-      const float xv = row[v];
+      const float f = row[v];
       float o;
       if (A.valid_mixture) {
-        const float lm_p = (expf(xv - st.mx) / st.sum) * scale;
+        const float lm_p = f * scale;
         o = keep * p[v] + A.beta * lm_p;
       } else {
-        o = p[v] * expf(A.beta * ((xv - st.mx) - log_sum));
+        o = p[v] * f;
       }
       row[v] = o;
     }
     wave_sync();
+    LM_STAMP(2);
     // what the frame reads of this row besides its list: the entries at the prefixes' last tokens
     if (lane < Kp) {
       const int lj = (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)0), (int64_t)(V - 1));
       etab[k * Kp + lane] = row[lj];
     }
+#if (PDT_LMDBG & 2)
+    const u64 tk = (u64)lane;
+#else
+#if (PDT_LM_TWICE & 2)
+    { const u64 tk0 = wave_top_sorted<false, false>(row, V, M, my_surv); asm volatile("" :: "v"(tk0)); wave_sync(); }
+#endif
     const u64 tk = wave_top_sorted<false, false>(row, V, M, my_surv);
+#endif
     if (lane < M) {
       L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
       L.tl_p[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));
     }
     wave_sync();
+    LM_STAMP(3);
   }
+  LM_STAMP(0);
   __syncthreads();
+  LM_STAMP(4);
   for (int k = wave; k < Kp; k += NW) {  // the others: their leader's list and table row
     const int lead = leader[k];
     if (lead == k) continue;
@@ -252,7 +362,9 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
   dc.yp_ss = a.yp_ss;
   dc.yp_sk = a.yp_sk;
   dc.S = S;
+  dc.slot = slots ? slot_l : nullptr;
   dc.lists_ready = 1;
+  LM_STAMP(0);
   if (wave == 0) {
     Beam bm;
     bm.nb = lane < Kp ? a.nb_prev[n * a.pb_sn + lane * a.pb_sk] : -PDT_INF;
@@ -271,7 +383,11 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
 #ifdef PDT_STAMPS
     unsigned pdt_stamp_acc[14] = {0};
 #endif
+#if (PDT_LMDBG & 4)
+    new_src = lane & 15; new_tok = 1; new_kind = 2;
+#else
     ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
+#endif
 
     // ---- outputs (:855-934) --------------------------------------------------------------
     if (lane < W) {
@@ -288,12 +404,62 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
       L.info[W + lane] = new_kind;
       newtok[lane] = new_tok;
     }
+    LM_STAMP(5);
   }
   __syncthreads();
+  LM_STAMP(4);
   // histories of the source prefixes, the new token behind them.  Token-contiguous histories (the
   // host's frame loop keeps them as (N, K, S) int16: yp_ss = yn_ss = 1) move 16 bytes at a time --
   // a column of the new beam is a plain copy of its source's column; the (S, N, K) layout of the
   // step functions is a permutation inside every row and goes token by token.
+#if (PDT_LMDBG & 8)
+  return;
+#endif
+  if (slots) {
+    // the new beam's slots: survivors keep theirs, extensions take the slots that were free before the
+    // frame in rank order (2 W slots, at most W of them in use: there are always enough)
+    if (wave == 0) {
+      const bool valid = lane < W && srcs[lane] >= 0;
+      const int kind = lane < W ? L.info[W + lane] : -1;
+      const bool ext = valid && (kind == 0 || kind == 1);
+      u64 used = 0ull;
+      for (int k = 0; k < Kp; ++k)
+        if (slot_l[k] >= 0) used |= 1ull << slot_l[k];
+      u64 free_slots = ~used & (2 * W >= 64 ? ~0ull : (1ull << (2 * W)) - 1ull);
+      const u64 extm = __ballot(ext);
+      const int rank = __popcll(extm & ((1ull << lane) - 1ull));
+      int ns = -1;
+      if (ext) {
+        for (int j = 0; j < rank; ++j) free_slots &= free_slots - 1ull;
+        ns = __builtin_ctzll(free_slots);
+      } else if (valid) {
+        ns = slot_l[srcs[lane]];
+      }
+      if (lane < W) {
+        dst_l[lane] = ns;
+        A.slot_next[n * W + lane] = ns;
+      }
+    }
+    __syncthreads();
+    const HT *hp = y_prev + n * a.yp_sn;
+    HT *hn = const_cast<HT *>(hp);
+    const int threads = NW * PDT_WAVE;
+    constexpr int PER = 16 / (int)sizeof(HT);  // tokens per 16 bytes
+    const int chunks = (S + 1 + PER - 1) / PER;
+    for (int idx = (int)threadIdx.x; idx < W * chunks; idx += threads) {
+      const int i = idx / chunks, c = idx - i * chunks;
+      const int src = srcs[i], kind_i = L.info[W + i], len_i = L.info[i];
+      if (src < 0 || !(kind_i == 0 || kind_i == 1) || c * PER >= len_i) continue;
+      union { uint4 q; HT t[PER]; } v;
+      v.q = *reinterpret_cast<const uint4 *>(hp + (int64_t)slot_l[src] * a.yp_sk + c * PER);
+#pragma unroll
+      for (int e = 0; e < PER; ++e)
+        if (c * PER + e == len_i - 1) v.t[e] = (HT)newtok[i];
+      *reinterpret_cast<uint4 *>(hn + (int64_t)dst_l[i] * a.yp_sk + c * PER) = v.q;
+    }
+    LM_STAMP(6);
+    return;
+  }
   const HT *yp_n = y_prev + n * a.yp_sn;
   HT *yn_n = y_next + n * A.yn_sn;
   const int threads = NW * PDT_WAVE;
@@ -331,6 +497,128 @@ __global__ void __launch_bounds__(512) ctc_lm_advance_kernel(const CtcLmAdvArgs 
       yn_n[(int64_t)s * A.yn_ss + i * A.yn_sk] = v;
     }
   }
+}
+
+}  // namespace pdt
+
+namespace pdt {
+
+// LDS plan of the frame kernel for (V, W, Kp); fills A.row_floats and the step's frame_bytes /
+// waves_per_wg.  Returns the dynamic LDS bytes, 0 when the shape does not fit.
+static size_t plan_lm_frame(CtcLmAdvArgs &A) {
+  CtcAdvArgs &a = A.s;
+  const int64_t V = a.V, Kp = a.Kp, width = a.W;
+  A.row_floats = (int)((V + 3) & ~(int64_t)3);
+  // waves per element: as many (a power of two <= min(Kp, 8)) as still let four workgroups share a
+  // CU's LDS -- every wave carries a row of V floats
+  size_t frame = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
+  frame = (frame + 15) & ~(size_t)15;
+  auto lds_of = [&](int nw) {
+    return frame + (size_t)nw * PDT_SURV_CAP * 8 + (size_t)((Kp * Kp + 3) & ~3) * 4 + (size_t)nw * A.row_floats * 4 +
+           (size_t)Kp * kLmMaxOrder * 4 + (size_t)width * 8;  // + the context table, the leaders, two slot lists
+  };
+  int nw = 1;
+  while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;
+  while (nw > 1 && lds_of(nw) > 40 * 1024) nw >>= 1;
+  if (const char *e = getenv("PDT_LM_STEP_WAVES")) {  // (experiments)
+    const int f = atoi(e);
+    if (f == 1 || f == 2 || f == 4 || f == 8) nw = f;
+  }
+  const size_t smem = lds_of(nw);
+  if (smem > 160 * 1024) return 0;
+  a.waves_per_wg = nw;
+  a.frame_bytes = (int)frame;
+  return smem;
+}
+
+static int launch_lm_frame(CtcLmAdvArgs &A, const int history_bytes, hipStream_t stream) {
+  const size_t smem = plan_lm_frame(A);
+  if (smem == 0) return PDT_E_TOO_LONG;
+  auto kern = history_bytes == 2 ? ctc_lm_advance_kernel<int16_t> : ctc_lm_advance_kernel<int64_t>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)A.s.N), dim3(64 * A.s.waves_per_wg), smem, stream, A);
+  return (int)hipGetLastError();
+}
+
+// ---- the whole search (pdt_ctc_lookup_lm_search) ------------------------------------------------
+// state of one side of the ping-pong: everything a frame reads / writes besides the histories
+struct LmSearchState {
+  float *nb, *b;
+  int64_t *last, *lens;
+  uint8_t *isp;
+  int32_t *slot;
+};
+
+__global__ void lm_search_init_kernel(LmSearchState st, const int N, const int W) {
+  const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (n >= N) return;
+  // one empty prefix per utterance, all of its mass on "ends in blank" (_decoding.py:1083-1097)
+  st.nb[(int64_t)n * W] = 0.0f;
+  st.b[(int64_t)n * W] = 1.0f;
+  st.last[(int64_t)n * W] = 0;
+  st.lens[(int64_t)n * W] = 0;
+  st.isp[(int64_t)n * W * W] = 1;
+  st.slot[(int64_t)n * W] = 0;
+}
+
+// y[s][n][i] = token s of beam entry i (0 beyond its length / for absent entries), lens and masses out
+template <typename HT>
+__global__ void __launch_bounds__(256)
+lm_search_gather_kernel(const HT *hist, const int64_t h_sn, const int64_t h_sk, const LmSearchState st, const int N,
+                        const int W, const int S_out, int64_t *y, int64_t *y_lens, float *nb, float *b) {
+  const int64_t n = blockIdx.x;
+  for (int i = (int)threadIdx.x; i < W; i += (int)blockDim.x) {
+    y_lens[n * W + i] = st.lens[n * W + i];
+    nb[n * W + i] = st.nb[n * W + i];
+    b[n * W + i] = st.b[n * W + i];
+  }
+  for (int idx = (int)threadIdx.x; idx < S_out * W; idx += (int)blockDim.x) {
+    const int s = idx / W, i = idx - s * W;
+    const int slot = st.slot[n * W + i];
+    const int64_t len = st.lens[n * W + i];
+    y[((int64_t)s * N + n) * W + i] = (slot >= 0 && s < len) ? (int64_t)hist[n * h_sn + (int64_t)slot * h_sk + s] : 0;
+  }
+}
+
+static size_t lm_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct LmSearchPlan {
+  size_t hist, side[2][6], nonext_flags, src, cache, cache_flag, total;
+  int64_t smax;
+  int cached;  // factor rows by context token kept (bigram model, table within kLmCacheBytes)
+};
+constexpr size_t kLmCacheBytes = (size_t)1 << 30;
+static LmSearchPlan plan_lm_search(int64_t n_frames, int64_t N, int64_t W, int history_bytes, int64_t V, int64_t U,
+                                   int64_t max_ngram) {
+  LmSearchPlan p{};
+  p.smax = (n_frames + 1 + 7) / 8 * 8;
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off = lm_align(off + bytes); return o; };
+  p.hist = take((size_t)N * 2 * W * p.smax * history_bytes);
+  for (int sd = 0; sd < 2; ++sd) {
+    p.side[sd][0] = take((size_t)N * W * 4);      // nb
+    p.side[sd][1] = take((size_t)N * W * 4);      // b
+    p.side[sd][2] = take((size_t)N * W * 8);      // last
+    p.side[sd][3] = take((size_t)N * W * 8);      // lens
+    p.side[sd][4] = take((size_t)N * W * W);      // is-prefix
+    p.side[sd][5] = take((size_t)N * W * 4);      // slots
+  }
+  p.nonext_flags = take((size_t)N * W);
+  p.src = take((size_t)N * W * 8);
+  const size_t rf = (size_t)((V + 31) & ~(int64_t)31);
+  p.cached = max_ngram == 2 && (size_t)U * rf * 4 <= kLmCacheBytes;
+  if (const char *e = getenv("PDT_LM_CACHE"))  // (comparisons)
+    if (e[0] == '0') p.cached = 0;
+  if (p.cached) {
+    p.cache = take((size_t)U * rf * 4);
+    p.cache_flag = take((size_t)U * 4);
+  }
+  p.total = off;
+  return p;
 }
 
 }  // namespace pdt
@@ -379,32 +667,106 @@ extern "C" int pdt_ctc_lookup_lm_advance(
   A.frame_lens = frame_lens;
   A.frame = frame_index;
   A.yn_ss = yn_ss; A.yn_sn = yn_sn; A.yn_sk = yn_sk;
-  A.row_floats = (int)((V + 3) & ~(int64_t)3);
-  // waves per element: as many (a power of two <= min(Kp, 8)) as still let four workgroups share a
-  // CU's LDS -- every wave carries a row of V floats
-  size_t frame = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
-  frame = (frame + 15) & ~(size_t)15;
-  auto lds_of = [&](int nw) {
-    return frame + (size_t)nw * PDT_SURV_CAP * 8 + (size_t)((Kp * Kp + 3) & ~3) * 4 + (size_t)nw * A.row_floats * 4 +
-           (size_t)Kp * kLmMaxOrder * 4;  // + the context table and the leaders
-  };
-  int nw = 1;
-  while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;
-  while (nw > 1 && lds_of(nw) > 40 * 1024) nw >>= 1;
-  if (const char *e = getenv("PDT_LM_STEP_WAVES")) {  // (experiments)
-    const int f = atoi(e);
-    if (f == 1 || f == 2 || f == 4 || f == 8) nw = f;
+  return launch_lm_frame(A, history_bytes, (hipStream_t)stream);
+}
+
+#ifdef PDT_LM_STAMPS
+extern "C" int pdt_debug_lm_stamps(unsigned long long *out, int reset) {
+  (void)hipDeviceSynchronize();
+  if (out) (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pdt::pdt_lm_stamp_acc), 64);
+  if (reset) {
+    unsigned long long z[8] = {0};
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(pdt::pdt_lm_stamp_acc), z, 64);
   }
-  const size_t smem = lds_of(nw);
-  if (smem > 160 * 1024) return PDT_E_TOO_LONG;
-  a.waves_per_wg = nw;
-  a.frame_bytes = (int)frame;
-  auto kern = history_bytes == 2 ? ctc_lm_advance_kernel<int16_t> : ctc_lm_advance_kernel<int64_t>;
-  if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  return 0;
+}
+#endif
+
+extern "C" int64_t pdt_ctc_lookup_lm_search_workspace_bytes(int64_t n_frames, int64_t N, int64_t V, int64_t width,
+                                                            int64_t max_ngram, int64_t U) {
+  if (n_frames < 0 || N < 0 || V < 1 || width < 1 || U < V + 1) return 0;
+  return (int64_t)pdt::plan_lm_search(n_frames, N, width, V <= 32767 ? 2 : 8, V, U, max_ngram).total;
+}
+
+extern "C" int pdt_ctc_lookup_lm_search(
+    const float *probs, int64_t p_st, int64_t p_sn, int64_t p_sv, const int64_t *frame_lens, int64_t n_frames,
+    int64_t N, int64_t V, int64_t width, const float *logps, const float *logbs, const int32_t *child_start,
+    const int32_t *ids, const int32_t *succ_start, const int32_t *succ_tok, const int32_t *succ_node,
+    int64_t max_ngram, int64_t U, int64_t sos, float beta, int valid_mixture, int64_t *y, int64_t *y_lens,
+    float *nb, float *b, void *workspace, int64_t workspace_bytes, void *stream) {
+  using namespace pdt;
+  if (N < 0 || V < 1 || width < 1 || n_frames < 1 || max_ngram < 2 || U < V + 1 || U > V + 2) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!probs || !y || !y_lens || !nb || !b || !logps || !logbs || !child_start || !ids || !succ_start || !succ_tok ||
+      !succ_node || !workspace)
+    return PDT_E_ARG;
+  if (V >= (1 << 30) || n_frames >= (1 << 26) || N >= (1ll << 31)) return PDT_E_TOO_LONG;
+  if (width > kMaxWidth || max_ngram > kLmMaxOrder) return PDT_E_TOO_LONG;
+  const int hb = V <= 32767 ? 2 : 8;
+  const LmSearchPlan p = plan_lm_search(n_frames, N, width, hb, V, U, max_ngram);
+  if ((int64_t)p.total > workspace_bytes) return PDT_E_ARG;
+  unsigned char *w = reinterpret_cast<unsigned char *>(workspace);
+  LmSearchState st[2];
+  for (int sd = 0; sd < 2; ++sd) {
+    st[sd].nb = reinterpret_cast<float *>(w + p.side[sd][0]);
+    st[sd].b = reinterpret_cast<float *>(w + p.side[sd][1]);
+    st[sd].last = reinterpret_cast<int64_t *>(w + p.side[sd][2]);
+    st[sd].lens = reinterpret_cast<int64_t *>(w + p.side[sd][3]);
+    st[sd].isp = reinterpret_cast<uint8_t *>(w + p.side[sd][4]);
+    st[sd].slot = reinterpret_cast<int32_t *>(w + p.side[sd][5]);
+  }
+  hipStream_t hs = (hipStream_t)stream;
+  hipLaunchKernelGGL(lm_search_init_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, hs, st[0], (int)N,
+                     (int)width);
+  CtcLmAdvArgs A{};
+  CtcAdvArgs &a = A.s;
+  a.N = (int)N; a.V = (int)V; a.W = (int)width;
+  A.lm = LmTrie{logps, logbs, child_start, ids, succ_start, succ_tok, succ_node, (int)V, (int)max_ngram, (int)U,
+                (int)(U - V - 1), sos};
+  A.beta = beta;
+  A.valid_mixture = valid_mixture;
+  A.frame_lens = frame_lens;
+  if (p.cached) {
+    A.cache = reinterpret_cast<float *>(w + p.cache);
+    A.cache_flag = reinterpret_cast<int32_t *>(w + p.cache_flag);
+    A.cache_stride = (int)((V + 31) & ~(int64_t)31);
+    hipError_t e = hipMemsetAsync(A.cache_flag, 0, (size_t)U * 4, hs);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(kern, dim3((unsigned)a.N), dim3(64 * nw), smem, (hipStream_t)stream, A);
+  // histories: 2 W slots of smax tokens per utterance, token-contiguous
+  a.y_prev = reinterpret_cast<const int64_t *>(w + p.hist);
+  a.y_next = reinterpret_cast<int64_t *>(w + p.hist);
+  a.yp_ss = 1; a.yp_sk = p.smax; a.yp_sn = 2 * width * p.smax;
+  A.yn_ss = 1; A.yn_sk = p.smax; A.yn_sn = 2 * width * p.smax;
+  a.next_src = reinterpret_cast<int64_t *>(w + p.src);
+  a.next_nonext = w + p.nonext_flags;
+  for (int64_t t = 0; t < n_frames; ++t) {
+    const LmSearchState &prev = st[t & 1], &next = st[(t + 1) & 1];
+    const int64_t Kp = t == 0 ? 1 : width;
+    a.Kp = (int)Kp;
+    a.S = (int)t;
+    a.nonext = probs + t * p_st; a.ne_sn = p_sn; a.ne_sv = p_sv;
+    a.blank = probs + t * p_st + V * p_sv; a.bl_sn = p_sn;
+    a.nb_prev = prev.nb; a.pb_sn = width; a.pb_sk = 1;
+    a.b_prev = prev.b; a.pbb_sn = width; a.pbb_sk = 1;
+    a.last = prev.last; a.la_sn = width; a.la_sk = 1;
+    a.lens = prev.lens; a.le_sn = width; a.le_sk = 1;
+    a.isp = prev.isp; a.ip_sn = width * width; a.ip_sa = width; a.ip_sb = 1;
+    a.y_next_last = next.last; a.y_next_lens = next.lens;
+    a.nb_next = next.nb; a.b_next = next.b; a.next_isp = next.isp;
+    A.slot_prev = prev.slot; A.slot_next = next.slot;
+    A.frame = t;
+    const int rc = launch_lm_frame(A, hb, hs);
+    if (rc != PDT_OK) return rc;
+  }
+  const LmSearchState &fin = st[n_frames & 1];
+  if (hb == 2)
+    hipLaunchKernelGGL(lm_search_gather_kernel<int16_t>, dim3((unsigned)N), dim3(256), 0, hs,
+                       reinterpret_cast<const int16_t *>(w + p.hist), 2 * width * p.smax, p.smax, fin, (int)N,
+                       (int)width, (int)n_frames, y, y_lens, nb, b);
+  else
+    hipLaunchKernelGGL(lm_search_gather_kernel<int64_t>, dim3((unsigned)N), dim3(256), 0, hs,
+                       reinterpret_cast<const int64_t *>(w + p.hist), 2 * width * p.smax, p.smax, fin, (int)N,
+                       (int)width, (int)n_frames, y, y_lens, nb, b);
   return (int)hipGetLastError();
 }

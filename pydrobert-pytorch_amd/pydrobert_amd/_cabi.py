@@ -71,6 +71,12 @@ SIGNATURES = {
         + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64]
         + [_F, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _INT, _P, _I64, _I64, _I64, _I64, _P],
     ),
+    "pdt_ctc_lookup_lm_search_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64, _I64, _I64]),
+    "pdt_ctc_lookup_lm_search": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _INT]
+        + [_P, _P, _P, _P, _P, _I64, _P],
+    ),
     "pdt_beam_search_step": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]

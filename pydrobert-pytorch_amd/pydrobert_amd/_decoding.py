@@ -602,6 +602,44 @@ class CTCPrefixSearch(torch.nn.Module):
                 _cabi.check(rc, "pdt_ctc_lookup_lm_advance")
         return o_last, o_lens, o_nb, o_b, o_isp
 
+    @torch.jit.unused
+    def _searches_in_one_call(self) -> bool:
+        """PDT_CTC_LM_SEARCH=0 keeps the host's frame loop around the one-kernel frames (comparisons)."""
+        return os.environ.get("PDT_CTC_LM_SEARCH", "1") != "0"
+
+    @torch.jit.unused
+    def _lookup_lm_search(
+        self, probs: torch.Tensor, lens: Optional[torch.Tensor], n_frames: int
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Every frame of the search with the n-gram model in the loop from ONE call of the library
+        (include/pdt_amd.h: pdt_ctc_lookup_lm_search): the frame kernel of :meth:`_lookup_lm_frame`
+        launched ``n_frames`` times from C, the beam's state and histories in a workspace in between."""
+        lm, W = self.lm, self.width
+        T, N, V = probs.size(0), probs.size(1), probs.size(2) - 1
+        device = probs.device
+        probs = _f32(probs)
+        shift = 0 if (0 <= lm.sos < V) else 1
+        L = _cabi.lib()
+        with torch.cuda.device(device):
+            y = torch.empty((n_frames, N, W), device=device, dtype=torch.long)
+            y_lens = torch.empty((N, W), device=device, dtype=torch.long)
+            nb = torch.empty((N, W), device=device, dtype=torch.float)
+            b = torch.empty((N, W), device=device, dtype=torch.float)
+            if N:
+                ws_bytes = int(L.pdt_ctc_lookup_lm_search_workspace_bytes(n_frames, N, V, W, lm.max_ngram, V + shift + 1))
+                ws = torch.empty(ws_bytes, device=device, dtype=torch.uint8)
+                lens_dev = None if lens is None else _i64(lens).contiguous()
+                rc = L.pdt_ctc_lookup_lm_search(
+                    _cabi.ptr(probs), probs.stride(0), probs.stride(1), probs.stride(2), _cabi.ptr(lens_dev),
+                    n_frames, N, V, W, _cabi.ptr(lm.logps), _cabi.ptr(lm.logbs), _cabi.ptr(lm.child_start),
+                    _cabi.ptr(lm.ids_wide), _cabi.ptr(lm.succ_start), _cabi.ptr(lm.succ_tok),
+                    _cabi.ptr(lm.succ_node), lm.max_ngram, V + shift + 1, lm.sos, float(self.beta),
+                    int(self.valid_mixture), _cabi.ptr(y), _cabi.ptr(y_lens), _cabi.ptr(nb), _cabi.ptr(b),
+                    _cabi.ptr(ws), ws_bytes, _cabi.stream_ptr(device),
+                )  # fmt: skip
+                _cabi.check(rc, "pdt_ctc_lookup_lm_search")
+        return y, y_lens, nb + b
+
     def _frame_by_frame(
         self, logits: torch.Tensor, lens: Optional[torch.Tensor], state: Dict[str, torch.Tensor]
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -634,6 +672,9 @@ class CTCPrefixSearch(torch.nn.Module):
             if fuse:
                 if not torch.jit.is_scripting():
                     one_kernel = self._fuses_lookup_lm(logits) and dtype == torch.float
+                if one_kernel and n_frames > 0:
+                    if self._searches_in_one_call():
+                        return self._lookup_lm_search(probs, lens, n_frames)
                 state = self.lm.update_input(state, y)
                 if one_kernel:
                     # the history as 16-bit tokens between the frames (copying the (t, N, K) tensor is what a

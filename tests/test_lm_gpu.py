@@ -163,12 +163,16 @@ def test_one_kernel_frames_equal_the_three_kernel_route(order, monkeypatch):
             ey, eyl, eyp = search(_t(lg), ln)
             monkeypatch.setenv("PDT_CTC_LM_FUSED", "1")
             assert search._fuses_lookup_lm(_t(lg))
-            y, yl, yp = search(_t(lg), ln)
-            what = (order, V, W, vm, ln is None)
-            assert torch.isfinite(eyp[:, 0]).all(), what
-            assert torch.equal(yl, eyl) and torch.equal(yp, eyp), what
-            mask = torch.arange(y.shape[0], device=DEV).view(-1, 1, 1) < yl.unsqueeze(0)
-            assert torch.equal(torch.where(mask, y, ey), ey), what
+            # one kernel per frame launched by the host loop, then every frame from one call of the
+            # library (histories in slots instead of copied from frame to frame)
+            for whole in ("0", "1"):
+                monkeypatch.setenv("PDT_CTC_LM_SEARCH", whole)
+                y, yl, yp = search(_t(lg), ln)
+                what = (order, V, W, vm, ln is None, whole)
+                assert torch.isfinite(eyp[:, 0]).all(), what
+                assert y.shape == ey.shape and torch.equal(yl, eyl) and torch.equal(yp, eyp), what
+                mask = torch.arange(y.shape[0], device=DEV).view(-1, 1, 1) < yl.unsqueeze(0)
+                assert torch.equal(torch.where(mask, y, ey), ey), what
 
 
 def test_beam_search_with_lookup_lm():
