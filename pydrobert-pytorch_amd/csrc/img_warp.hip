@@ -693,7 +693,11 @@ __global__ void __launch_bounds__(256) sparse_warp_fast_kernel(const WarpArgs a)
   for (int i = (int)threadIdx.x; i < 2 * M; i += 256) lk[i] = a.knots[n * 2 * M + i];
   for (int i = (int)threadIdx.x; i < 2 * (M + 3); i += 256) lw[i] = a.wv[n * 2 * (M + 3) + i];
   __syncthreads();
+#ifdef PDT_WARP_VGPR
+  auto uni = [](float v) { asm volatile("" : "+v"(v)); return v; };
+#else
   auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+#endif
   float kx[kWarpFastM], ky[kWarpFastM], wx[kWarpFastM], wy[kWarpFastM];
 #pragma unroll
   for (int m = 0; m < kWarpFastM; ++m) {
