@@ -94,6 +94,15 @@
 #define K_SMOV(r) asm volatile("s_mov_b32 %0, %0" : "+s"(s0));
 #define K_SADD(r) asm volatile("s_add_u32 %0, %0, %0" : "+s"(s0) : : "scc");
 
+#define K_CMPCND_VCC(r) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(b0) : "vcc");
+#define K_CMPCND_SG(r) asm volatile("v_cmp_lt_u32 %1, %0, %2\n v_cndmask_b32 %0, %0, %2, %1" : "+v"(r), "+s"(sm) : "v"(b0));
+#define K_UNUSED_CND_VCC_SET(r) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r) : "v"(b0), "{vcc}"(sm));
+#define K_CMP64(r) asm volatile("v_cmp_le_u64 vcc, %0, %1" : : "v"(p##r), "v"(pb0) : "vcc");
+#define K_CMP64S(r) asm volatile("v_cmp_le_u64 %0, %1, %2" : "=s"(sm) : "v"(p##r), "v"(pb0));
+#define K_MINU(r) asm volatile("v_min_u32 %0, %0, %1" : "+v"(r) : "v"(b0));
+#define K_MINDPPU(r) asm volatile("v_min_u32_dpp %0, %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(b0));
+#define K_MOV_DPP_BC(r) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(b0));
+
 #define KERNEL(NAME, K)                                                                     \
   __global__ void NAME(unsigned *out, int iters) {                                          \
     unsigned a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 + 11, a5 = a0 + 13, \
@@ -117,7 +126,8 @@
   X(or_, K_OR) X(xor_, K_XOR) X(sub, K_SUB) X(subrev, K_SUBREV) X(xnor, K_XNOR) X(not_, K_NOT) X(mov, K_MOV) X(mov_lit, K_MOVK) X(add_sgpr, K_ADDS) X(add_inline, K_ADDI) X(add_lit, K_ADDL) \
   X(max_u32, K_MAXU) X(lshr, K_LSHR) X(ashr, K_ASHR) X(fmul, K_FMUL) X(fsub, K_FSUB) X(fmin, K_FMIN) X(fma_sgpr, K_FMAS) X(fma_inline, K_FMAK) X(fadd_sgpr, K_FADDS) \
   X(fcmp_vcc, K_FCMP) X(fmed3, K_FMED3) X(cvt_f32_i32, K_CVTFI) X(cvt_i32_f32, K_CVTIF) X(log, K_LOG) X(rcp, K_RCP) X(pk_fma_f32, K_PKFMA) X(pk_add_f32, K_PKFADD) X(pk_mul_f32, K_PKFMUL) \
-  X(lshl_add_u64, K_ADD64) X(bitop3_sgpr, K_BITOP3S) X(writelane, K_WRITELANE) X(swap, K_SWAP) X(ds_swizzle_wait, K_DSSWZ) X(ds_bpermute_wait, K_BPERM) X(s_mov, K_SMOV) X(s_add, K_SADD)
+  X(lshl_add_u64, K_ADD64) X(bitop3_sgpr, K_BITOP3S) X(writelane, K_WRITELANE) X(swap, K_SWAP) X(ds_swizzle_wait, K_DSSWZ) X(ds_bpermute_wait, K_BPERM) X(s_mov, K_SMOV) X(s_add, K_SADD) \
+  X(cmp_cndmask_vcc_pair, K_CMPCND_VCC) X(cmp_cndmask_sgpr_pair, K_CMPCND_SG) X(cmp_u64_vcc, K_CMP64) X(cmp_u64_sgpr, K_CMP64S) X(min_u32, K_MINU) X(min_u32_dpp, K_MINDPPU) X(mov_dpp_bc, K_MOV_DPP_BC)
 
 #define DEF(n, k) KERNEL(kern_##n, k)
 LIST(DEF)

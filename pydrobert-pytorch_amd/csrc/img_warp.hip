@@ -57,6 +57,11 @@ __device__ __forceinline__ float ln_fast(float x) {
 
 template <int ORDER>
 __device__ __forceinline__ float phi_from_d2(float d2, int order) {
+#ifndef PDT_WARP_REFERENCE_PHI
+  // d2 + 1e-37 is d2 itself for every distance that is not 0 (and 0 * ln(1e-37) = 0 there); the
+  // half and ln 2 folded into one factor
+  if (ORDER == 2) return d2 * (__builtin_amdgcn_logf(d2 + 1e-37f) * 0.34657359f);
+#endif
   if (ORDER == 2) return d2 * (0.5f * ln_fast(fmaxf(d2, FLT_EPSILON * FLT_EPSILON)));
   if (ORDER == 1) return sqrtf(d2);
   if (ORDER == 3) return d2 * sqrtf(d2);
@@ -765,10 +770,12 @@ __global__ void __launch_bounds__(256) sparse_warp_fast_kernel(const WarpArgs a)
       // (border / reflection padding: the coordinates are inside [0, size - 1] already)
       const int xc0 = PADDING == PAD_ZEROS ? min(max(x0, 0), W - 1) : x0, xc1 = min(max(x0 + 1, 0), W - 1);
       const int yc0 = (PADDING == PAD_ZEROS ? min(max(y0, 0), H - 1) : y0) * W, yc1 = min(max(y0 + 1, 0), H - 1) * W;
-      t00[j] = pl[yc0 + xc0];
-      t01[j] = pl[yc0 + xc1];
-      t10[j] = pl[yc1 + xc0];
-      t11[j] = pl[yc1 + xc1];
+      // (unsigned 32-bit byte offsets from the plane's uniform base: no 64-bit address arithmetic per tap)
+      const unsigned char *plb = reinterpret_cast<const unsigned char *>(pl);
+      t00[j] = *reinterpret_cast<const float *>(plb + ((unsigned)(yc0 + xc0) << 2));
+      t01[j] = *reinterpret_cast<const float *>(plb + ((unsigned)(yc0 + xc1) << 2));
+      t10[j] = *reinterpret_cast<const float *>(plb + ((unsigned)(yc1 + xc0) << 2));
+      t11[j] = *reinterpret_cast<const float *>(plb + ((unsigned)(yc1 + xc1) << 2));
     }
 #pragma unroll
     for (int j = 0; j < kWarpPix; ++j) {
@@ -783,7 +790,8 @@ __global__ void __launch_bounds__(256) sparse_warp_fast_kernel(const WarpArgs a)
       acc += (vx0 && vy1) ? t10[j] * (wx0 * wy1) : 0.0f;
       acc += (vx1 && vy1) ? t11[j] * (wx1 * wy1) : 0.0f;
       const int pix = base + j * 256;
-      if (pix < HW) a.out[(n * a.C + c) * (int64_t)HW + pix] = acc;
+      if (pix < HW)
+        *reinterpret_cast<float *>(reinterpret_cast<unsigned char *>(a.out + (n * a.C + c) * (int64_t)HW) + ((unsigned)pix << 2)) = acc;
     }
   }
 }
