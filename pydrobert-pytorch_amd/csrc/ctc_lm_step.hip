@@ -304,6 +304,7 @@ __global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvAr
     }
     wave_sync();
     // the mix with the frame's probabilities (fusion_ext.hip)
+    unsigned lmax = 0u;  // this lane's largest ordering key (every mixed value is >= +0): the selection's first pass
     for (int v = lane; v < V; v += PDT_WAVE) {
       const float f = row[v];
       float o;
@@ -314,6 +315,7 @@ __global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvAr
         o = p[v] * f;
       }
       row[v] = o;
+      lmax = max(lmax, fkey_nonneg(o));
     }
     wave_sync();
     LM_STAMP(2);
@@ -326,13 +328,13 @@ __global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvAr
     const u64 tk = (u64)lane;
 #else
 #if (PDT_LM_TWICE & 2)
-    { const u64 tk0 = wave_top_sorted<false, false>(row, V, M, my_surv); asm volatile("" :: "v"(tk0)); wave_sync(); }
+    { const u64 tk0 = wave_top_sorted<false, true>(row, V, M, my_surv, &lmax); asm volatile("" :: "v"(tk0)); wave_sync(); }
 #endif
-    const u64 tk = wave_top_sorted<false, false>(row, V, M, my_surv);
+    const u64 tk = wave_top_sorted<false, true>(row, V, M, my_surv, V > PDT_WAVE ? &lmax : nullptr);
 #endif
     if (lane < M) {
       L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
-      L.tl_p[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));
+      L.tl_p[k * PDT_WAVE + lane] = fkey_nonneg_inv(key_of(tk));
     }
     wave_sync();
     LM_STAMP(3);

@@ -9,6 +9,8 @@ differentiable with respect to the features / image (bilinear scatter in the bac
 import math
 from typing import Any, Optional, Tuple
 
+import warnings
+
 import torch
 from torch.library import custom_op, register_autograd
 
@@ -41,9 +43,22 @@ SpecAugmentParams = Tuple[
 ]  # fmt: skip
 
 
+_NARROWING_WARNED = False
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
+    """float32 contiguous view / copy of ``t`` for the kernels.  The image kernels compute in float32
+    (the spline systems are solved in float64 inside); a float64 argument is narrowed, results are
+    cast back -- said out loud once per process, since the reference would have computed in float64."""
+    global _NARROWING_WARNED
     t = t.detach()
     if t.dtype != torch.float:
+        if t.dtype == torch.double and not _NARROWING_WARNED:
+            _NARROWING_WARNED = True
+            warnings.warn(
+                "pydrobert_amd: float64 input to an image operator is computed in float32 on the GPU "
+                "and cast back (the reference computes in float64); this warning is shown once"
+            )
         t = t.float()
     return t.contiguous()
 

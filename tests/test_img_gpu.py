@@ -440,3 +440,23 @@ def test_warps_gradients_wrt_flow_and_points(device, include_flow):
     for name, a, b in (("source", s2, s), ("dest", d2, d)):
         err = (a.grad.cpu().double() - b.grad).abs().max() / b.grad.abs().max()
         assert err < 5e-3, (name, include_flow, float(err))
+
+
+def test_float64_images_are_narrowed_out_loud(device):
+    """The image kernels compute in float32; a float64 argument comes back as float64, close to the
+    float32 result, and the narrowing is announced (once per process) instead of happening silently."""
+    import warnings
+
+    from pydrobert_amd import _img
+
+    g = torch.Generator(device=device).manual_seed(5)
+    img = torch.randn((2, 1, 12, 9), device=device, generator=g)
+    flow = torch.randn((2, 12, 9, 2), device=device, generator=g)
+    exp = F.dense_image_warp(img, flow)
+    _img._NARROWING_WARNED = False
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        act = F.dense_image_warp(img.double(), flow.double())
+        act2 = F.dense_image_warp(img.double(), flow.double())
+    assert act.dtype == torch.double and torch.allclose(act.float(), exp, atol=1e-6) and torch.equal(act, act2)
+    assert sum("float64" in str(x.message) for x in w) == 1
