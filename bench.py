@@ -622,7 +622,7 @@ def run_rank(args):
     kernel_names = {
         "error_rate": "pdt::lev_classify_kernel<8> + pdt::lev_bitpar_kernel",
         "prefix_error_rates": "pdt::lev_bitpar_kernel (tables of the error_rate call reused)",
-        "optimal_completion": "pdt::lev_rowsync_kernel<false, false> + pdt::oc_expand_tiles_kernel<8>",
+        "optimal_completion": "pdt::lev_classify_kernel<8> + pdt::oc_bitpar_kernel<3> + pdt::oc_expand_tiles_kernel<8>",
         "ctc_prefix_search": ctc_kernel_name(args.V, args.beam),
     }
     # HBM bytes per launch and instruction counts from the rocprofv3 PMC passes (profiles/), only
@@ -635,13 +635,14 @@ def run_rank(args):
             traffic = rec.get("hbm_bytes_per_launch")
             if "sq" in rec:
                 insts = rec["sq"]["SQ_INSTS_VALU_per_launch"]
-                cyc = rec["sq"].get("valu_issue_cycles_per_inst_measured")
+                ns = rec["sq"].get("valu_issue_ns_per_inst_static_mix")
                 valu = {
                     "wave_insts_per_launch": insts,
-                    "issue_cycles_per_wave_inst": cyc,
-                    "pipe_busy_frac": None if cyc is None else insts * cyc / (1024 * 2.4e9 * op_ms[dom] * 1e-3),
-                    "source": "profiles/r03_ctc_traffic.json (SQ_INSTS_VALU: profiles/collect_r03.sh), profiles/r02_valu_issue.json "
-                              "(measured issue cycles per wave64 VALU instruction at 8 waves/SIMD)",
+                    "issue_ns_per_wave_inst": ns,
+                    "pipe_busy_frac": None if ns is None else insts * ns * 1e-9 / (1024 * op_ms[dom] * 1e-3),
+                    "source": "profiles/r03_ctc_traffic.json (SQ_INSTS_VALU: profiles/collect_r03.sh; the kernel's static "
+                              "instruction mix priced by profiles/tools/valu_mix.py with the issue costs of "
+                              "profiles/r03_valu_issue_cost.txt, measured by profiles/tools/micro/valu_cost.hip)",
                 }
 
     def say(msg):
@@ -693,8 +694,8 @@ def run_rank(args):
                     "profiles/r03_ctc_traffic.json: FETCH_SIZE / WRITE_SIZE PMC passes of profiles/collect_r03.sh over this "
                     "configuration (2 x FETCH + WRITE), a committed record -- not collected in this run",
                 "valu": valu,
-                "note": "priced against HBM as the contract asks; the kernel's own limiter is the "
-                        "consumer wave's dependent instruction chain (DESIGN.md section 4.3)",
+                "note": "priced against HBM as the contract asks; the kernel's own limiter is vector-"
+                        "instruction issue (valu.pipe_busy_frac; DESIGN.md section 4.3)",
             },
         }
         if extra is not None:
