@@ -598,7 +598,14 @@ __global__ void __launch_bounds__(NW * PDT_WAVE) oc_expand_tiles_kernel(const Oc
           v[q].y = tok_of(id[q].y);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) d2[i + q * PDT_WAVE] = v[q];
+        for (int q = 0; q < 4; ++q) {
+          // (non-temporal: 1.95 GB written once and never read by this kernel -- 0.74 -> 0.71 ms for the operator)
+          typedef long long ll2 __attribute__((ext_vector_type(2)));
+          ll2 t;
+          t.x = v[q].x;
+          t.y = v[q].y;
+          __builtin_nontemporal_store(t, reinterpret_cast<ll2 *>(&d2[i + q * PDT_WAVE]));
+        }
       }
       for (; i < pairs; i += PDT_WAVE) {
         const int2 id = s2[i];
