@@ -13,6 +13,6 @@ buf = (ctypes.c_ulonglong * 16)()
 L.pdt_debug_read_stats(buf, 1)
 F.ctc_prefix_search(logits, K); torch.cuda.synchronize()
 L.pdt_debug_read_stats(buf, 1)
-names = ["producer frames", "short list", "miss: too few", "miss: too many", "consumer completes", "lean tier fails", "hidden bound wins", "rounded-key tie", "simd0 prod", "simd0 cons", "simd1 prod", "simd1 cons", "simd2 prod", "simd2 cons", "simd3 prod", "simd3 cons"]
+names = ["producer frames", "short list", "miss: too few", "miss: too many", "consumer completes", "lean tier fails", "third entry wins: 1 prefix", "third entry wins: several", "simd0 prod", "simd0 cons", "simd1 prod", "simd1 cons", "simd2 prod", "simd2 cons", "simd3 prod", "simd3 cons"]
 for i, nm in enumerate(names):
     print("%-20s %10d  %6.2f%%" % (nm, buf[i], 100.0 * buf[i] / (N * T)))

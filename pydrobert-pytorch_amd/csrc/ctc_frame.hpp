@@ -398,6 +398,11 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       else if (!full_list) key2 = fkey_nonneg(tot2 * p2) + 1u;  // upper bound of a hidden entry
       const bool third_wins = isw && rw == 1 && key2 != 0u && key2 >= kth;
       lean_ok = __ballot(third_wins) == 0ull;
+#ifdef PDT_STATS
+      if (!lean_ok) {
+        if (__popcll(__ballot(third_wins)) == 1) PDT_STAT(6); else PDT_STAT(7);
+      }
+#endif
     }
     if (lean_ok) {
       if (isw) {
