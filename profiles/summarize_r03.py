@@ -61,7 +61,13 @@ rec = {
             "waiting": sq2["SQ_WAIT_ANY"] / sq1["SQ_WAVE_CYCLES"],
         },
         "valu_issue_cycles_per_inst_measured": 2.8488,
-        "note": "cycles at 2.4 GHz per wave64 VALU instruction per SIMD with 8 waves resident (profiles/r02_valu_issue.json)",
+        "note": "cycles at 2.4 GHz per wave64 VALU instruction per SIMD with 8 waves resident (profiles/r02_valu_issue.json): the price of a v_add",
+        # the kernel's static instruction mix priced per kind (profiles/tools/valu_mix.py on a hipcc -S
+        # listing of ctc_search.hip with the costs of profiles/r03_valu_issue_cost.txt): 705 fast (1.1 ns),
+        # 144 fast with a scalar operand + 2374 others (1.8 ns), 19 transcendental (3.4 ns) of 3242
+        "valu_issue_ns_per_inst_static_mix": 1.66,
+        "valu_issue_ns_note": "static instruction mix of the kernel's listing priced with profiles/r03_valu_issue_cost.txt "
+                              "(profiles/tools/valu_mix.py; four or more waves per SIMD)",
     },
 }
 json.dump(rec, open(os.path.join(here, "r03_ctc_traffic.json"), "w"), indent=1)
