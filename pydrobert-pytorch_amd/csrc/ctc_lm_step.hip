@@ -11,7 +11,7 @@
 // waves copy the histories.  Scores follow lm_lookup.hip operation for operation, the mix follows
 // fusion_ext.hip: the same bits as the three-kernel route.
 #ifndef PDT_LM_TWICE
-#define PDT_LM_TWICE 0  // timing experiments (same results): 1 the cached row read twice, 2 the list selection twice
+#define PDT_LM_TWICE 0  // timing experiments (same results): 1 the cached row read twice, 2 the list selection twice, 4 the frame twice
 #endif
 #ifndef PDT_LMDBG
 #define PDT_LMDBG 0  // timing experiments (results change): skip 2 list selection, 4 the frame, 8 the history copy
@@ -388,6 +388,15 @@ __global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvAr
 #if (PDT_LMDBG & 4)
     new_src = lane & 15; new_tok = 1; new_kind = 2;
 #else
+#if (PDT_LM_TWICE & 4)
+    {
+      Beam bm2 = bm;
+      int s2, t2, k2;
+      ctc_frame<true>(bm2, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, s2, t2, k2 PDT_STAMP_ARG);
+      asm volatile("" :: "v"(s2), "v"(t2), "v"(k2), "v"(bm2.nb));
+      wave_sync();
+    }
+#endif
     ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
 #endif
 

@@ -6,6 +6,7 @@ Host-side mirror of the reference's ``_img.py`` for the operators on the hot pat
 (``include/pdt_amd.h``).  ``spec_augment_apply_parameters`` and the image warps are
 differentiable with respect to the features / image (bilinear scatter in the backward pass).
 """
+import functools
 import math
 from typing import Any, Optional, Tuple
 
@@ -409,6 +410,19 @@ def dense_image_warp(
     return torch.ops.pydrobert_amd.dense_image_warp(image, flow, indexing, mode, padding_mode)
 
 
+@functools.lru_cache(maxsize=16)
+def _pinned_points_const(k: int, W: int, H: int, device: torch.device) -> torch.Tensor:
+    """(4 k, 2) boundary points for one image size -- constants of (k, W, H): built once per device
+    instead of with a dozen small launches in every call (read only; never modified in place)."""
+    return _pinned_points(k, W, H, 1, device)[0].contiguous()
+
+
+@functools.lru_cache(maxsize=16)
+def _wh_const(W: int, H: int, device: torch.device) -> torch.Tensor:
+    """[W, H] as a device constant (a host-to-device copy per call otherwise)."""
+    return torch.tensor([W, H], dtype=torch.float, device=device)
+
+
 def _pinned_points(k: int, W: int, H: int, N: int, device) -> torch.Tensor:
     # reference _img.py:244-265, points in (x=w, y=h) order
     r = torch.linspace(0.0, 1.0, k + 1, device=device)
@@ -442,14 +456,13 @@ def _sparse_prepare(image, source_points, dest_points, indexing, pinned_boundary
     if src.shape[1] == 0:
         return device, None, None, 0
     if pinned_boundary_points > 0:
-        pp = _pinned_points(pinned_boundary_points, W, H, N, device)
+        pp = _pinned_points_const(pinned_boundary_points, W, H, device).unsqueeze(0).expand(N, -1, -1)
         src, dst = torch.cat([src, pp], 1), torch.cat([dst, pp], 1)
     Mp = src.shape[1]
     if include_flow:
         vals = dst - src  # :561-562
     else:
-        WH = torch.tensor([W, H], dtype=torch.float, device=device)
-        vals = (2.0 * src + 1.0) / WH - 1.0  # :633
+        vals = (2.0 * src + 1.0) / _wh_const(W, H, device) - 1.0  # :633
     return device, dst.contiguous(), vals.contiguous(), Mp
 
 
