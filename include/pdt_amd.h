@@ -311,6 +311,24 @@ int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int6
                          int32_t *pad_from, void *stream);
 
 
+/* Table form of pdt_beam_search_step: the scores of prefix (n, k) are row rows[n * Kp + k] (int64,
+ * in [0, U)) of a (U, V) table -- e.g. the rows of a bigram LookupLanguageModel by context token,
+ * computed once -- and, if row_stats (U, 2) is given (pdt_row_log_softmax_stats of the same table), a
+ * row's maximum and log-sum-exp are read from it instead of being recomputed every iteration.
+ * Everything else as pdt_beam_search_step; the same bits. */
+int pdt_beam_search_step_table(const float *table, int64_t tb_sr, int64_t tb_sv, int64_t U,
+                               const float *row_stats, const int64_t *rows, int64_t N, int64_t Kp,
+                               int64_t V, int64_t width, const float *log_probs_prev, int64_t lp_sn,
+                               int64_t lp_sk, const int64_t *y_prev, int64_t S, int64_t yp_ss,
+                               int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_lens, int64_t le_sn,
+                               int64_t le_sk, int has_eos, int64_t eos, int finish_all_paths,
+                               int64_t pad_value, int64_t *y_next, int64_t *y_next_lens,
+                               float *log_probs_next, int64_t *next_src, int32_t *active,
+                               int32_t *pad_from, void *stream);
+/* stats[2 r], stats[2 r + 1] = max_v table[r][v], log sum_v exp(table[r][v] - max) */
+int pdt_row_log_softmax_stats(const float *table, int64_t tb_sr, int64_t tb_sv, int64_t U, int64_t V,
+                              float *stats, void *stream);
+
 /* ---------------------------------------------------------------------------------------
  * ctc_greedy_search (reference _decoding.py:507-558).  logits (T, N, V) through element
  * strides; blank_idx already normalised to [0, V).  max_out (N,): sum of the per-frame maximum

@@ -35,6 +35,10 @@ struct BeamStepArgs {
   int32_t *active;                   // [1]: += batch elements NOT finished at the start of this iteration
   int32_t *pad_from;                 // (N,): first row of y that is padding (INT32_MAX: none yet)
   int waves_per_wg;
+  // table form (pdt_beam_search_step_table): the scores of prefix (n, k) are row rows[n * Kp + k] of
+  // `scores` (row stride sc_sk; sc_sn unused), its (maximum, log-sum-exp) row_stats[2 r], [2 r + 1]
+  const int64_t *rows;
+  const float *row_stats;
 };
 
 // maximum and log-sum-exp of a strided row (two passes, eight loads in flight)
@@ -135,9 +139,15 @@ __global__ void __launch_bounds__(512) beam_step_kernel(const BeamStepArgs a) {
         cnt[k] = 1;
       }
     } else {
-      const float *row = a.scores + n * a.sc_sn + k * a.sc_sk;
+      const int64_t r = a.rows ? a.rows[n * Kp + k] : 0;
+      const float *row = a.rows ? a.scores + r * a.sc_sk : a.scores + n * a.sc_sn + k * a.sc_sk;
       float mx, lse;
-      row_log_softmax_stats(row, a.sc_sv, V, mx, lse);
+      if (a.row_stats) {
+        mx = a.row_stats[2 * r];
+        lse = a.row_stats[2 * r + 1];
+      } else {
+        row_log_softmax_stats(row, a.sc_sv, V, mx, lse);
+      }
       const u64 tk = wave_top_sorted_strided<true, false, true, true>(row, a.sc_sv, V, M, surv, nullptr, nullptr, 1,
                                                                       bias, mx, lse);
       if (lane < M) {
@@ -205,15 +215,29 @@ __global__ void __launch_bounds__(512) beam_step_kernel(const BeamStepArgs a) {
 
 }  // namespace pdt
 
-extern "C" int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, int64_t N,
-                                    int64_t Kp, int64_t V, int64_t width, const float *log_probs_prev,
-                                    int64_t lp_sn, int64_t lp_sk, const int64_t *y_prev, int64_t S,
-                                    int64_t yp_ss, int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_lens,
-                                    int64_t le_sn, int64_t le_sk, int has_eos, int64_t eos, int finish_all_paths,
-                                    int64_t pad_value, int64_t *y_next, int64_t *y_next_lens,
-                                    float *log_probs_next, int64_t *next_src, int32_t *active,
-                                    int32_t *pad_from, void *stream) {
-  using namespace pdt;
+namespace pdt {
+
+// (maximum, log-sum-exp) of every row of a (U, V) table: what beam_step_kernel computes per prefix and
+// iteration, once per table (the same routine: the same bits)
+__global__ void __launch_bounds__(256) row_stats_kernel(const float *table, const int64_t tb_sr, const int64_t tb_sv,
+                                                        const int U, const int V, float *stats) {
+  const int r = (int)(blockIdx.x * 4 + (threadIdx.x >> 6));
+  if (r >= U) return;
+  float mx, lse;
+  row_log_softmax_stats(table + (int64_t)r * tb_sr, tb_sv, V, mx, lse);
+  if (lane_id() == 0) {
+    stats[2 * r] = mx;
+    stats[2 * r + 1] = lse;
+  }
+}
+
+static int beam_step_entry(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, const int64_t *rows,
+                           const float *row_stats, int64_t N, int64_t Kp, int64_t V, int64_t width,
+                           const float *log_probs_prev, int64_t lp_sn, int64_t lp_sk, const int64_t *y_prev, int64_t S,
+                           int64_t yp_ss, int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_lens, int64_t le_sn,
+                           int64_t le_sk, int has_eos, int64_t eos, int finish_all_paths, int64_t pad_value,
+                           int64_t *y_next, int64_t *y_next_lens, float *log_probs_next, int64_t *next_src,
+                           int32_t *active, int32_t *pad_from, void *stream) {
   if (N < 0 || Kp < 1 || V < 1 || width < 1 || S < 0) return PDT_E_ARG;
   if (N == 0) return PDT_OK;
   if (!scores || !log_probs_prev || (S > 0 && !y_prev) || !y_prev_lens || !y_next || !y_next_lens ||
@@ -224,6 +248,7 @@ extern "C" int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t 
   if (width > PDT_WAVE || Kp > PDT_WAVE) return PDT_E_TOO_LONG;  // (wider beams: the step-by-step form)
   BeamStepArgs a{};
   a.scores = scores; a.sc_sn = sc_sn; a.sc_sk = sc_sk; a.sc_sv = sc_sv;
+  a.rows = rows; a.row_stats = row_stats;
   a.lpp = log_probs_prev; a.lp_sn = lp_sn; a.lp_sk = lp_sk;
   a.y_prev = y_prev; a.yp_ss = yp_ss; a.yp_sn = yp_sn; a.yp_sk = yp_sk;
   a.lens = y_prev_lens; a.le_sn = le_sn; a.le_sk = le_sk;
@@ -238,5 +263,47 @@ extern "C" int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t 
   const size_t smem = ((size_t)nw * PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 8 + (size_t)a.W * 12 +
                        (size_t)a.Kp * 8 + 15) & ~(size_t)15;
   hipLaunchKernelGGL(beam_step_kernel, dim3((unsigned)a.N), dim3(64 * nw), smem, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pdt
+
+extern "C" int pdt_beam_search_step(const float *scores, int64_t sc_sn, int64_t sc_sk, int64_t sc_sv, int64_t N,
+                                    int64_t Kp, int64_t V, int64_t width, const float *log_probs_prev,
+                                    int64_t lp_sn, int64_t lp_sk, const int64_t *y_prev, int64_t S,
+                                    int64_t yp_ss, int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_lens,
+                                    int64_t le_sn, int64_t le_sk, int has_eos, int64_t eos, int finish_all_paths,
+                                    int64_t pad_value, int64_t *y_next, int64_t *y_next_lens,
+                                    float *log_probs_next, int64_t *next_src, int32_t *active,
+                                    int32_t *pad_from, void *stream) {
+  return pdt::beam_step_entry(scores, sc_sn, sc_sk, sc_sv, nullptr, nullptr, N, Kp, V, width, log_probs_prev, lp_sn,
+                              lp_sk, y_prev, S, yp_ss, yp_sn, yp_sk, y_prev_lens, le_sn, le_sk, has_eos, eos,
+                              finish_all_paths, pad_value, y_next, y_next_lens, log_probs_next, next_src, active,
+                              pad_from, stream);
+}
+
+extern "C" int pdt_beam_search_step_table(const float *table, int64_t tb_sr, int64_t tb_sv, int64_t U,
+                                          const float *row_stats, const int64_t *rows, int64_t N, int64_t Kp,
+                                          int64_t V, int64_t width, const float *log_probs_prev, int64_t lp_sn,
+                                          int64_t lp_sk, const int64_t *y_prev, int64_t S, int64_t yp_ss,
+                                          int64_t yp_sn, int64_t yp_sk, const int64_t *y_prev_lens, int64_t le_sn,
+                                          int64_t le_sk, int has_eos, int64_t eos, int finish_all_paths,
+                                          int64_t pad_value, int64_t *y_next, int64_t *y_next_lens,
+                                          float *log_probs_next, int64_t *next_src, int32_t *active,
+                                          int32_t *pad_from, void *stream) {
+  if (!rows || U < 1) return PDT_E_ARG;
+  return pdt::beam_step_entry(table, 0, tb_sr, tb_sv, rows, row_stats, N, Kp, V, width, log_probs_prev, lp_sn, lp_sk,
+                              y_prev, S, yp_ss, yp_sn, yp_sk, y_prev_lens, le_sn, le_sk, has_eos, eos,
+                              finish_all_paths, pad_value, y_next, y_next_lens, log_probs_next, next_src, active,
+                              pad_from, stream);
+}
+
+extern "C" int pdt_row_log_softmax_stats(const float *table, int64_t tb_sr, int64_t tb_sv, int64_t U, int64_t V,
+                                         float *stats, void *stream) {
+  if (U < 0 || V < 1 || U >= (1ll << 31) || V >= (1 << 30)) return PDT_E_ARG;
+  if (U == 0) return PDT_OK;
+  if (!table || !stats) return PDT_E_ARG;
+  hipLaunchKernelGGL(pdt::row_stats_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table,
+                     tb_sr, tb_sv, (int)U, (int)V, stats);
   return (int)hipGetLastError();
 }

@@ -84,7 +84,8 @@ extern "C" {
 // 2: pdt_ctc_prefix_search_workspace_bytes takes V; 3: pdt_lev takes a workspace;
 // 4: pdt_lookup_lm_log_probs takes the forward index of the trie's second level
 // 5: pdt_lev_classified
-// 6: pdt_ctc_lookup_lm_search; pdt_oc_mask takes a workspace for references of up to 512 tokens
+// 6: pdt_ctc_lookup_lm_search; pdt_oc_mask takes a workspace for references of up to 512 tokens;
+//    pdt_beam_search_step_table, pdt_row_log_softmax_stats
 int pdt_amd_abi_version(void) { return 6; }
 
 int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {

@@ -82,6 +82,12 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
         + [_P, _I64, _I64, _INT, _I64, _INT, _I64, _P, _P, _P, _P, _P, _P, _P],
     ),
+    "pdt_beam_search_step_table": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
+        + [_P, _I64, _I64, _INT, _I64, _INT, _I64, _P, _P, _P, _P, _P, _P, _P],
+    ),
+    "pdt_row_log_softmax_stats": (_INT, [_P, _I64, _I64, _I64, _I64, _P, _P]),
     "pdt_ctc_greedy_search": (
         _INT, [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _INT, _P, _P, _I64, _I64, _P, _P],
     ),

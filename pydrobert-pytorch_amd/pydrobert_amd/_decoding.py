@@ -9,6 +9,7 @@ user-supplied language model.
 """
 import math
 import os
+import weakref
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
@@ -747,6 +748,10 @@ class CTCPrefixSearch(torch.nn.Module):
         return y, y_lens, total
 
 
+# dense tables of bigram LookupLanguageModels, per model object (BeamSearch._bigram_table)
+_BIGRAM_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
 class BeamSearch(torch.nn.Module):
     """Beam search driven by an :class:`ExtractableSequentialLanguageModel` (reference
     _decoding.py:158-504).  Each iteration is the user's LM forward, a ``log_softmax``, the
@@ -825,6 +830,43 @@ class BeamSearch(torch.nn.Module):
                                    "grow y".format(int(lens.max()), hist.size(0)))
 
     @torch.jit.unused
+    def _bigram_table(self, device: torch.device):
+        """``(table (U, V), stats (U, 2), sos_row)`` for a bigram :class:`LookupLanguageModel` whose dense
+        table stays below 64 MiB, else ``None``: row ``c`` holds the model's scores after context token
+        ``c`` (one call of its own scoring kernel over every context, made once per model and device and
+        kept while the model's buffers are unchanged), ``stats`` every row's maximum and log-sum-exp.
+        An iteration of the search then reads its prefixes' rows straight from the table
+        (``pdt_beam_search_step_table``) instead of having the model write ``(N K, V)`` scores first."""
+        lm = self.lm
+        if type(lm) is not LookupLanguageModel or lm.max_ngram != 2 or os.environ.get("PDT_BEAM_TABLE", "1") == "0":
+            return None
+        V = lm.vocab_size
+        shift = 0 if (0 <= lm.sos < V) else 1
+        U = V + shift
+        if U * V * 4 > (64 << 20) or lm.logps.device != device:
+            return None
+        key = (lm.logps.data_ptr(), lm.logps._version, lm.logbs.data_ptr(), lm.logbs._version, str(device))
+        ent = _BIGRAM_TABLES.get(lm)
+        if ent is not None and ent[0] == key:
+            return ent[1], ent[2], ent[3]
+        with torch.no_grad():
+            toks = torch.arange(V, device=device)
+            if shift:
+                toks = torch.cat([toks, torch.tensor([lm.sos], device=device)])
+            table, _ = lm.calc_idx_log_probs(toks.unsqueeze(0), dict(), torch.tensor(1, device=device))
+            table = _f32(table).contiguous()
+            stats = torch.empty((U, 2), device=device, dtype=torch.float)
+            with torch.cuda.device(device):
+                rc = _cabi.lib().pdt_row_log_softmax_stats(
+                    _cabi.ptr(table), table.stride(0), table.stride(1), U, V, _cabi.ptr(stats),
+                    _cabi.stream_ptr(device),
+                )
+            _cabi.check(rc, "pdt_row_log_softmax_stats")
+        sos_row = lm.sos if shift == 0 else V
+        _BIGRAM_TABLES[lm] = (key, table, stats, sos_row)
+        return table, stats, sos_row
+
+    @torch.jit.unused
     def _forward_fused(
         self, prev: Dict[str, torch.Tensor], batch_size: Optional[int], max_iters: Optional[int]
     ) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
@@ -870,7 +912,42 @@ class BeamSearch(torch.nn.Module):
                     W: torch.arange(0, W * N, W, device=device).unsqueeze(1)}
         Kp, t, t_stop = 1, 0, -1
         out_dtype = torch.float
+        dense = self._bigram_table(device)
+        first_rows = None if dense is None else torch.full((N, 1), dense[2], dtype=torch.long, device=device)
         while t < max_iters:
+            if dense is not None:
+                # a bigram table model: the prefixes' rows of its dense table, by their last tokens
+                table, stats, _ = dense
+                rows = first_rows if t == 0 else y[t - 1]
+                with torch.cuda.device(device):
+                    y_new = torch.empty((t + 1, N, W), dtype=torch.long, device=device)
+                    lens_new = torch.empty((N, W), dtype=torch.long, device=device)
+                    lp_new = torch.empty((N, W), device=device)
+                    src = torch.empty((N, W), dtype=torch.long, device=device)
+                    rc = L.pdt_beam_search_step_table(
+                        _cabi.ptr(table), table.stride(0), table.stride(1), table.size(0), _cabi.ptr(stats),
+                        _cabi.ptr(rows), N, Kp, V, W,
+                        _cabi.ptr(log_probs), log_probs.stride(0), log_probs.stride(1),
+                        _cabi.ptr(y), t, y.stride(0), y.stride(1), y.stride(2),
+                        _cabi.ptr(lens), lens.stride(0), lens.stride(1), int(has_eos), int(self.eos or 0),
+                        int(self.finish_all_paths), int(self.pad_value), _cabi.ptr(y_new), _cabi.ptr(lens_new),
+                        _cabi.ptr(lp_new), _cabi.ptr(src), counts.data_ptr() + 4 * (t % check_every),
+                        _cabi.ptr(pad_from), _cabi.stream_ptr(device),
+                    )  # fmt: skip
+                _cabi.check(rc, "pdt_beam_search_step_table")
+                y, lens, log_probs, Kp = y_new, lens_new, lp_new, W
+                t += 1
+                if has_eos and (t % check_every == 0 or t == max_iters):
+                    seen = counts.tolist()
+                    lo = t - ((t - 1) % check_every + 1)
+                    for i in range(lo, t):
+                        if i > 0 and seen[i % check_every] == 0:
+                            t_stop = i
+                            break
+                    if t_stop >= 0:
+                        break
+                    counts.zero_()
+                continue
             if t and t % 1024 == 0:
                 steps = torch.arange(t, t + 1024, device=device)
             scores, state_next = self.lm.calc_idx_log_probs(y.flatten(1), prev, steps[t % 1024])

@@ -188,6 +188,40 @@ def test_beam_search_with_lookup_lm():
     assert torch.equal(torch.where(mask, y, exp), exp)
 
 
+@pytest.mark.parametrize("sos", [-1, 0, 3])
+def test_beam_search_reads_a_bigram_models_table(sos, monkeypatch):
+    """BeamSearch over a bigram LookupLanguageModel reads its prefixes' scores (and their log-softmax
+    statistics) from the model's dense (context, token) table, built once, instead of having the model
+    write (N K, V) scores every iteration: the same paths, lengths and log-probabilities -- to the bit --
+    as the fused iterations around the model's own forward (PDT_BEAM_TABLE=0) and as the step-by-step
+    loop; a changed model gets a new table."""
+    rng = np.random.default_rng(4100 + sos)
+    for V, W, N, eos, iters in [(7, 3, 4, 0, 12), (12, 8, 3, None, 9), (40, 16, 5, 5, 20), (5, 5, 2, 1, 6)]:
+        dicts = random_dicts(rng, V, 2, 0.5, sos if sos < 0 else None)
+        for v in range(V):
+            dicts[0].setdefault(v, (float(rng.normal()), float(rng.normal())))
+        lm = M.LookupLanguageModel(V, sos if sos < V else 0, dicts, destructive=True).to(DEV)
+        search = M.BeamSearch(lm, W, eos=eos).to(DEV)
+        outs = []
+        for fused, table in (("1", "1"), ("1", "0"), ("0", "0")):
+            monkeypatch.setenv("PDT_BEAM_FUSED", fused)
+            monkeypatch.setenv("PDT_BEAM_TABLE", table)
+            outs.append(search(dict(), batch_size=N, max_iters=iters))
+        (y, yl, lp), (y1, yl1, lp1), (y2, yl2, lp2) = outs
+        what = (sos, V, W, N, eos)
+        assert y.shape == y1.shape and torch.equal(y, y1) and torch.equal(yl, yl1) and torch.equal(lp, lp1), what
+        assert torch.equal(yl, yl2) and torch.allclose(lp, lp2, rtol=1e-5, atol=1e-6), what
+        monkeypatch.setenv("PDT_BEAM_FUSED", "1")
+        monkeypatch.setenv("PDT_BEAM_TABLE", "1")
+        assert search._bigram_table(search.device_buffer.device) is not None
+        with torch.no_grad():
+            lm.logps.add_(0.25 * torch.randn_like(lm.logps))  # (version counter moves: the table is rebuilt)
+        ya, yla, lpa = search(dict(), batch_size=N, max_iters=iters)
+        monkeypatch.setenv("PDT_BEAM_TABLE", "0")
+        yb, ylb, lpb = search(dict(), batch_size=N, max_iters=iters)
+        assert torch.equal(ya, yb) and torch.equal(yla, ylb) and torch.equal(lpa, lpb), what
+
+
 def test_shallow_fusion_of_two_models():
     """tests/test_lm.py:512-560: fused scores = first + beta * second, states kept apart."""
     g = golden()
