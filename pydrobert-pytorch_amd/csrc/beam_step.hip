@@ -148,8 +148,12 @@ __global__ void __launch_bounds__(512) beam_step_kernel(const BeamStepArgs a) {
       } else {
         row_log_softmax_stats(row, a.sc_sv, V, mx, lse);
       }
-      const u64 tk = wave_top_sorted_strided<true, false, true, true>(row, a.sc_sv, V, M, surv, nullptr, nullptr, 1,
-                                                                      bias, mx, lse);
+      // rows of up to 1024 entries whose statistics are known are read ONCE, all loads in flight, and
+      // ranked out of registers (the general form walks the row twice)
+      const u64 tk = (a.row_stats && V <= 16 * PDT_WAVE)
+                         ? wave_top_sorted_regs<16, true, true>(row, a.sc_sv, V, M, surv, bias, mx, lse)
+                         : wave_top_sorted_strided<true, false, true, true>(row, a.sc_sv, V, M, surv, nullptr, nullptr, 1,
+                                                                            bias, mx, lse);
       if (lane < M) {
         tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
         tlm[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));  // the value that was ranked

@@ -348,11 +348,13 @@ __device__ __forceinline__ u64 wave_top_sorted_strided(const float *xb, const in
 // The same selection for a row in global memory of at most 64 * NR elements, read ONCE: the row
 // stays in registers (all loads in flight) between the per-lane maxima and the survivor pass.
 // Longer rows fall through to wave_top_sorted_strided<LONG>.
-template <int NR, bool BIAS = false>
+template <int NR, bool BIAS = false, bool SOFT = false>
 __device__ __forceinline__ u64 wave_top_sorted_regs(const float *xb, const int64_t sx, int V, int M,
-                                                    u64 *surv, float bias = 0.0f) {
+                                                    u64 *surv, float bias = 0.0f, float soft_max = 0.0f,
+                                                    float soft_lse = 0.0f) {
   if (V > NR * PDT_WAVE || V <= PDT_WAVE)
-    return wave_top_sorted_strided<true, false, BIAS>(xb, sx, V, M, surv, nullptr, nullptr, 1, bias);
+    return wave_top_sorted_strided<true, false, BIAS, SOFT>(xb, sx, V, M, surv, nullptr, nullptr, 1, bias, soft_max,
+                                                            soft_lse);
   int lane = lane_id();
   asm volatile("" : "+v"(lane));
   unsigned keys[NR];
@@ -360,7 +362,10 @@ __device__ __forceinline__ u64 wave_top_sorted_regs(const float *xb, const int64
   for (int i = 0; i < NR; ++i) {
     const int v = lane + i * PDT_WAVE;
     float x = 0.0f;
-    if (i * PDT_WAVE < V && v < V) x = BIAS ? (bias + xb[(int64_t)v * sx]) + 0.0f : xb[(int64_t)v * sx];
+    if (i * PDT_WAVE < V && v < V) {
+      const float raw = xb[(int64_t)v * sx];
+      x = SOFT ? (bias + ((raw - soft_max) - soft_lse)) + 0.0f : (BIAS ? (bias + raw) + 0.0f : raw);
+    }
     keys[i] = (i * PDT_WAVE < V && v < V) ? fkey(x) : 0u;  // 0 < every key: never a survivor
   }
   unsigned lmax = 0u;
@@ -385,7 +390,8 @@ __device__ __forceinline__ u64 wave_top_sorted_regs(const float *xb, const int64
   wave_sync();
   if (count <= PDT_SURV_CAP) return wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
   // too many survivors (heavy ties): the chunked merge of the general form
-  return wave_top_sorted_strided<true, false, BIAS>(xb, sx, V, M, surv, nullptr, nullptr, 1, bias);
+  return wave_top_sorted_strided<true, false, BIAS, SOFT>(xb, sx, V, M, surv, nullptr, nullptr, 1, bias, soft_max,
+                                                          soft_lse);
 }
 
 template <bool LONG = false, bool NONNEG = false>
