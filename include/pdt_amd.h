@@ -110,10 +110,12 @@ int pdt_fill_after_eos(const int64_t *tokens, int64_t outer, int64_t L, int64_t 
  *     class_tokens[n * R + k] = token value of class k            (N, R) int64
  *     max_count (device int32, must be zeroed by the caller) = max set size = the
  *     reference's `C = counts.max().item()` (:511).
- *     workspace: pdt_oc_mask_workspace_bytes(R, H, N) bytes -- 0 up to R = 2048 (the DP row lives in
- *     registers); longer references run a plain one-workgroup-per-utterance form whose rows, sort
- *     buffer and class ids live there (costs that are not exact in float32 replay the reference's
- *     unrolled deletion term by term there as well, O(R^2) per row).
+ *     workspace: pdt_oc_mask_workspace_bytes(R, H, N) bytes.  R <= 512: the tables of the bit-parallel
+ *     kernel (uniform costs; a caller that passes no workspace, or other costs, gets the same masks
+ *     from the row-synchronous kernel, whose DP row lives in registers); 512 < R <= 2048: 0; longer
+ *     references run a plain one-workgroup-per-utterance form whose rows, sort buffer and class ids
+ *     live there (costs that are not exact in float32 replay the reference's unrolled deletion term
+ *     by term there as well, O(R^2) per row).
  * Phase 2, pdt_oc_expand (after the caller has read max_count and allocated targets):
  *     targets[h * tgt_sh + n * tgt_sn + i], i < C, ascending tokens then `padding`.
  * ------------------------------------------------------------------------------------- */
