@@ -638,23 +638,41 @@ __device__ __forceinline__ void oc_table_reads32(const unsigned *tab, const unsi
   e[6] = *reinterpret_cast<const unsigned *>(t + byte_times4<3>(ze, two));
   e[7] = *reinterpret_cast<const unsigned *>(t + byte_times4<3>(zo, two));
 }
-__device__ __forceinline__ void oc_block_decode32(const unsigned (&e)[8], int &total, int &best, unsigned &am) {
-  int run = 0, cand[8];
+// R rows at once, their chains interleaved instruction by instruction (a dependent SDWA instruction
+// right behind its producer costs wait states: 20 s_nop per row when the rows were decoded one after
+// the other)
+template <int R>
+__device__ __forceinline__ void oc_block_decode32(const unsigned (&e)[R][8], int (&total)[R], int (&best)[R],
+                                                  unsigned (&am)[R]) {
+  int run[R], cand[R][8];
+#pragma unroll
+  for (int r = 0; r < R; ++r) run[r] = 0;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(cand[k]) : "v"(run), "v"(e[k]));
-    asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(run) : "v"(run), "v"(e[k]));
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(cand[r][k]) : "v"(run[r]), "v"(e[r][k]));
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      asm("v_add_u32_sdwa %0, %1, sext(%2) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(run[r]) : "v"(run[r]), "v"(e[r][k]));
   }
-  best = min(min(min(cand[0], cand[1]), min(cand[2], cand[3])), min(min(cand[4], cand[5]), min(cand[6], cand[7])));
-  am = 0u;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    best[r] = min(min(min(cand[r][0], cand[r][1]), min(cand[r][2], cand[r][3])),
+                  min(min(cand[r][4], cand[r][5]), min(cand[r][6], cand[r][7])));
+    am[r] = 0u;
+    total[r] = run[r];
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    unsigned t, sh = 4u * k;
-    asm volatile("" : "+v"(sh));
-    asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(t) : "v"(sh), "v"(e[k]));
-    am |= cand[k] == best ? t : 0u;
+    unsigned t[R];
+    const unsigned sh = 4u * k;  // (a scalar operand: no vector move per nibble)
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(t[r]) : "s"(sh), "v"(e[r][k]));
+#pragma unroll
+    for (int r = 0; r < R; ++r) am[r] |= cand[r][k] == best[r] ? t[r] : 0u;
   }
-  total = run;
 }
 
 // min over the 16 lanes of a DPP row, in every lane (written out: left to the compiler every
@@ -909,13 +927,20 @@ __global__ void __launch_bounds__(64 * (NC + 1)) oc_bitpar_kernel(const OcBitArg
     unsigned rest[kChunk], or0[kChunk], or1[kChunk];
     int c0[kChunk], c1[kChunk];
     bool zero_min[kChunk];
+#if PDT_OC_TABLE32
+    int total_r[kChunk], best_r[kChunk];
+    unsigned am_r[kChunk];
+    oc_block_decode32<kChunk>(e, total_r, best_r, am_r);
+#endif
 #pragma unroll
     for (int r = 0; r < kChunk; ++r) {
       const bool active = h0 + r + 1 <= Heff;
       int total, best;
       unsigned am;
 #if PDT_OC_TABLE32
-      oc_block_decode32(e[r], total, best, am);
+      total = total_r[r];
+      best = best_r[r];
+      am = am_r[r];
 #else
       oc_block_decode(e[r], total, best, am);
 #endif
