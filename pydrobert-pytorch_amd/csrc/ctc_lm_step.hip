@@ -146,8 +146,7 @@ __device__ __forceinline__ void lm_score_row(const LmTrie &a, const int (&ct)[kL
 // them, or int16_t: the host's frame loop keeps its own narrow copy between frames (the copy of the
 // (t, N, K) history is what a frame costs beyond ~30 us: a quarter of the bytes)
 template <typename HT>
-__global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvArgs A) {
-  extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void lm_frame(const CtcLmAdvArgs &A, unsigned char *smem) {
   const CtcAdvArgs &a = A.s;
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6), NW = a.waves_per_wg;
@@ -510,6 +509,58 @@ __global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvAr
   }
 }
 
+template <typename HT>
+__global__ void __launch_bounds__(512, 4) ctc_lm_advance_kernel(const CtcLmAdvArgs A) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  lm_frame<HT>(A, smem);
+}
+
+// state of one side of the search's ping-pong: everything a frame reads / writes besides the histories
+struct LmSearchState {
+  float *nb, *b;
+  int64_t *last, *lens;
+  uint8_t *isp;
+  int32_t *slot;
+};
+
+// Every frame of the search in ONE launch: a workgroup stays with its utterance and runs the frames
+// one after the other (no utterance waits for the slowest one of every frame: the frames' costs
+// differ with the number of distinct contexts in the beam, and a launch per frame takes the
+// maximum over the batch a thousand times).  The state goes through the same global buffers as in
+// the launch-per-frame form -- written and read by this workgroup only, a barrier in between.
+template <typename HT>
+__global__ void __launch_bounds__(512, 4)
+ctc_lm_search_kernel(const CtcLmAdvArgs A0, const LmSearchState st0, const LmSearchState st1, const float *probs,
+                     const int64_t p_st, const int64_t p_sn, const int64_t p_sv, const int n_frames) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int W = A0.s.W;
+  for (int t = 0; t < n_frames; ++t) {
+    CtcLmAdvArgs A = A0;
+    CtcAdvArgs &a = A.s;
+    const LmSearchState &prev = (t & 1) ? st1 : st0, &next = (t & 1) ? st0 : st1;
+    a.Kp = t == 0 ? 1 : W;
+    a.S = t;
+    a.nonext = probs + t * p_st; a.ne_sn = p_sn; a.ne_sv = p_sv;
+    a.blank = probs + t * p_st + (int64_t)a.V * p_sv; a.bl_sn = p_sn;
+    a.nb_prev = prev.nb; a.pb_sn = W; a.pb_sk = 1;
+    a.b_prev = prev.b; a.pbb_sn = W; a.pbb_sk = 1;
+    a.last = prev.last; a.la_sn = W; a.la_sk = 1;
+    a.lens = prev.lens; a.le_sn = W; a.le_sk = 1;
+    a.isp = prev.isp; a.ip_sn = (int64_t)W * W; a.ip_sa = W; a.ip_sb = 1;
+    a.y_next_last = next.last; a.y_next_lens = next.lens;
+    a.nb_next = next.nb; a.b_next = next.b; a.next_isp = next.isp;
+    A.slot_prev = prev.slot; A.slot_next = next.slot;
+    A.frame = t;
+    lm_frame<HT>(A, smem);
+    // this utterance's state and histories for the next frame: written by this workgroup, read by it
+    // through ordinary loads -- release to L2, meet, then drop what this CU's L1 may still hold of the
+    // buffers' previous contents (~2 us per frame; a launch boundary did both)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  }
+}
+
 }  // namespace pdt
 
 namespace pdt {
@@ -556,14 +607,6 @@ static int launch_lm_frame(CtcLmAdvArgs &A, const int history_bytes, hipStream_t
 }
 
 // ---- the whole search (pdt_ctc_lookup_lm_search) ------------------------------------------------
-// state of one side of the ping-pong: everything a frame reads / writes besides the histories
-struct LmSearchState {
-  float *nb, *b;
-  int64_t *last, *lens;
-  uint8_t *isp;
-  int32_t *slot;
-};
-
 __global__ void lm_search_init_kernel(LmSearchState st, const int N, const int W) {
   const int n = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (n >= N) return;
@@ -751,24 +794,43 @@ extern "C" int pdt_ctc_lookup_lm_search(
   A.yn_ss = 1; A.yn_sk = p.smax; A.yn_sn = 2 * width * p.smax;
   a.next_src = reinterpret_cast<int64_t *>(w + p.src);
   a.next_nonext = w + p.nonext_flags;
-  for (int64_t t = 0; t < n_frames; ++t) {
-    const LmSearchState &prev = st[t & 1], &next = st[(t + 1) & 1];
-    const int64_t Kp = t == 0 ? 1 : width;
-    a.Kp = (int)Kp;
-    a.S = (int)t;
-    a.nonext = probs + t * p_st; a.ne_sn = p_sn; a.ne_sv = p_sv;
-    a.blank = probs + t * p_st + V * p_sv; a.bl_sn = p_sn;
-    a.nb_prev = prev.nb; a.pb_sn = width; a.pb_sk = 1;
-    a.b_prev = prev.b; a.pbb_sn = width; a.pbb_sk = 1;
-    a.last = prev.last; a.la_sn = width; a.la_sk = 1;
-    a.lens = prev.lens; a.le_sn = width; a.le_sk = 1;
-    a.isp = prev.isp; a.ip_sn = width * width; a.ip_sa = width; a.ip_sb = 1;
-    a.y_next_last = next.last; a.y_next_lens = next.lens;
-    a.nb_next = next.nb; a.b_next = next.b; a.next_isp = next.isp;
-    A.slot_prev = prev.slot; A.slot_next = next.slot;
-    A.frame = t;
-    const int rc = launch_lm_frame(A, hb, hs);
+  // one launch for every frame (ctc_lm_search_kernel); PDT_LM_PERSISTENT=0: a launch per frame (comparisons)
+  bool persistent = true;
+  if (const char *e = getenv("PDT_LM_PERSISTENT")) persistent = e[0] != '0';
+  if (persistent) {
+    a.Kp = (int)width;  // (the LDS plan of the widest frame; the first frame's single prefix fits inside it)
+    const size_t smem = plan_lm_frame(A);
+    if (smem == 0) return PDT_E_TOO_LONG;
+    auto kern = hb == 2 ? ctc_lm_search_kernel<int16_t> : ctc_lm_search_kernel<int64_t>;
+    if (smem > 64 * 1024) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+      if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)N), dim3(64 * a.waves_per_wg), smem, hs, A, st[0], st[1], probs, p_st,
+                       p_sn, p_sv, (int)n_frames);
+    const int rc = (int)hipGetLastError();
     if (rc != PDT_OK) return rc;
+  } else {
+    for (int64_t t = 0; t < n_frames; ++t) {
+      const LmSearchState &prev = st[t & 1], &next = st[(t + 1) & 1];
+      const int64_t Kp = t == 0 ? 1 : width;
+      a.Kp = (int)Kp;
+      a.S = (int)t;
+      a.nonext = probs + t * p_st; a.ne_sn = p_sn; a.ne_sv = p_sv;
+      a.blank = probs + t * p_st + V * p_sv; a.bl_sn = p_sn;
+      a.nb_prev = prev.nb; a.pb_sn = width; a.pb_sk = 1;
+      a.b_prev = prev.b; a.pbb_sn = width; a.pbb_sk = 1;
+      a.last = prev.last; a.la_sn = width; a.la_sk = 1;
+      a.lens = prev.lens; a.le_sn = width; a.le_sk = 1;
+      a.isp = prev.isp; a.ip_sn = width * width; a.ip_sa = width; a.ip_sb = 1;
+      a.y_next_last = next.last; a.y_next_lens = next.lens;
+      a.nb_next = next.nb; a.b_next = next.b; a.next_isp = next.isp;
+      A.slot_prev = prev.slot; A.slot_next = next.slot;
+      A.frame = t;
+      const int rc = launch_lm_frame(A, hb, hs);
+      if (rc != PDT_OK) return rc;
+    }
   }
   const LmSearchState &fin = st[n_frames & 1];
   if (hb == 2)
