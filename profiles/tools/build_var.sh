@@ -14,6 +14,7 @@ cd "$CS"
 make -s -j8 > /dev/null
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off"
 BASE=$(basename "$SRC" .hip)
+[ "$BASE" = ctc_search ] && FLAGS="$FLAGS -fno-slp-vectorize"  # (as the Makefile builds it)
 /opt/rocm/bin/hipcc $FLAGS "$@" -c "$SRC" -o "$D/$BASE.o"
 OBJS=$(ls build/*.o | grep -v "build/$BASE.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o "$D/lib.so" "$D/$BASE.o" $OBJS
