@@ -40,6 +40,13 @@ extern "C" {
 /* Library / build identification. */
 int pdt_amd_abi_version(void);
 
+/* Run-time switches (kernel selection for comparisons; INTEGRATION.md "Switches").  Each is
+ * initialised ONCE from the environment variable of the same name the first time the library
+ * needs one -- nothing on a launch path calls getenv -- and can be changed / read afterwards.
+ * Unknown names return PDT_E_ARG.  No counterpart in the reference (it has one route per operator). */
+int pdt_amd_set_switch(const char *name, int value);
+int pdt_amd_get_switch(const char *name, int *value);
+
 /* ---------------------------------------------------------------------------------------
  * Batched Levenshtein: error_rate, edit_distance, prefix_error_rates,
  * prefix_edit_distances.  Replaces _string_matching (_string.py:146-406) for

@@ -4,6 +4,7 @@ import os, sys, torch
 sys.path.insert(0, "."); sys.path.insert(0, "pydrobert-pytorch_amd")
 import bench
 from pydrobert_amd import modules as M
+from pydrobert_amd import switches
 dev = torch.device("cuda:0")
 T, N, V, K = 1000, 1024, 1000, 16
 lg = bench.peaky_logits(T, N, V, dev, 0x5EED0003)
@@ -12,14 +13,14 @@ lens = torch.randint(T // 2, T + 1, (N,), device=dev)
 for vm in (False, True):
     search = M.CTCPrefixSearch(K, 0.2, lm, valid_mixture=vm)
     for ln in (None, lens):
-        os.environ["PDT_CTC_LM_SEARCH"] = "1"; a = search(lg, ln)
-        os.environ["PDT_CTC_LM_SEARCH"] = "0"; b = search(lg, ln)
+        switches.set("PDT_CTC_LM_SEARCH", 1); a = search(lg, ln)
+        switches.set("PDT_CTC_LM_SEARCH", 0); b = search(lg, ln)
         mask = torch.arange(a[0].shape[0], device=dev).view(-1, 1, 1) < a[1].unsqueeze(0)
         ok = torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(torch.where(mask, a[0], b[0]), b[0])
         print("ctc + lookup lm, valid_mixture", vm, "ragged", ln is not None, "equal:", ok)
         assert ok
 bs = M.BeamSearch(lm, 16, eos=0).to(dev)
-os.environ["PDT_BEAM_TABLE"] = "1"; a = bs(dict(), batch_size=N, max_iters=100)
-os.environ["PDT_BEAM_TABLE"] = "0"; b = bs(dict(), batch_size=N, max_iters=100)
+switches.set("PDT_BEAM_TABLE", 1); a = bs(dict(), batch_size=N, max_iters=100)
+switches.set("PDT_BEAM_TABLE", 0); b = bs(dict(), batch_size=N, max_iters=100)
 ok = all(torch.equal(x, y) for x, y in zip(a, b))
 print("beam search table form equal:", ok); assert ok

@@ -4,6 +4,7 @@ three-kernel route: random models of order 2-4, widths, vocabularies, ragged len
 import os, sys, numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "pydrobert-pytorch_amd"); sys.path.insert(0, "tests")
 from pydrobert_amd import modules as M
+from pydrobert_amd import switches
 from _lm_fixtures import random_dicts
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
@@ -22,10 +23,10 @@ for it in range(cases):
     lens = torch.from_numpy(rng.integers(0, T + 1, N)).to(dev) if rng.random() < 0.6 else None
     search = M.CTCPrefixSearch(W, beta, lm, valid_mixture=vm)
     x = torch.from_numpy(lg).to(dev)
-    os.environ["PDT_CTC_LM_FUSED"] = "1"; os.environ["PDT_CTC_LM_SEARCH"] = "1"
+    switches.set("PDT_CTC_LM_FUSED", 1); switches.set("PDT_CTC_LM_SEARCH", 1)
     y, yl, yp = search(x, lens)
-    os.environ["PDT_CTC_LM_SEARCH"] = "0"
-    if it % 4 == 3: os.environ["PDT_CTC_LM_FUSED"] = "0"
+    switches.set("PDT_CTC_LM_SEARCH", 0)
+    if it % 4 == 3: switches.set("PDT_CTC_LM_FUSED", 0)
     ey, eyl, eyp = search(x, lens)
     mask = torch.arange(y.shape[0], device=dev).view(-1, 1, 1) < yl.unsqueeze(0)
     ok = y.shape == ey.shape and torch.equal(yl, eyl) and torch.equal(yp, eyp) and torch.equal(torch.where(mask, y, ey), ey)

@@ -4,6 +4,7 @@ disagreement or the number of cases."""
 import os, sys, numpy as np, torch
 sys.path.insert(0, "."); sys.path.insert(0, "pydrobert-pytorch_amd")
 from pydrobert_amd import functional as F
+from pydrobert_amd import switches
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 400
@@ -24,8 +25,8 @@ for it in range(cases):
     ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
     if rng.random() < 0.3:  # non-contiguous views
         ta = torch.stack([ta, ta], -1)[..., 0]
-    os.environ["PDT_OC_BITPAR"] = "1"; x = F.optimal_completion(ta, tb, warn=False, **kw)
-    os.environ["PDT_OC_BITPAR"] = "0"; y = F.optimal_completion(ta, tb, warn=False, **kw)
+    switches.set("PDT_OC_BITPAR", 1); x = F.optimal_completion(ta, tb, warn=False, **kw)
+    switches.set("PDT_OC_BITPAR", 0); y = F.optimal_completion(ta, tb, warn=False, **kw)
     if x.shape != y.shape or not torch.equal(x, y):
         print("MISMATCH", it, R, H, N, V, kw); sys.exit(1)
 print("fuzz_oc: %d cases, no disagreement" % cases)

@@ -9,6 +9,7 @@
 // candidate index (the reference's torch.topk leaves them unspecified).
 #include "advance_args.hpp"
 #include "ctc_frame.hpp"
+#include "switches.hpp"
 
 namespace pdt {
 
@@ -108,7 +109,7 @@ __global__ void __launch_bounds__(512) ctc_advance_kernel(const CtcAdvArgs a) {
 
 int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
-  static const bool force_wide = getenv("PDT_STEP_WIDE") != nullptr;
+  const bool force_wide = switches().step_wide != 0;
   if (force_wide || a.W > kMaxWidth || a.Kp > kMaxWidth) return launch_ctc_advance_wide(a, stream);  // (advance_wide.hip)
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
@@ -216,7 +217,7 @@ __global__ void __launch_bounds__(512) beam_advance_kernel(const BeamAdvArgs a) 
 
 int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
-  static const bool force_wide = getenv("PDT_STEP_WIDE") != nullptr;
+  const bool force_wide = switches().step_wide != 0;
   if (force_wide || a.W > PDT_WAVE || a.Kp > PDT_WAVE) return launch_beam_advance_wide(a, stream);  // (advance_wide.hip)
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)

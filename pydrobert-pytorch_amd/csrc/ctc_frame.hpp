@@ -59,10 +59,6 @@ struct Beam {
   int last, len, node;
   unsigned isp;  // bit k' set <=> this prefix is a prefix of beam entry k' (beam width <= 32)
   int origin = 0;  // trie form: the beam entry of the last checkpoint this prefix descends from
-  // FAMILY form (ctc_packed.hip): the beam entries that are this prefix plus one token, and the
-  // entry that is this prefix minus its last token (-1: not in the beam)
-  unsigned dch = 0u;
-  int dpar = -1;
 };
 
 __device__ __forceinline__ u64 readlane_u64(u64 v, int l) {
@@ -120,8 +116,6 @@ struct FrameLds {
   int list_len;
   float *hdr;
   int2 *trie_u = nullptr;  // trie form: this utterance's records, trie + n * T * W (wave-uniform)
-  int *dpar_tab = nullptr;  // FAMILY form: [W] direct parent of every new beam entry
-  unsigned tau_in = 0u;     // SKIP_LEAN form: a lower bound of the K-th winner's key the caller knows (0: none)
   static __host__ __device__ size_t bytes(int V, int W, int Kp, bool dense) {
     const int RS = W > Kp ? W : Kp;
     size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)(dense ? Kp : 1) * PDT_WAVE * 8;
@@ -183,9 +177,7 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 
 // Returns whether the list as handed over was enough (false: this wave had to complete a short
 // list -- the search kernel's producers send short lists only while that stays rare).
-// FAMILY: also maintain Beam::dch / dpar.  SKIP_LEAN: the caller's own lean tier has already
-// failed on this frame -- straight to the full tiers (FrameLds::tau_in).
-template <bool DENSE, bool FAMILY = false, bool SKIP_LEAN = false>
+template <bool DENSE>
 __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float inv, const int V,
                                           const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
@@ -314,8 +306,8 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   bool selected = false;
   // a lower bound of the K-th winner's key the lean tier leaves behind for the full tiers
   // (0: none): its candidates are a subset of theirs, so its K-th largest cannot exceed theirs
-  unsigned tau_hint = SKIP_LEAN ? L.tau_in : 0u;
-  if constexpr (!SKIP_LEAN) {  // scope of the lean tier's per-lane layout values
+  unsigned tau_hint = 0u;
+  {  // scope of the lean tier's per-lane layout values
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
   // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
   // available list entries of stream 0 in order, entry 3R-2 is stream 1, entry 3R-1 stream 2.
@@ -695,7 +687,6 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // nxt[a * W + b] = token of prefix b at position len(a), defined when a is a strict prefix.
   const int RS = W > Kp ? W : Kp;
   if (lane < RS) L.chm[lane] = fresh_zero();
-  if (FAMILY && lane < RS) L.dpar_tab[lane] = -1;
   wave_sync();
   if (is_valid) {
     atomicOr(&L.chm[new_src], 1u << lane);
@@ -704,7 +695,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   }
   wave_sync();
   PDT_STAMP(10);
-  unsigned isp_new = 0u, dch_new = 0u;
+  unsigned isp_new = 0u;
   bool need_walk = false;
   if (is_valid) {
     unsigned cand = 0u;
@@ -741,10 +732,6 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
           need_walk = true;
         }
         L.nxt_new[lane * W + b] = nx;
-        if (FAMILY && nw.len + 1 == len_b) {  // my direct child; I am its direct parent
-          dch_new |= 1u << b;
-          L.dpar_tab[b] = lane;
-        }
       }
     }
   }
@@ -770,11 +757,6 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     }
   }
   nw.isp = isp_new;
-  if (FAMILY) {
-    wave_sync();
-    nw.dch = dch_new;
-    nw.dpar = is_valid ? L.dpar_tab[lane] : -1;
-  }
   bm = nw;
   wave_sync();
   PDT_STAMP(5);

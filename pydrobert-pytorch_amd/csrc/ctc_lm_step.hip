@@ -21,6 +21,7 @@
 #include "advance_args.hpp"
 #include "ctc_frame.hpp"
 #include "row_reduce.hpp"
+#include "switches.hpp"
 
 namespace pdt {
 
@@ -583,8 +584,8 @@ static size_t plan_lm_frame(CtcLmAdvArgs &A) {
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;
   while (nw > 1 && lds_of(nw) > 40 * 1024) nw >>= 1;
-  if (const char *e = getenv("PDT_LM_STEP_WAVES")) {  // (experiments)
-    const int f = atoi(e);
+  {  // (experiments)
+    const int f = switches().lm_step_waves;
     if (f == 1 || f == 2 || f == 4 || f == 8) nw = f;
   }
   const size_t smem = lds_of(nw);
@@ -666,8 +667,7 @@ static LmSearchPlan plan_lm_search(int64_t n_frames, int64_t N, int64_t W, int h
   p.src = take((size_t)N * W * 8);
   const size_t rf = (size_t)((V + 31) & ~(int64_t)31);
   p.cached = max_ngram == 2 && (size_t)U * rf * 4 <= kLmCacheBytes;
-  if (const char *e = getenv("PDT_LM_CACHE"))  // (comparisons)
-    if (e[0] == '0') p.cached = 0;
+  if (!switches().lm_cache) p.cached = 0;  // (comparisons)
   if (p.cached) {
     p.cache = take((size_t)U * rf * 4);
     p.cache_flag = take((size_t)U * 4);
@@ -796,8 +796,7 @@ extern "C" int pdt_ctc_lookup_lm_search(
   a.next_src = reinterpret_cast<int64_t *>(w + p.src);
   a.next_nonext = w + p.nonext_flags;
   // one launch for every frame (ctc_lm_search_kernel); PDT_LM_PERSISTENT=0: a launch per frame (comparisons)
-  bool persistent = true;
-  if (const char *e = getenv("PDT_LM_PERSISTENT")) persistent = e[0] != '0';
+  const bool persistent = switches().lm_persistent != 0;
   if (persistent) {
     a.Kp = (int)width;  // (the LDS plan of the widest frame; the first frame's single prefix fits inside it)
     const size_t smem = plan_lm_frame(A);

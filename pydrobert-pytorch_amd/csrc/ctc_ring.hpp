@@ -1,6 +1,5 @@
-// Pieces shared by the two forms of the fused CTC prefix search (ctc_search.hip: one consumer wave
-// per utterance; ctc_packed.hip: four utterances per consumer wave): tuning constants, the softmax
-// numerator, and the LDS ring slot that producer and consumer waves of an utterance share.
+// Pieces of the fused CTC prefix search (ctc_search.hip): tuning constants, the softmax numerator,
+// and the LDS ring slot that producer and consumer waves of an utterance share.
 #pragma once
 #include "ctc_frame.hpp"
 
@@ -90,12 +89,5 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
   r.producers = producers;
   return r;
 }
-
-// the four-utterances-per-consumer-wave form (ctc_packed.hip): beams of up to 16 prefixes over rows
-// of up to 511 tokens
-struct PackedLayout;
-bool ctc_packed_applies(int V, int W);
-int launch_ctc_search_packed(CtcArgs a, hipStream_t stream);
-int ctc_packed_ring_slots(int V, int W);
 
 }  // namespace pdt

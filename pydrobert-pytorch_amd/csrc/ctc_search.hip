@@ -30,6 +30,7 @@
 // Tie policy: equal-mass candidates are taken lowest lane first (the reference's torch.topk
 // leaves ties unspecified); parity is defined on tie-free inputs.
 #include "ctc_ring.hpp"
+#include "switches.hpp"
 
 #include <cstdlib>
 
@@ -651,10 +652,6 @@ int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4) {
   const int rc = pdt::plan_ctc_search((int)V, (int)width, &plan, &rl);
   if (rc != PDT_OK) return rc;
   plan4[0] = plan.producers; plan4[1] = plan.nstage; plan4[2] = plan.utt_per_wg; plan4[3] = plan.inreg;
-  if (pdt::ctc_packed_applies((int)V, (int)width)) {  // four utterances per consumer wave
-    plan4[1] = pdt::ctc_packed_ring_slots((int)V, (int)width);
-    plan4[2] = 4;
-  }
   return PDT_OK;
 }
 
@@ -676,11 +673,7 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   a.trie = reinterpret_cast<int2 *>(workspace);
   a.ckpt = a.trie + T * N * width;
   a.grow = reinterpret_cast<unsigned char *>(workspace) + ctc_trie_bytes(T, N, width);
-  {
-    const char *e = std::getenv("PDT_CTC_EXACT_DIV");
-    a.exact_div = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (ctc_packed_applies(a.V, a.W)) return launch_ctc_search_packed(a, (hipStream_t)stream);
+  a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
   CtcPlan plan;
   RingLayout rl;
   const int rc = plan_ctc_search(a.V, a.W, &plan, &rl);

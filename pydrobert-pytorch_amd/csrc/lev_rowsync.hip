@@ -16,6 +16,7 @@
 // and optimal-completion sets come out as class bitmasks whose set bits are already in the
 // ascending token order the reference produces with sort + masked_scatter (:503-514).
 #include "lev_classes.hpp"
+#include "switches.hpp"
 
 namespace pdt {
 
@@ -664,8 +665,8 @@ int launch_oc_expand(const uint32_t *bitmask, const int64_t *class_tokens, int R
       const size_t l8 = oc_tile_lds(R, W, C, NB, a.over_n, chunk, 8, nullptr, nullptr);
       const size_t lds_cu = 160 * 1024;
       if (min(lds_cu / l8, (size_t)4) * 8 > min(lds_cu / l4, (size_t)8) * 4) nw = 8;
-      static const char *force = getenv("PDT_OC_WAVES");
-      if (force && (atoi(force) == 4 || atoi(force) == 8)) nw = atoi(force);
+      const int force = switches().oc_waves;
+      if (force == 4 || force == 8) nw = force;
     }
     a.nw = nw;
     const size_t smem = oc_tile_lds(R, W, C, NB, a.over_n, chunk, nw, nullptr, nullptr);

@@ -6,6 +6,8 @@
 #include <cstdlib>
 
 #include "lev_common.hpp"
+#include "switches.hpp"
+#include <cstring>
 
 namespace pdt {
 int launch_lev_skewed(LevArgs a, hipStream_t stream);
@@ -48,19 +50,37 @@ static bool costs_exact_in_f32(float ins, float del, float sub, int64_t R, int64
 
 // The bit-parallel kernels (lev_bitpar.hip) serve unit costs when the caller passed the workspace
 // their plan asks for; PDT_LEV_BITPAR=0 keeps the cell-by-cell kernels (for comparisons).
-static bool bitpar_enabled() {
-  static const bool on = [] {
-    const char *e = std::getenv("PDT_LEV_BITPAR");
-    return !(e && e[0] == '0');
-  }();
-  return on;
-}
+static bool bitpar_enabled() { return switches().lev_bitpar != 0; }
 
-// PDT_OC_BITPAR=0 keeps optimal completion on the row-synchronous kernel (read at every call:
-// the tests run both in one process).
-static bool oc_bitpar_enabled() {
-  const char *e = std::getenv("PDT_OC_BITPAR");
-  return !(e && e[0] == '0');
+// PDT_OC_BITPAR=0 keeps optimal completion on the row-synchronous kernel (the tests run both in one
+// process through pdt_amd_set_switch).
+static bool oc_bitpar_enabled() { return switches().oc_bitpar != 0; }
+
+namespace {
+struct SwitchName {
+  const char *name;
+  int Switches::*field;
+  int deft;
+};
+const SwitchName kSwitchNames[] = {
+    {"PDT_LEV_BITPAR", &Switches::lev_bitpar, 1},       {"PDT_OC_BITPAR", &Switches::oc_bitpar, 1},
+    {"PDT_OC_WAVES", &Switches::oc_waves, 0},           {"PDT_CTC_EXACT_DIV", &Switches::ctc_exact_div, 0},
+    {"PDT_CTC_ROWREG", &Switches::ctc_rowreg, 1},       {"PDT_STEP_WIDE", &Switches::step_wide, 0},
+    {"PDT_LM_CACHE", &Switches::lm_cache, 1},           {"PDT_LM_PERSISTENT", &Switches::lm_persistent, 1},
+    {"PDT_LM_STEP_WAVES", &Switches::lm_step_waves, 0},
+};
+}  // namespace
+
+Switches &switches() {
+  static Switches s = [] {
+    Switches v{};
+    for (const SwitchName &n : kSwitchNames) {
+      const char *e = std::getenv(n.name);
+      v.*(n.field) = (e && e[0]) ? std::atoi(e) : n.deft;
+    }
+    return v;
+  }();
+  return s;
 }
 
 static int fill_common(LevArgs &a, const int64_t *ref, int64_t R, int64_t ref_st, int64_t ref_sn,
@@ -86,7 +106,22 @@ extern "C" {
 // 5: pdt_lev_classified
 // 6: pdt_ctc_lookup_lm_search; pdt_oc_mask takes a workspace for references of up to 512 tokens;
 //    pdt_beam_search_step_table, pdt_row_log_softmax_stats
-int pdt_amd_abi_version(void) { return 6; }
+// 7: pdt_amd_set_switch / pdt_amd_get_switch; the four-utterances-per-wave CTC form left the library
+int pdt_amd_abi_version(void) { return 7; }
+
+int pdt_amd_set_switch(const char *name, int value) {
+  if (!name) return PDT_E_ARG;
+  for (const pdt::SwitchName &n : pdt::kSwitchNames)
+    if (std::strcmp(n.name, name) == 0) return pdt::switches().*(n.field) = value, PDT_OK;
+  return PDT_E_ARG;
+}
+
+int pdt_amd_get_switch(const char *name, int *value) {
+  if (!name || !value) return PDT_E_ARG;
+  for (const pdt::SwitchName &n : pdt::kSwitchNames)
+    if (std::strcmp(n.name, name) == 0) return *value = pdt::switches().*(n.field), PDT_OK;
+  return PDT_E_ARG;
+}
 
 int64_t pdt_lev_workspace_bytes(int64_t R, int64_t H, int64_t N) {
   if (R < 0 || H < 0 || N <= 0) return 0;

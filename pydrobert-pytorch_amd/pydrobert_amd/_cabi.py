@@ -28,6 +28,8 @@ _F = _c.c_float
 # name -> (restype, argtypes); mirrors include/pdt_amd.h declaration by declaration
 SIGNATURES = {
     "pdt_amd_abi_version": (_INT, []),
+    "pdt_amd_set_switch": (_INT, [_c.c_char_p, _INT]),
+    "pdt_amd_get_switch": (_INT, [_c.c_char_p, _P]),
     "pdt_lev": (
         _INT,
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _F, _F, _F]

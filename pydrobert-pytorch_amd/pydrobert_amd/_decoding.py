@@ -8,14 +8,13 @@ Host-side mirror of the reference's ``_decoding.py`` for the operators on the ho
 user-supplied language model.
 """
 import math
-import os
 import weakref
 from typing import Any, Dict, List, Optional, Tuple
 
 import torch
 from torch.library import custom_op, register_autograd
 
-from . import _cabi, argcheck, config
+from . import _cabi, argcheck, config, switches
 from ._lm import ExtractableSequentialLanguageModel, LookupLanguageModel, MixableSequentialLanguageModel
 
 __all__ = [
@@ -552,9 +551,9 @@ class CTCPrefixSearch(torch.nn.Module):
         scoring methods (a subclass that overrides them must be called), of order two or more with its
         forward index built, the beam fits the frame routine and nothing wants gradients."""
         lm = self.lm
-        if type(lm) is not LookupLanguageModel or os.environ.get("PDT_CTC_LM_FUSED", "1") == "0":
+        if type(lm) is not LookupLanguageModel or not switches.get("PDT_CTC_LM_FUSED"):
             return False
-        if lm.max_ngram < 2 or self.width > 32 or self.beta == 0.0:
+        if lm.max_ngram < 2 or self.width > 32 or self.beta == 0.0 or logits.device.type != "cuda":
             return False
         shift = 0 if (0 <= lm.sos < lm.vocab_size) else 1
         if lm.succ_start.numel() != lm.vocab_size + shift + 2 or lm.logps.device != logits.device:
@@ -573,7 +572,7 @@ class CTCPrefixSearch(torch.nn.Module):
         lm, W = self.lm, self.width
         N, V = nonext.shape
         Kp, S = nb.size(1), y.size(0)
-        device = nonext.device
+        device = _cabi.require_hip(nonext, blank, nb, b, y, y_last, y_lens, is_prefix, y_next, lens, *_lm_buffers(lm))
         nonext, blank, nb, b = (_f32(x) for x in (nonext, blank, nb, b))
         shift = 0 if (0 <= lm.sos < V) else 1
         with torch.cuda.device(device):
@@ -606,7 +605,7 @@ class CTCPrefixSearch(torch.nn.Module):
     @torch.jit.unused
     def _searches_in_one_call(self) -> bool:
         """PDT_CTC_LM_SEARCH=0 keeps the host's frame loop around the one-kernel frames (comparisons)."""
-        return os.environ.get("PDT_CTC_LM_SEARCH", "1") != "0"
+        return switches.get("PDT_CTC_LM_SEARCH") != 0
 
     @torch.jit.unused
     def _lookup_lm_search(
@@ -617,7 +616,7 @@ class CTCPrefixSearch(torch.nn.Module):
         launched ``n_frames`` times from C, the beam's state and histories in a workspace in between."""
         lm, W = self.lm, self.width
         T, N, V = probs.size(0), probs.size(1), probs.size(2) - 1
-        device = probs.device
+        device = _cabi.require_hip(probs, lens, *_lm_buffers(lm))
         probs = _f32(probs)
         shift = 0 if (0 <= lm.sos < V) else 1
         L = _cabi.lib()
@@ -748,6 +747,20 @@ class CTCPrefixSearch(torch.nn.Module):
         return y, y_lens, total
 
 
+def _lm_buffers(lm: "LookupLanguageModel"):
+    """Every trie buffer of an n-gram model the kernels read through raw pointers."""
+    return (lm.logps, lm.logbs, lm.child_start, lm.ids_wide, lm.succ_start, lm.succ_tok, lm.succ_node)
+
+
+def _identity_of(*tensors):
+    """(address, version) of every tensor, or None when one carries no version counter (inference
+    tensors): then there is nothing to recognise an unchanged tensor by and the caller rebuilds."""
+    try:
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    except RuntimeError:
+        return None
+
+
 # dense tables of bigram LookupLanguageModels, per model object (BeamSearch._bigram_table)
 _BIGRAM_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
@@ -759,6 +772,9 @@ class BeamSearch(torch.nn.Module):
     """
 
     __constants__ = ["width", "eos", "finish_all_paths", "pad_value"]
+    # iterations between host reads of the termination count in the fused loop (None: 8 for this
+    # package's LookupLanguageModel, 1 -- the reference's behaviour -- for any other model)
+    host_check_interval: Optional[int] = None
 
     def __init__(
         self,
@@ -824,7 +840,7 @@ class BeamSearch(torch.nn.Module):
 
     @torch.jit.unused
     def _check_growth(self, lens: torch.Tensor, hist: torch.Tensor) -> None:
-        if os.environ.get("PDT_CHECK_INVARIANTS", "0") == "1" and lens.numel():
+        if switches.get("PDT_CHECK_INVARIANTS") == 1 and lens.numel():
             if int(lens.max()) < hist.size(0):
                 raise RuntimeError("BeamSearch: no path is as long as the history ({} < {}): the step must not "
                                    "grow y".format(int(lens.max()), hist.size(0)))
@@ -838,16 +854,21 @@ class BeamSearch(torch.nn.Module):
         An iteration of the search then reads its prefixes' rows straight from the table
         (``pdt_beam_search_step_table``) instead of having the model write ``(N K, V)`` scores first."""
         lm = self.lm
-        if type(lm) is not LookupLanguageModel or lm.max_ngram != 2 or os.environ.get("PDT_BEAM_TABLE", "1") == "0":
+        if type(lm) is not LookupLanguageModel or lm.max_ngram != 2 or not switches.get("PDT_BEAM_TABLE"):
             return None
         V = lm.vocab_size
         shift = 0 if (0 <= lm.sos < V) else 1
         U = V + shift
         if U * V * 4 > (64 << 20) or lm.logps.device != device:
             return None
-        key = (lm.logps.data_ptr(), lm.logps._version, lm.logbs.data_ptr(), lm.logbs._version, str(device))
+        # (kept while EVERY trie buffer is the same tensor at the same version; models whose buffers carry
+        # no version counter -- built under inference_mode -- get a fresh table per search.  Writes the
+        # counter does not see (`.data`, raw pointers) are the caller's to announce: `del
+        # _BIGRAM_TABLES[lm]` or PDT_BEAM_TABLE=0)
+        ident = _identity_of(*_lm_buffers(lm))
+        key = None if ident is None else (ident, str(device))
         ent = _BIGRAM_TABLES.get(lm)
-        if ent is not None and ent[0] == key:
+        if key is not None and ent is not None and ent[0] == key:
             return ent[1], ent[2], ent[3]
         with torch.no_grad():
             toks = torch.arange(V, device=device)
@@ -863,7 +884,8 @@ class BeamSearch(torch.nn.Module):
                 )
             _cabi.check(rc, "pdt_row_log_softmax_stats")
         sos_row = lm.sos if shift == 0 else V
-        _BIGRAM_TABLES[lm] = (key, table, stats, sos_row)
+        if key is not None:
+            _BIGRAM_TABLES[lm] = (key, table, stats, sos_row)
         return table, stats, sos_row
 
     @torch.jit.unused
@@ -879,7 +901,7 @@ class BeamSearch(torch.nn.Module):
         nothing wants gradients and the beam fits a wave; returns ``None`` otherwise."""
         if type(self).update_log_probs_for_step is not BeamSearch.update_log_probs_for_step:
             return None
-        if self.width > 64 or os.environ.get("PDT_BEAM_FUSED", "1") == "0":
+        if self.width > 64 or not switches.get("PDT_BEAM_FUSED"):
             return None
         if torch.is_grad_enabled() and (
             any(p.requires_grad for p in self.lm.parameters())
@@ -904,7 +926,16 @@ class BeamSearch(torch.nn.Module):
         y = y.unsqueeze(2)
         log_probs = torch.zeros((N, 1), device=device)
         lens = torch.zeros((N, 1), dtype=torch.long, device=device)
-        check_every = 8
+        # Iterations between host reads of the "everything finished" count.  Between reads the search may
+        # call the language model up to `check_every - 1` times past the reference's stopping point (their
+        # output is cut off again) -- invisible for a stateless, deterministic model like this package's
+        # LookupLanguageModel, but a stochastic or stateful user model would see extra calls: those are
+        # checked every iteration, as the reference does (_decoding.py:426), unless the caller says
+        # otherwise through `host_check_interval`.
+        check_every = self.host_check_interval
+        if check_every is None:
+            check_every = 8 if type(self.lm) is LookupLanguageModel else 1
+        check_every = max(1, min(int(check_every), 1024))
         counts = torch.zeros((check_every,), dtype=torch.int32, device=device)
         pad_from = torch.full((N,), 2147483647, dtype=torch.int32, device=device)
         steps = torch.arange(0, 1024, device=device)

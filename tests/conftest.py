@@ -49,3 +49,20 @@ def device():
     import torch
 
     return torch.device("cuda:0")
+
+
+@pytest.fixture
+def switch():
+    """``switch("PDT_BEAM_FUSED", 0)``: set one of the package's run-time switches (read from the
+    environment once at import; pydrobert_amd/switches.py) for the rest of the test."""
+    from pydrobert_amd import switches
+
+    old = {}
+
+    def set_(name, value):
+        old.setdefault(name, switches.get(name))
+        switches.set(name, int(value))
+
+    yield set_
+    for name, value in old.items():
+        switches.set(name, value)

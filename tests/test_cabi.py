@@ -44,7 +44,9 @@ def test_ctypes_table_matches_header():
         params = [p for p in m.group(1).split(",") if p.strip() and p.strip() != "void"]
         assert len(params) == len(args), (name, len(params), len(args))
         for p, a in zip(params, args):
-            if "*" in p:
+            if "const char *" in p:
+                assert a is ctypes.c_char_p, (name, p)
+            elif "*" in p:
                 assert a is ctypes.c_void_p, (name, p)
             elif "float" in p:
                 assert a is ctypes.c_float, (name, p)
@@ -98,3 +100,30 @@ def test_check_maps_status_to_runtime_error():
     for rc in (_cabi.PDT_E_ARG, _cabi.PDT_E_TOO_LONG, 700):
         with pytest.raises(RuntimeError):
             _cabi.check(rc, "x")
+
+
+def test_switches_read_once_and_settable(lib):
+    """Every PDT_* switch is listed in one table per side (csrc/switches.hpp, pydrobert_amd/switches.py),
+    initialised from the environment once, and can be changed and read back through the C ABI."""
+    from pydrobert_amd import _cabi, switches
+
+    assert lib.pdt_amd_set_switch(b"PDT_NO_SUCH_SWITCH", 1) == _cabi.PDT_E_ARG
+    for name in switches.names():
+        old = switches.get(name)
+        with switches.override(**{name: old + 1}):
+            assert switches.get(name) == old + 1
+        assert switches.get(name) == old
+    with pytest.raises(KeyError):
+        switches.get("PDT_NO_SUCH_SWITCH")
+    # nothing on an operator's call path reads the environment
+    pkg = os.path.join(ROOT, "pydrobert-pytorch_amd")
+    for sub, pat in (("pydrobert_amd", r"os\.environ|getenv"), ("csrc", r"getenv")):
+        for fn in sorted(os.listdir(os.path.join(pkg, sub))):
+            if not fn.endswith((".py", ".hip", ".hpp")) or fn in ("switches.py", "_cabi.py"):
+                continue
+            text = open(os.path.join(pkg, sub, fn)).read()
+            hits = [l for l in text.splitlines() if re.search(pat, l) and not l.lstrip().startswith(("//", "#"))]
+            if fn == "pdt_api.hip":  # the one reader (pdt::switches)
+                assert len(hits) == 1, hits
+            else:
+                assert not hits, (fn, hits)

@@ -22,15 +22,6 @@ def _peaky_logits(rng, T, N, V, scale=6.0):
     return lg
 
 
-@pytest.fixture(params=["packed", "single"])
-def ctc_form(request, monkeypatch):
-    """Both forms of the one-kernel search: four utterances per consumer wave (beams of up to 16
-    prefixes, rows of up to 511 tokens; csrc/ctc_packed.hip) and one (csrc/ctc_search.hip, which
-    also serves everything beyond).  PDT_CTC_PACKED is read at every call."""
-    monkeypatch.setenv("PDT_CTC_PACKED", "1" if request.param == "packed" else "0")  # (default: the one-utterance form)
-    return request.param
-
-
 def _check_search(act, exp, what):
     y, yl, yp = (x.cpu().numpy() for x in act)
     ey, eyl, eyp = exp
@@ -44,7 +35,7 @@ def _check_search(act, exp, what):
 
 @pytest.mark.parametrize("V", [2, 5, 12, 70, 300])
 @pytest.mark.parametrize("K", [1, 2, 4, 16, 32])
-def test_ctc_prefix_search_random(device, V, K, ctc_form):
+def test_ctc_prefix_search_random(device, V, K):
     if K > V + 1:
         # the reference itself breaks here: padded beam entries carry b = -inf * 0 = NaN into the
         # next frame (_decoding.py:875) and NaN wins every later topk.  See test_ctc_wide_beam.
@@ -147,7 +138,7 @@ def test_ctc_plan_covers_every_vocabulary():
     assert _ctc_plan(1 << 20, 16)[1][3] == 2 and _ctc_plan(256, 16)[1][3] == 1 and _ctc_plan(5000, 16)[1][3] == 0
 
 
-def test_ctc_prefix_search_golden_shape(device, ctc_form):
+def test_ctc_prefix_search_golden_shape(device):
     """SURVEY G-D2 shape: T=30, N=8, V=12, K=4, peaky logits, ragged lens."""
     rng = np.random.default_rng(0x5EED0003)
     lg = _peaky_logits(rng, 30, 8, 12)
@@ -158,7 +149,7 @@ def test_ctc_prefix_search_golden_shape(device, ctc_form):
     _check_search(act, exp, "golden")
 
 
-def test_ctc_prefix_search_long(device, ctc_form):
+def test_ctc_prefix_search_long(device):
     """Longer searches with related beams (trie walks, re-created prefixes); lengths chosen so
     float32 prefix masses do not underflow to 0 (after which everything is a tie)."""
     rng = np.random.default_rng(5)
@@ -170,7 +161,7 @@ def test_ctc_prefix_search_long(device, ctc_form):
         _check_search(act, exp, ("long", T, V, K))
 
 
-def test_ctc_prefix_search_many_checkpoints(device, ctc_form):
+def test_ctc_prefix_search_many_checkpoints(device):
     """Long utterances: the output walk goes through many checkpoints, and with a small ring
     (small V) the checkpoint spacing doubles until the table fits; ragged lengths end between
     checkpoints.  Very peaky frames keep the float32 masses away from 0."""
@@ -185,7 +176,7 @@ def test_ctc_prefix_search_many_checkpoints(device, ctc_form):
         _check_search(act, exp, ("checkpoints", T, V, K))
 
 
-def test_ctc_prefix_search_masked_tokens(device, ctc_form):
+def test_ctc_prefix_search_masked_tokens(device):
     """-inf logits (masked vocabulary entries) and rows with a huge dynamic range: the
     threshold guess of the short lists sees a -inf / overflowing row mean and must fall back to
     the complete selection."""
@@ -201,7 +192,7 @@ def test_ctc_prefix_search_masked_tokens(device, ctc_form):
         _check_search(act, exp, ("masked", T, V, K))
 
 
-def test_ctc_wide_beam(device, ctc_form):
+def test_ctc_wide_beam(device):
     """width > V + 1: the kernel treats padded entries as absent (documented superset of the
     reference, which degenerates to NaN).  Checks: no NaN, valid prefixes are distinct, their
     probabilities are the exact CTC prefix probabilities of a brute-force enumeration."""
@@ -253,7 +244,7 @@ def test_ctc_prefix_search_wider_than_the_kernel_holds(device, V, K):
             _check_search(M.CTCPrefixSearch(K)(torch.from_numpy(lg).to(device), tl), exp, (V, K, T, N, "module"))
 
 
-def test_ctc_strided_logits_and_errors(device, ctc_form):
+def test_ctc_strided_logits_and_errors(device):
     rng = np.random.default_rng(6)
     lg = _peaky_logits(rng, 12, 4, 9)
     t = torch.from_numpy(np.ascontiguousarray(lg.transpose(1, 0, 2))).to(device).transpose(0, 1)
@@ -586,7 +577,7 @@ def test_beam_search_advance_exact_ties(device):
         assert np.array_equal(act[0][..., :K], exp[0][..., :K]), it
 
 
-def test_ctc_prefix_search_exact_ties(device, ctc_form):
+def test_ctc_prefix_search_exact_ties(device):
     """Tokens with IDENTICAL logits give extensions of one prefix identical masses; the list is
     ordered (value, then token), so the lower token wins -- the oracle's flat index order.  The
     keys of such candidates collide in the lean tier's rounded 32-bit sort, which must hand the
@@ -629,7 +620,7 @@ def _disagreeing(y, yl, ey, eyl):
     return [n for n in range(y.shape[1]) if not (np.array_equal(yl[n], eyl[n]) and np.array_equal(y[:, n], ey[:, n]))]
 
 
-def test_ctc_prefix_search_near_ties_are_the_only_disagreements(device, ctc_form):
+def test_ctc_prefix_search_near_ties_are_the_only_disagreements(device):
     """Probabilities are p * (1 / sum) with a guard-free exp: within an ulp or two of the
     reference's quotient.  That can swap two beam entries whose masses agree to ~1e-6 (measured by
     the fuzz scripts: ~4 utterances in 100 000).  Bound it: wherever the beams of kernel and oracle
@@ -649,7 +640,7 @@ def test_ctc_prefix_search_near_ties_are_the_only_disagreements(device, ctc_form
         assert mine == theirs or gap < 1e-5, (n, gap)
 
 
-def test_ctc_prefix_search_exact_division_switch(device, ctc_form, monkeypatch):
+def test_ctc_prefix_search_exact_division_switch(device, switch):
     """PDT_CTC_EXACT_DIV=1 makes the search form every probability as the IEEE quotient e / sum (what
     the reference's softmax does) instead of e * (1 / sum).  Same beams up to near ties either way;
     with the quotient the masses sit no further from the oracle's and no more utterances disagree --
@@ -658,7 +649,7 @@ def test_ctc_prefix_search_exact_division_switch(device, ctc_form, monkeypatch):
     tl = torch.from_numpy(lg).to(device)
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("PDT_CTC_EXACT_DIV", mode)
+        switch("PDT_CTC_EXACT_DIV", mode)
         y, yl, yp = (x.cpu().numpy() for x in F.ctc_prefix_search(tl, K))
         assert np.allclose(yp, eyp, rtol=1e-5, atol=0.0)
         res[mode] = (len(_disagreeing(y, yl, ey, eyl)), float(np.abs(yp / eyp - 1.0).max()))
@@ -667,7 +658,7 @@ def test_ctc_prefix_search_exact_division_switch(device, ctc_form, monkeypatch):
 
 
 @pytest.mark.parametrize("finish_all", [False, True])
-def test_beam_search_fused_iterations_equal_the_step_by_step_loop(device, finish_all, monkeypatch):
+def test_beam_search_fused_iterations_equal_the_step_by_step_loop(device, finish_all, switch):
     """BeamSearch with every iteration in one kernel (csrc/beam_step.hip; the number of unfinished
     batch elements read every eighth iteration) against the loop of reference-shaped torch ops around
     beam_search_advance (PDT_BEAM_FUSED=0): same paths, lengths and padding, log-probabilities to 1e-5;
@@ -696,10 +687,10 @@ def test_beam_search_fused_iterations_equal_the_step_by_step_loop(device, finish
         lm = PositionalBigramLM(torch.from_numpy(table).to(device), torch.from_numpy(pos).to(device))
         for eos in (1, None):
             mod = M.BeamSearch(lm, W, eos, finish_all, -5).to(device)
-            monkeypatch.setenv("PDT_BEAM_FUSED", "0")
-            monkeypatch.setenv("PDT_CHECK_INVARIANTS", "1")  # (the loop's "y grows every iteration" is checked)
+            switch("PDT_BEAM_FUSED", "0")
+            switch("PDT_CHECK_INVARIANTS", "1")  # (the loop's "y grows every iteration" is checked)
             ey, eyl, elp = mod(None, N, iters)
-            monkeypatch.setenv("PDT_BEAM_FUSED", "1")
+            switch("PDT_BEAM_FUSED", "1")
             y, yl, lp = mod(None, N, iters)
             what = (V, W, N, iters, eos, finish_all)
             assert y.shape == ey.shape and torch.equal(yl, eyl), (what, y.shape, ey.shape)

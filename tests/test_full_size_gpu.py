@@ -222,7 +222,7 @@ def test_c3_beam_search_advance(device):
 # ------------------------------------------------------------------------------------------
 # C4: SpecAugment and sparse_image_warp on 2048 x 1000 x 80
 # ------------------------------------------------------------------------------------------
-def test_c3_searches_with_the_bigram_model_in_the_loop(device, monkeypatch):
+def test_c3_searches_with_the_bigram_model_in_the_loop(device, switch):
     """C3 shapes (N=1024, T=1000, V=1000, K=16) with a bigram LookupLanguageModel: the whole
     CTCPrefixSearch from one library call (history slots, cached factor rows) equals the host's frame
     loop around the same frame kernel -- ragged lengths, both mixes -- and BeamSearch reading the
@@ -237,17 +237,17 @@ def test_c3_searches_with_the_bigram_model_in_the_loop(device, monkeypatch):
     with torch.no_grad():
         for vm, ln in ((False, lens), (True, None)):
             search = M.CTCPrefixSearch(K, 0.2, lm, valid_mixture=vm)
-            monkeypatch.setenv("PDT_CTC_LM_SEARCH", "1")
+            switch("PDT_CTC_LM_SEARCH", "1")
             y, yl, yp = search(lg, ln)
-            monkeypatch.setenv("PDT_CTC_LM_SEARCH", "0")
+            switch("PDT_CTC_LM_SEARCH", "0")
             ey, eyl, eyp = search(lg, ln)
             mask = torch.arange(y.shape[0], device=device).view(-1, 1, 1) < yl.unsqueeze(0)
             assert torch.equal(yl, eyl) and torch.equal(yp, eyp) and torch.equal(torch.where(mask, y, ey), ey), vm
             assert bool(torch.isfinite(yp[:, 0]).all())
         bs = M.BeamSearch(lm, K, eos=0).to(device)
-        monkeypatch.setenv("PDT_BEAM_TABLE", "1")
+        switch("PDT_BEAM_TABLE", "1")
         a = bs(dict(), batch_size=N, max_iters=100)
-        monkeypatch.setenv("PDT_BEAM_TABLE", "0")
+        switch("PDT_BEAM_TABLE", "0")
         b = bs(dict(), batch_size=N, max_iters=100)
         assert all(torch.equal(x, z) for x, z in zip(a, b))
 

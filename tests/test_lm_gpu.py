@@ -140,7 +140,7 @@ def test_ctc_prefix_search_with_lookup_lm_fusion():
 
 
 @pytest.mark.parametrize("order", [2, 3, 4])
-def test_one_kernel_frames_equal_the_three_kernel_route(order, monkeypatch):
+def test_one_kernel_frames_equal_the_three_kernel_route(order, switch):
     """A frame of CTCPrefixSearch with the n-gram model in the loop as ONE kernel
     (csrc/ctc_lm_step.hip: scores, mix, lists, prefix step) against the route through
     lookup_lm_log_probs -> fusion_ext -> ctc_prefix_search_advance (PDT_CTC_LM_FUSED=0): the same
@@ -159,14 +159,14 @@ def test_one_kernel_frames_equal_the_three_kernel_route(order, monkeypatch):
         lens = rng.integers(0, T + 1, N)
         search = M.CTCPrefixSearch(W, beta, lm, valid_mixture=vm)
         for ln in (None, torch.from_numpy(lens).to(DEV)):
-            monkeypatch.setenv("PDT_CTC_LM_FUSED", "0")
+            switch("PDT_CTC_LM_FUSED", "0")
             ey, eyl, eyp = search(_t(lg), ln)
-            monkeypatch.setenv("PDT_CTC_LM_FUSED", "1")
+            switch("PDT_CTC_LM_FUSED", "1")
             assert search._fuses_lookup_lm(_t(lg))
             # one kernel per frame launched by the host loop, then every frame from one call of the
             # library (histories in slots instead of copied from frame to frame)
             for whole in ("0", "1"):
-                monkeypatch.setenv("PDT_CTC_LM_SEARCH", whole)
+                switch("PDT_CTC_LM_SEARCH", whole)
                 y, yl, yp = search(_t(lg), ln)
                 what = (order, V, W, vm, ln is None, whole)
                 assert torch.isfinite(eyp[:, 0]).all(), what
@@ -189,7 +189,7 @@ def test_beam_search_with_lookup_lm():
 
 
 @pytest.mark.parametrize("sos", [-1, 0, 3])
-def test_beam_search_reads_a_bigram_models_table(sos, monkeypatch):
+def test_beam_search_reads_a_bigram_models_table(sos, switch):
     """BeamSearch over a bigram LookupLanguageModel reads its prefixes' scores (and their log-softmax
     statistics) from the model's dense (context, token) table, built once, instead of having the model
     write (N K, V) scores every iteration: the same paths, lengths and log-probabilities -- to the bit --
@@ -204,20 +204,20 @@ def test_beam_search_reads_a_bigram_models_table(sos, monkeypatch):
         search = M.BeamSearch(lm, W, eos=eos).to(DEV)
         outs = []
         for fused, table in (("1", "1"), ("1", "0"), ("0", "0")):
-            monkeypatch.setenv("PDT_BEAM_FUSED", fused)
-            monkeypatch.setenv("PDT_BEAM_TABLE", table)
+            switch("PDT_BEAM_FUSED", fused)
+            switch("PDT_BEAM_TABLE", table)
             outs.append(search(dict(), batch_size=N, max_iters=iters))
         (y, yl, lp), (y1, yl1, lp1), (y2, yl2, lp2) = outs
         what = (sos, V, W, N, eos)
         assert y.shape == y1.shape and torch.equal(y, y1) and torch.equal(yl, yl1) and torch.equal(lp, lp1), what
         assert torch.equal(yl, yl2) and torch.allclose(lp, lp2, rtol=1e-5, atol=1e-6), what
-        monkeypatch.setenv("PDT_BEAM_FUSED", "1")
-        monkeypatch.setenv("PDT_BEAM_TABLE", "1")
+        switch("PDT_BEAM_FUSED", "1")
+        switch("PDT_BEAM_TABLE", "1")
         assert search._bigram_table(search.device_buffer.device) is not None
         with torch.no_grad():
             lm.logps.add_(0.25 * torch.randn_like(lm.logps))  # (version counter moves: the table is rebuilt)
         ya, yla, lpa = search(dict(), batch_size=N, max_iters=iters)
-        monkeypatch.setenv("PDT_BEAM_TABLE", "0")
+        switch("PDT_BEAM_TABLE", "0")
         yb, ylb, lpb = search(dict(), batch_size=N, max_iters=iters)
         assert torch.equal(ya, yb) and torch.equal(yla, ylb) and torch.equal(lpa, lpb), what
 

@@ -3,6 +3,7 @@
 Bit-exact comparison (float32 ``==``) on seeded random inputs at sizes the oracle
 finishes in seconds; the structure follows the reference's tests/test_string.py.
 """
+import contextlib
 import warnings
 import zlib
 
@@ -404,7 +405,7 @@ def test_optimal_completion_shape_sweep(device):
 
 
 @pytest.mark.parametrize("R", [1, 2, 31, 32, 33, 63, 64, 65, 200, 480, 511, 512])
-def test_optimal_completion_bit_parallel_rows(device, R, monkeypatch):
+def test_optimal_completion_bit_parallel_rows(device, R, switch):
     """Uniform costs and references of up to 512 tokens take the bit-parallel mask kernel
     (csrc/lev_bitpar.hip, oc_bitpar_kernel): one case per number of 32-column blocks in use, ragged
     lengths on both sides (eos anywhere, including position 0), vocabularies from two tokens (every
@@ -424,9 +425,9 @@ def test_optimal_completion_bit_parallel_rows(device, R, monkeypatch):
                    dict(batch_first=True, ins_cost=2.5, del_cost=2.5, sub_cost=2.5)):
             a, b = (ref.T.copy(), hyp.T.copy()) if kw.get("batch_first") else (ref, hyp)
             ta, tb = torch.from_numpy(a).to(device), torch.from_numpy(b).to(device)
-            monkeypatch.setenv("PDT_OC_BITPAR", "1")
+            switch("PDT_OC_BITPAR", "1")
             act = F.optimal_completion(ta, tb, warn=False, **kw)
-            monkeypatch.setenv("PDT_OC_BITPAR", "0")
+            switch("PDT_OC_BITPAR", "0")
             row = F.optimal_completion(ta, tb, warn=False, **kw)
             assert act.shape == row.shape and torch.equal(act, row), (R, H, N, V, kw)
             if R * H * N <= 40000:
@@ -523,10 +524,11 @@ def test_lev_workspace_is_optional(device):
 
 
 def test_classification_is_reused_only_for_the_same_inputs(device):
-    """error_rate followed by prefix_error_rates on one (ref, hyp) pair classifies once
-    (pdt_lev_classified through the host's one-entry cache).  The entry must not outlive its inputs'
-    CONTENTS: in-place edits, other eos handling, other tensors at recycled addresses, another
-    stream -- every call against the oracle; warnings repeat with the cached bits."""
+    """Inside `reuse_classification()` error_rate followed by prefix_error_rates on one (ref, hyp) pair
+    classifies once (pdt_lev_classified through the host's one-entry, one-hit cache).  The entry must
+    not outlive its inputs' CONTENTS as far as the version counter sees them: in-place edits, other
+    eos handling, other tensors at recycled addresses, another stream -- every call against the
+    oracle; warnings repeat with the cached bits.  Leaving the block drops the entry."""
     import warnings
 
     from pydrobert_amd import _string
@@ -544,31 +546,81 @@ def test_classification_is_reused_only_for_the_same_inputs(device):
 
     tr = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
     th = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
-    check(tr, th, eos=4, include_eos=True)
-    assert _string._CLASSIFIED[device.index][0][0] == tr.data_ptr()  # an entry stands
-    check(tr, th, eos=4, include_eos=False)  # other length rule: not the cached tables
-    th[3] = (th[3] + 1) % V  # in-place edit: same address, new version
-    check(tr, th, eos=4, include_eos=False)
-    tr.add_(1).remainder_(V)
-    check(tr, th, eos=4, include_eos=False)
-    for _ in range(6):  # fresh tensors, freed every round: the allocator recycles their addresses
-        a = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
-        b = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
-        check(a, b, eos=None)
-        del a, b
-    side = torch.cuda.Stream(device)
-    with torch.cuda.stream(side):
+    with _string.reuse_classification():
+        F.error_rate(tr, th, eos=4, include_eos=True, warn=False)
+        assert _string._CLASSIFIED[device.index][0][0] == tr.data_ptr()  # an entry stands ...
+        F.prefix_error_rates(tr, th, eos=4, include_eos=True, warn=False)
+        assert device.index not in _string._CLASSIFIED  # ... for one hit
+        check(tr, th, eos=4, include_eos=True)
+        check(tr, th, eos=4, include_eos=False)  # other length rule: not the cached tables
+        th[3] = (th[3] + 1) % V  # in-place edit: same address, new version
+        check(tr, th, eos=4, include_eos=False)
+        tr.add_(1).remainder_(V)
+        check(tr, th, eos=4, include_eos=False)
+        for _ in range(6):  # fresh tensors, freed every round: the allocator recycles their addresses
+            a = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
+            b = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
+            check(a, b, eos=None)
+            del a, b
+        side = torch.cuda.Stream(device)
+        with torch.cuda.stream(side):
+            check(tr, th, eos=2, include_eos=True)
+        side.synchronize()
         check(tr, th, eos=2, include_eos=True)
-    side.synchronize()
-    check(tr, th, eos=2, include_eos=True)
-    # warnings: the second call of a pair reports what the classifying call found
-    nr = torch.full((R, N), 1, device=device)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        F.error_rate(nr, th, eos=4, include_eos=True, norm=True)
-        n1 = len(w)
-        F.prefix_error_rates(nr, th, eos=4, include_eos=True, norm=True)
-    assert n1 >= 1 and len(w) == 2 * n1, [str(x.message)[:40] for x in w]
+        # warnings: the second call of a pair reports what the classifying call found
+        nr = torch.full((R, N), 1, device=device)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            F.error_rate(nr, th, eos=4, include_eos=True, norm=True)
+            n1 = len(w)
+            F.prefix_error_rates(nr, th, eos=4, include_eos=True, norm=True)
+        assert n1 >= 1 and len(w) == 2 * n1, [str(x.message)[:40] for x in w]
+        F.error_rate(tr, th, warn=False)
+    assert not _string._CLASSIFIED  # nothing stays pinned outside the block
+
+
+def test_no_reuse_by_default_and_writes_behind_the_version_counter(device):
+    """By default every string operator classifies its own inputs: nothing is kept between calls, so a
+    write the version counter does not see (`.data.copy_`) between error_rate and prefix_error_rates
+    cannot serve stale tables."""
+    from pydrobert_amd import _string, switches
+
+    assert switches.get("PDT_LEV_CACHE") == 0
+    rng = np.random.default_rng(5)
+    R, H, N, V = 90, 80, 7, 6
+    tr = torch.from_numpy(rng.integers(0, V, (R, N))).to(device)
+    th = torch.from_numpy(rng.integers(0, V, (H, N))).to(device)
+    F.error_rate(tr, th, warn=False)
+    assert not _string._CLASSIFIED
+    v0 = th._version
+    th.data.copy_(torch.from_numpy(rng.integers(0, V, (H, N))).to(device))
+    assert th._version == v0  # the hazard: contents changed, identity did not
+    act = F.prefix_error_rates(tr, th, warn=False).cpu().numpy()
+    assert np.array_equal(act, oracle.prefix_error_rates(tr.cpu().numpy(), th.cpu().numpy()))
+
+
+def test_string_operators_on_inference_tensors(device):
+    """ref / hyp created under torch.inference_mode() (the usual evaluation set-up) carry no version
+    counter; every operator runs on them, with and without the opt-in reuse."""
+    from pydrobert_amd import _string
+
+    rng = np.random.default_rng(8)
+    R, H, N, V = 60, 55, 6, 7
+    r, h = rng.integers(0, V, (R, N)), rng.integers(0, V, (H, N))
+    for reuse in (False, True):
+        with torch.inference_mode():
+            tr, th = torch.from_numpy(r).to(device), torch.from_numpy(h).to(device)
+            assert tr.is_inference()
+            ctx = _string.reuse_classification() if reuse else contextlib.nullcontext()
+            with ctx:
+                for name in ("error_rate", "prefix_error_rates", "edit_distance", "prefix_edit_distances",
+                             "optimal_completion"):
+                    act = getattr(F, name)(tr, th, eos=V - 1, warn=False).cpu().numpy()
+                    exp = getattr(oracle, name)(r, h, eos=V - 1)
+                    assert act.shape == exp.shape and np.array_equal(act, exp), (name, reuse)
+                hs = torch.from_numpy(rng.integers(0, V, (H, N, 3))).to(device)
+                loss = F.minimum_error_rate_loss(torch.randn(N, 3, device=device), tr, hs, eos=V - 1, warn=False)
+                assert torch.isfinite(loss)
 
 
 def test_bitpar_empty_sequences(device):
