@@ -116,6 +116,9 @@ struct FrameLds {
   int list_len;
   float *hdr;
   int2 *trie_u = nullptr;  // trie form: this utterance's records, trie + n * T * W (wave-uniform)
+  // ROWLESS form (ctc_rowreg.hip: the row never leaves the producer's registers): the two
+  // probabilities a frame reads besides the list -- this lane's last token's and the blank's
+  float pl_in = 0.0f, pblank_in = 0.0f;
   static __host__ __device__ size_t bytes(int V, int W, int Kp, bool dense) {
     const int RS = W > Kp ? W : Kp;
     size_t b = (size_t)PDT_SURV_CAP * 8 + (size_t)(dense ? Kp : 1) * PDT_WAVE * 8;
@@ -177,7 +180,9 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 
 // Returns whether the list as handed over was enough (false: this wave had to complete a short
 // list -- the search kernel's producers send short lists only while that stays rare).
-template <bool DENSE>
+// ROWLESS (shared-list form only): there is no row `p` to read -- the list is complete (M entries)
+// and FrameLds::pl_in / pblank_in carry the two other probabilities of the frame.
+template <bool DENSE, bool ROWLESS = false>
 __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float inv, const int V,
                                           const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
@@ -211,9 +216,10 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   const int *mt = L.tl_tok + (DENSE ? me : 0) * PDT_WAVE;
 
   // ---- candidate masses that do not depend on the token (:777-794) ----------------------
-  const float p_blank = p[V] * inv;
+  static_assert(!(DENSE && ROWLESS), "the row-less form reads the shared list");
+  const float p_blank = ROWLESS ? L.pblank_in : p[V] * inv;
   const int lastc = min(max(bm.last, 0), V - 1);
-  const float pl = p[lastc] * inv;  // non-extension probability of my last token
+  const float pl = ROWLESS ? L.pl_in : p[lastc] * inv;  // non-extension probability of my last token
   const float e_last = DENSE ? (dc.etab ? dc.etab[me * dc.etab_stride + me] : dc.ext[me * dc.ext_sk + lastc * dc.ext_sv]) : pl;
   const float tot = bm.nb + bm.b;
   const float B = tot * p_blank;
@@ -227,8 +233,8 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // (:804-837); only prefixes that have descendants in the beam are visited.
   // `c` = entries the list holds.  Run once per frame, and a second time (accumulate = false:
   // the masses are already in `add`) if a short list had to be completed.
-  const int c_list = DENSE ? M : min(L.list_len, M);
-  const bool full_list = DENSE || c_list >= M;
+  const int c_list = (DENSE || ROWLESS) ? M : min(L.list_len, M);
+  const bool full_list = DENSE || ROWLESS || c_list >= M;
   int jl = -1;
   u64 avail = 0ull;
   bool s1_open = valid_beam, s2_open = valid_beam;
@@ -645,6 +651,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   return bound_won;
   };
   if (full_tiers(full_list)) {
+    if constexpr (!ROWLESS) {
     list_sufficed = false;
     // complete the list here (the short list is a prefix of the complete one, so the entries
     // already indexed stay valid), redo the bookkeeping that depends on list positions, and
@@ -658,6 +665,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     new_src = 0, new_tok = 0, new_kind = -1;
     new_mass = -PDT_INF;
     full_tiers(true);
+    }
   }
   }
   PDT_STAMP(3);

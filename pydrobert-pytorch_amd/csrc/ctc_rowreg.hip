@@ -1,0 +1,375 @@
+// CTC prefix beam search over LONG rows (513 .. 5120 elements): the row of a frame never leaves
+// the registers of the producer wave that read it.
+//
+// Replaces CTCPrefixSearch.forward without a language model (reference _decoding.py:1064-1202;
+// the softmax of :1093-1095 and the per-frame step :1110-1152) for vocabularies where the form of
+// ctc_search.hip -- whole rows of probabilities in an LDS ring -- leaves room for two utterances
+// per CU (V = 5000: 3 slots x 25 KB): there the bytes in flight are capped by the residency, not by
+// the loads (0.22 of the HBM rate).  What the consumer reads of a frame is small -- the sorted list
+// of the K + K' best tokens, the blank's probability, and the probabilities of its prefixes' last
+// tokens -- so here
+//   * a producer wave loads the whole row into registers (NR x 64 elements, every load in flight at
+//     once), takes maximum, exponentials and sum from them, selects the list from them (threshold =
+//     M-th largest per-lane maximum, survivors compacted through LDS, one sort), and hands over
+//     ONLY the list + a header (reciprocal normaliser, row maximum, the blank's numerator): 0.5 KB
+//     per frame instead of the row.  Same arithmetic in the same order as the other forms (per-lane
+//     strided sums, then the DPP reduction): identical bits;
+//   * the consumer wave (the frame routine of ctc_frame.hpp, ROWLESS) indexes the list in its own
+//     token -> position table (V bytes of LDS, set and cleared per frame), and fetches the logit of
+//     each prefix's last token itself -- one scattered load per frame, issued as soon as the frame
+//     before has decided the prefixes, turned into a probability with the header's maximum and
+//     reciprocal (a token on the list reads its probability there).
+// An utterance takes ~11 KB of LDS at V = 5000, so the residency is set by the registers: 128 per
+// lane (80 of them the row) = four waves per SIMD, every CU holding four utterances x (three
+// producers + consumer).
+#include "ctc_ring.hpp"
+#include "switches.hpp"
+
+namespace pdt {
+
+struct RowregLayout {
+  int nstage;      // ring slots per utterance
+  int slot_bytes;  // [64 tokens | 64 probabilities | header: 1/sum, row max, list length, blank, sum]
+  int pos_bytes;   // V padded to 16: token -> list position (0xFF: not listed), owned by the consumer
+  int utt_bytes;   // ring + pos + consumer scratch + one survivor buffer per producer + flags
+  int utt_per_wg, producers;
+};
+
+__host__ __device__ inline RowregLayout rowreg_layout(int V, int W, int nstage, int utt_per_wg, int producers) {
+  RowregLayout r;
+  r.nstage = nstage;
+  r.slot_bytes = PDT_WAVE * 8 + 32;
+  r.pos_bytes = (V + 15) & ~15;
+  const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
+  r.utt_bytes = (r.slot_bytes * nstage + r.pos_bytes + consumer + producers * PDT_SURV_CAP * 8 + 32 + 15) & ~15;
+  r.utt_per_wg = utt_per_wg;
+  r.producers = producers;
+  return r;
+}
+
+// NR: 64-element chunks of a row the producer's registers hold (V + 1 <= 64 * NR); P producers per
+// utterance take the frames t = p, p + P, ... in turn.  A workgroup is four waves: one utterance with
+// three producers, or two with one each.
+template <int NR, int P>
+__global__ void __launch_bounds__(256, NR <= 16 ? 8 : (NR <= 32 ? 6 : (NR <= 48 ? 5 : 4)))
+ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int u = wave / (P + 1);
+  const int role = wave - u * (P + 1);  // 0 .. P-1: producer, P: consumer
+  const bool producer = role < P;
+  const int64_t n_raw = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
+  const bool idle = u >= rl.utt_per_wg || n_raw >= a.N;
+  const int64_t n = idle ? 0 : n_raw;
+  const int V = a.V, W = a.W, NS = rl.nstage;
+  unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
+  unsigned char *ring = ub;
+  unsigned char *pos = ub + (size_t)rl.slot_bytes * NS;
+  unsigned char *cs = pos + rl.pos_bytes;  // consumer scratch
+  u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
+  int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
+  int *ready = consumed + 1;                                          // [nstage <= 4] frame + 1 held by a slot
+  auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(ring + (size_t)sl * rl.slot_bytes); };
+  auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
+  auto slot_hdr = [&](int sl) { return slot_p(sl) + PDT_WAVE; };
+  const int Tn = min(a.S, a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T);
+
+  if (!producer && !idle) {
+    for (int v = lane; v < rl.pos_bytes; v += PDT_WAVE) pos[v] = 0xFF;
+    if (lane <= 4) __hip_atomic_store(&consumed[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  __syncthreads();  // flags / position table initialised (the only workgroup barrier)
+  if (idle) return;
+
+  if (producer) {
+    const int pr = role;
+    u64 *surv = surv0 + pr * PDT_SURV_CAP;
+    const int nt_ = V >> 6, rem_ = V & 63;  // full token chunks; lane of the blank in the chunk after them
+    // the row: logits, then the ordering keys of their numerators.  r[i], i < nt: token chunks with
+    // every lane in use; rt: the chunk that ends with the blank (lanes 0 .. rem; tokens below rem)
+    unsigned r[NR], rt = 0u;
+    auto load_row = [&](int t, const int nt, const bool in_row) {
+      // (rows are contiguous here -- the launcher sends strided logits to the LDS form -- so a
+      // chunk is base + lane * 4 + an immediate)
+      int lq = lane;
+      asm volatile("" : "+v"(lq));
+      const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn + lq;
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i < nt) r[i] = __float_as_uint(row[i * PDT_WAVE]);
+      if (in_row) rt = __float_as_uint(row[nt * PDT_WAVE]);
+    };
+    if (pr < Tn) load_row(pr, nt_, lane <= rem_);
+    int sl = pr % NS;
+    for (int t = pr; t < Tn; t += P, sl = sl + P >= NS ? sl + P - NS : sl + P) {
+      // (laundered: nothing derived from the lane index or the chunk count is loop-invariant to the
+      // compiler -- hoisted, the per-chunk predicates and index words are NR live values that spill)
+      int lp = lane, nt = nt_, rem = rem_;
+      asm volatile("" : "+v"(lp), "+s"(nt), "+s"(rem));
+      const bool in_row = lp <= rem, is_tok = lp < rem;
+      // ---- softmax statistics (:1093): e[v] = exp(x[v] - max), sum over v in [0, V] ---------
+      float mx = in_row ? __uint_as_float(rt) : -PDT_INF;
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i < nt) mx = fmax_raw(mx, __uint_as_float(r[i]));
+      mx = wave_max_f(mx);
+      float s = 0.0f;
+      unsigned lmax = 0u;  // per-lane maximum key over the tokens (not the blank)
+#pragma unroll
+      for (int i = 0; i < NR; i += 2) {
+        if (i + 1 < nt) {  // two full chunks: the range reduction in packed fp32, same bits
+          const f32x2 e2 = exp_nonpos2(f32x2{__uint_as_float(r[i]), __uint_as_float(r[i + 1])} - f32x2{mx, mx});
+          s += e2.x;
+          r[i] = fkey_nonneg(e2.x);
+          lmax = max(lmax, r[i]);
+          s += e2.y;
+          r[i + 1] = fkey_nonneg(e2.y);
+          lmax = max(lmax, r[i + 1]);
+        } else if (i < nt) {
+          const float e = exp_nonpos(__uint_as_float(r[i]) - mx);
+          s += e;
+          r[i] = fkey_nonneg(e);
+          lmax = max(lmax, r[i]);
+        }
+      }
+      float eb = 0.0f;
+      {  // the chunk with the blank (last in the lane's sum, as in the other forms)
+        float e = 0.0f;
+        unsigned key = 0u;
+        if (in_row) {
+          e = exp_nonpos(__uint_as_float(rt) - mx);
+          s += e;
+          if (is_tok) key = fkey_nonneg(e);
+        }
+        rt = key;  // (the blank is no token: never on the list; lanes beyond it hold nothing)
+        lmax = max(lmax, key);
+        eb = readlane_f(e, rem);
+      }
+      s = wave_sum_f(s);
+      const float inv0 = __builtin_amdgcn_rcpf(s);
+      const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+      // ---- the sorted list of the M best tokens, from the registers --------------------------
+      // (wave_top_sorted_strided's selection: same threshold, same survivors, same order)
+      const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
+      const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
+      const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+      int count = 0;
+      auto survivors = [&](const unsigned key, const int v) {
+        const bool pred = key >= tau;  // (tau >= 1: every lane holds a token; absent elements are 0)
+        const u64 bal = __ballot(pred);
+        if (bal) {
+          const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+          if (pred && at < PDT_SURV_CAP) surv[at] = pack_key(key, (unsigned)v);
+          count += __popcll(bal);
+        }
+      };
+#pragma unroll
+      for (int i = 0; i < NR; ++i)
+        if (i < nt) survivors(r[i], lp + i * PDT_WAVE);
+      survivors(rt, lp + nt * PDT_WAVE);
+      u64 tk = 0ull;
+      if (count > PDT_SURV_CAP) {
+        // heavy ties / clustered values: chunked top-64 merge.  Rare, and a register file cannot be
+        // indexed by a loop counter: the row is read again (L2) and its numerators formed again --
+        // the same routine on the same inputs, the same bits
+        const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+        for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
+          const int v = v0 + lp;
+          const unsigned key = v < V ? fkey_nonneg(exp_nonpos(row[(int64_t)v * a.lg_sv] - mx)) : 0u;
+          const bool pred = key >= tau;
+          if (__ballot(pred)) tk = wave_merge_top64(tk, pred ? pack_key(key, (unsigned)v) : 0ull);
+        }
+      }
+      // the registers are free: the next row of this wave is on its way while the list is sorted
+      // and handed over
+      if (t + P < Tn) load_row(t + P, nt, in_row);
+      wave_sync();
+      if (count <= PDT_SURV_CAP) tk = wave_sort_desc<u64>(lp < count ? surv[lp] : 0ull);
+      // wait for the slot to be free: at most NS frames in flight
+      while (t - __hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
+        __builtin_amdgcn_s_sleep(2);
+      if (lp < M) {
+        const float e = fkey_nonneg_inv(key_of(tk));
+        slot_tok(sl)[lp] = (int)idx_of(tk);
+        slot_p(sl)[lp] = a.exact_div ? e / s : e * inv;
+      }
+      if (lp == 0) {
+        float *hdr = slot_hdr(sl);
+        hdr[0] = inv;
+        hdr[1] = mx;
+        hdr[2] = a.exact_div ? eb / s : eb * inv;
+        hdr[3] = s;
+      }
+      wave_sync();
+      if (lp == 0) __hip_atomic_store(&ready[sl], t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return;
+  }
+
+  // ---- consumer: the sequential beam update --------------------------------------------------
+  __builtin_amdgcn_s_setprio(PDT_CONSUMER_PRIO);
+  FrameLds L;
+  L.surv = surv0;  // unused by the shared-list form
+  L.trie_u = a.trie + (int64_t)n * a.T * W;
+  L.nxt_old = reinterpret_cast<int *>(cs);
+  L.nxt_new = L.nxt_old + nxt_stride(W);
+  L.chm = reinterpret_cast<unsigned *>(L.nxt_new + nxt_stride(W));
+  L.info = reinterpret_cast<int *>(L.chm + W);
+  L.pos = pos;
+  Beam bm;  // :1097-1105: one empty prefix with all the mass on "ends in blank"
+  bm.nb = lane == 0 ? 0.0f : -PDT_INF;
+  bm.b = lane == 0 ? 1.0f : -PDT_INF;
+  bm.last = 0;
+  bm.len = 0;
+  bm.node = -1;
+  bm.isp = lane == 0 ? 1u : 0u;
+  bm.origin = lane;
+  int Kp = 1;
+  const float *lg_n = a.logits + n * a.lg_sn;
+  // the logit of every prefix's last token in the coming frame (lanes beyond the beam read token 0)
+  float xg = Tn > 0 ? lg_n[0] : 0.0f;
+  int sl = 0;
+  for (int t = 0; t < Tn; ++t, sl = sl + 1 == NS ? 0 : sl + 1) {
+    if (__hip_atomic_load(&ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t) {
+      __builtin_amdgcn_s_setprio(0);
+      do {
+        __builtin_amdgcn_s_sleep(PDT_SPIN_SLEEP);
+      } while (__hip_atomic_load(&ready[sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t);
+      __builtin_amdgcn_s_setprio(PDT_CONSUMER_PRIO);
+    }
+    const int M = ctc_list_len(V, W, Kp);
+    L.tl_tok = slot_tok(sl);
+    L.tl_p = slot_p(sl);
+    L.hdr = slot_hdr(sl);
+    L.list_len = M;
+    int ns, nt_, nk;
+    // every mass has underflowed to 0: nothing is left to decide (see ctc_search.hip)
+    if (!(readlane_f(bm.nb + bm.b, 0) == 0.0f)) {
+      int lane_l = lane;
+      asm volatile("" : "+v"(lane_l));
+      const int tok_l = lane_l < M ? L.tl_tok[lane_l] : 0;
+      if (lane_l < M) pos[tok_l] = (unsigned char)lane_l;
+      const float inv = L.hdr[0], mx = L.hdr[1], s = L.hdr[3];
+      L.pblank_in = L.hdr[2];
+      wave_sync();
+      const int lastc = min(max(bm.last, 0), V - 1);
+      const unsigned q = pos[lastc];
+      const float e = exp_nonpos(xg - mx);
+      const float pl_row = a.exact_div ? e / s : e * inv;
+      L.pl_in = q == 0xFFu ? pl_row : L.tl_p[q & 63u];
+      ctc_frame<false, true>(bm, nullptr, inv, V, W, Kp, t, n, a, DenseCtx{}, L, ns, nt_, nk PDT_STAMP_ARG);
+      if (lane_l < M) pos[tok_l] = 0xFF;  // (ordered behind the frame's reads by its closing wave_sync)
+      int *tmp = L.nxt_old;
+      L.nxt_old = L.nxt_new;
+      L.nxt_new = tmp;
+      Kp = W;
+    }
+    if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (t + 1 < Tn)
+      xg = lg_n[(int64_t)(t + 1) * a.lg_st + (int64_t)min(max(bm.last, 0), V - 1) * a.lg_sv];
+    if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
+      const int c = ((t + 1) >> a.ckpt_shift) - 1;
+      if (lane < W)
+        a.ckpt[((int64_t)n * a.ckpt_count + c) * W + lane] = make_int2(bm.node, bm.len | (bm.origin << 24));
+      bm.origin = lane;
+    }
+  }
+
+  // ---- outputs (:1188-1200): probabilities, lengths, and the prefixes read off the trie ------
+  if (lane < W) {
+    a.y_probs[n * W + lane] = bm.nb + bm.b;
+    a.y_lens[n * W + lane] = bm.len;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  {
+    // the walk of ctc_search.hip: checkpoint table in the freed ring + position table
+    const int C = Tn >> a.ckpt_shift;
+    int2 *tab = reinterpret_cast<int2 *>(ub);  // [(C + 1) x W]: fits, see launch_ctc_rowreg
+    wave_sync();
+    if (lane < W) {
+      const bool ok = bm.node >= 0;
+      tab[C * W + lane] = make_int2(bm.node, bm.len);
+      int cur = bm.origin;
+      for (int c = C - 1; c >= 0; --c) {
+        const int2 *rec = a.ckpt + (((int64_t)n * a.ckpt_count + c) * W + cur);
+        const int nd = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lo = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tab[c * W + lane] = ok ? make_int2(nd, lo & 0xFFFFFF) : make_int2(-1, 0);
+        cur = lo >> 24;
+      }
+    }
+    wave_sync();
+    for (int sg = lane; sg < (C + 1) * W; sg += PDT_WAVE) {
+      const int c = sg / W, k = sg - c * W;
+      const int2 top = tab[sg];
+      const int stop = c > 0 ? tab[sg - W].y : 0;
+      int node = top.x;
+      for (int ps = top.y - 1; ps >= stop && node >= 0; --ps) {
+        const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
+        const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.y[((int64_t)ps * a.N + n) * W + k] = tok;
+        node = par;
+      }
+    }
+    int lmin = lane < W ? bm.len : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) lmin = min(lmin, shfl_i(lmin, lane ^ off));
+    for (int f = lmin * W + lane; f < a.S * W; f += PDT_WAVE) {
+      const int ps = f / W, k = f - ps * W;
+      if (ps >= tab[C * W + k].y) a.y[((int64_t)ps * a.N + n) * W + k] = 0;
+    }
+  }
+}
+
+// rows of 513 .. 5120 elements, beams the one-kernel search holds; PDT_CTC_ROWREG=0 keeps the LDS
+// rows of ctc_search.hip (comparisons), =2 the one-producer form (two utterances per workgroup)
+bool ctc_rowreg_applies(int V, int W) {
+  const int mode = switches().ctc_rowreg;
+  return mode != 0 && W >= 1 && W <= kMaxWidth && V + 1 > 8 * PDT_WAVE && V / PDT_WAVE <= 80;
+}
+
+RowregLayout plan_ctc_rowreg(int V, int W) {
+  if (switches().ctc_rowreg == 2) return rowreg_layout(V, W, 4, 2, 1);
+  return rowreg_layout(V, W, 4, 1, 3);
+}
+
+void ctc_rowreg_plan4(int V, int W, int32_t *plan4) {
+  const RowregLayout rl = plan_ctc_rowreg(V, W);
+  plan4[0] = rl.producers; plan4[1] = rl.nstage; plan4[2] = rl.utt_per_wg; plan4[3] = 3;
+}
+
+template <int NR, int P>
+static int launch_rowreg(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
+  const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_rowreg_kernel<NR, P>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
+  hipLaunchKernelGGL((ctc_rowreg_kernel<NR, P>), dim3(grid), dim3(256), smem, stream, a, rl);
+  return (int)hipGetLastError();
+}
+
+template <int P>
+static int launch_rowreg_nr(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
+  const int chunks = a.V / PDT_WAVE;  // full token chunks; the chunk with the blank has a register of its own
+  if (chunks <= 16) return launch_rowreg<16, P>(a, rl, stream);
+  if (chunks <= 32) return launch_rowreg<32, P>(a, rl, stream);
+  if (chunks <= 48) return launch_rowreg<48, P>(a, rl, stream);
+  return launch_rowreg<80, P>(a, rl, stream);
+}
+
+int launch_ctc_rowreg(CtcArgs a, hipStream_t stream) {
+  const RowregLayout rl = plan_ctc_rowreg(a.V, a.W);
+  // checkpoint spacing: the (C + 1) x W table of the output walk overlays the ring and the position table
+  const size_t room = (size_t)rl.slot_bytes * rl.nstage + rl.pos_bytes;
+  int sh = 5;
+  while (((size_t)(a.T >> sh) + 1) * a.W * sizeof(int2) > room) ++sh;
+  a.ckpt_shift = sh;
+  a.ckpt_count = (a.T >> sh) + 1;
+  return rl.producers == 1 ? launch_rowreg_nr<1>(a, rl, stream) : launch_rowreg_nr<3>(a, rl, stream);
+}
+
+}  // namespace pdt

@@ -617,6 +617,11 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
   return *plan = CtcPlan{1, nstage, upw, 1}, PDT_OK;
 }
 
+// rows held in the producers' registers (ctc_rowreg.hip)
+bool ctc_rowreg_applies(int V, int W);
+void ctc_rowreg_plan4(int V, int W, int32_t *plan4);
+int launch_ctc_rowreg(CtcArgs a, hipStream_t stream);
+
 int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &rl, hipStream_t stream) {
   if (plan.inreg == 2) return launch_ctc_search_p<3, -1, false, true>(a, rl, stream);
   if (plan.producers == 3) return launch_ctc_search_p<3>(a, rl, stream);
@@ -652,6 +657,7 @@ int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4) {
   const int rc = pdt::plan_ctc_search((int)V, (int)width, &plan, &rl);
   if (rc != PDT_OK) return rc;
   plan4[0] = plan.producers; plan4[1] = plan.nstage; plan4[2] = plan.utt_per_wg; plan4[3] = plan.inreg;
+  if (pdt::ctc_rowreg_applies((int)V, (int)width)) pdt::ctc_rowreg_plan4((int)V, (int)width, plan4);  // (3: rows in registers)
   return PDT_OK;
 }
 
@@ -674,6 +680,8 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   a.ckpt = a.trie + T * N * width;
   a.grow = reinterpret_cast<unsigned char *>(workspace) + ctc_trie_bytes(T, N, width);
   a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
+  // (contiguous rows: the register form addresses a row as base + immediates)
+  if (ctc_rowreg_applies(a.V, a.W) && lg_sv == 1) return launch_ctc_rowreg(a, (hipStream_t)stream);
   CtcPlan plan;
   RingLayout rl;
   const int rc = plan_ctc_search(a.V, a.W, &plan, &rl);
