@@ -43,6 +43,12 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
   return r;
 }
 
+__device__ __forceinline__ float fmax3_raw(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // two at a time: the multiplies / fmas / adds of the range reduction as packed fp32 (one
 // instruction for both); identical arithmetic per element, so identical results
 typedef float f32x2 __attribute__((ext_vector_type(2)));

@@ -51,7 +51,7 @@ __host__ __device__ inline RowregLayout rowreg_layout(int V, int W, int nstage, 
 // utterance take the frames t = p, p + P, ... in turn.  A workgroup is four waves: one utterance with
 // three producers, or two with one each.
 template <int NR, int P>
-__global__ void __launch_bounds__(256, NR <= 16 ? 8 : (NR <= 32 ? 6 : (NR <= 48 ? 5 : 4)))
+__global__ void __launch_bounds__(256, NR <= 16 ? 8 : (NR <= 24 ? 7 : (NR <= 32 ? 6 : (NR <= 48 ? 5 : 4))))
 ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -86,21 +86,27 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
     const int pr = role;
     u64 *surv = surv0 + pr * PDT_SURV_CAP;
     const int nt_ = V >> 6, rem_ = V & 63;  // full token chunks; lane of the blank in the chunk after them
-    // the row: logits, then the ordering keys of their numerators.  r[i], i < nt: token chunks with
-    // every lane in use; rt: the chunk that ends with the blank (lanes 0 .. rem; tokens below rem)
-    unsigned r[NR], rt = 0u;
-    auto load_row = [&](int t, const int nt, const bool in_row) {
+    // chunks every row of this instantiation has: the launcher picks NR with NR - 8 < nt <= NR, so
+    // the first NR - 8 need no guard (a guard per chunk is a scalar branch and, worse, a merge of the
+    // two versions of everything the chunk touches)
+    constexpr int NF = NR > 8 ? NR - 8 : 0;
+    // the row's logits: r[i], i < nt: token chunks with every lane in use; rt: the chunk that ends
+    // with the blank (lanes 0 .. rem; tokens below rem)
+    float r[NR], rt = 0.0f;
+    auto row_of = [&](int t) {
       // (rows are contiguous here -- the launcher sends strided logits to the LDS form -- so a
       // chunk is base + lane * 4 + an immediate)
       int lq = lane;
       asm volatile("" : "+v"(lq));
-      const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn + lq;
+      return a.logits + (int64_t)t * a.lg_st + n * a.lg_sn + lq;
+    };
+    if (pr < Tn) {
+      const float *row = row_of(pr);
 #pragma unroll
       for (int i = 0; i < NR; ++i)
-        if (i < nt) r[i] = __float_as_uint(row[i * PDT_WAVE]);
-      if (in_row) rt = __float_as_uint(row[nt * PDT_WAVE]);
-    };
-    if (pr < Tn) load_row(pr, nt_, lane <= rem_);
+        if (i < NF || i < nt_) r[i] = row[i * PDT_WAVE];
+      if (lane <= rem_) rt = row[nt_ * PDT_WAVE];
+    }
     int sl = pr % NS;
     for (int t = pr; t < Tn; t += P, sl = sl + P >= NS ? sl + P - NS : sl + P) {
       // (laundered: nothing derived from the lane index or the chunk count is loop-invariant to the
@@ -108,84 +114,82 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       int lp = lane, nt = nt_, rem = rem_;
       asm volatile("" : "+v"(lp), "+s"(nt), "+s"(rem));
       const bool in_row = lp <= rem, is_tok = lp < rem;
-      // ---- softmax statistics (:1093): e[v] = exp(x[v] - max), sum over v in [0, V] ---------
-      float mx = in_row ? __uint_as_float(rt) : -PDT_INF;
-#pragma unroll
-      for (int i = 0; i < NR; ++i)
-        if (i < nt) mx = fmax_raw(mx, __uint_as_float(r[i]));
-      mx = wave_max_f(mx);
-      float s = 0.0f;
-      unsigned lmax = 0u;  // per-lane maximum key over the tokens (not the blank)
+      const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
+      // ---- pass A: per-lane maximum over the tokens; with the blank, the row maximum ---------
+      float lmx = is_tok ? rt : -PDT_INF;
 #pragma unroll
       for (int i = 0; i < NR; i += 2) {
-        if (i + 1 < nt) {  // two full chunks: the range reduction in packed fp32, same bits
-          const f32x2 e2 = exp_nonpos2(f32x2{__uint_as_float(r[i]), __uint_as_float(r[i + 1])} - f32x2{mx, mx});
-          s += e2.x;
-          r[i] = fkey_nonneg(e2.x);
-          lmax = max(lmax, r[i]);
-          s += e2.y;
-          r[i + 1] = fkey_nonneg(e2.y);
-          lmax = max(lmax, r[i + 1]);
-        } else if (i < nt) {
-          const float e = exp_nonpos(__uint_as_float(r[i]) - mx);
-          s += e;
-          r[i] = fkey_nonneg(e);
-          lmax = max(lmax, r[i]);
-        }
+        if (i + 1 < NF || i + 1 < nt) lmx = fmax3_raw(lmx, r[i], r[i + 1]);
+        else if (i < nt) lmx = fmax_raw(lmx, r[i]);
       }
-      float eb = 0.0f;
-      {  // the chunk with the blank (last in the lane's sum, as in the other forms)
-        float e = 0.0f;
-        unsigned key = 0u;
-        if (in_row) {
-          e = exp_nonpos(__uint_as_float(rt) - mx);
-          s += e;
-          if (is_tok) key = fkey_nonneg(e);
-        }
-        rt = key;  // (the blank is no token: never on the list; lanes beyond it hold nothing)
-        lmax = max(lmax, key);
-        eb = readlane_f(e, rem);
-      }
-      s = wave_sum_f(s);
-      const float inv0 = __builtin_amdgcn_rcpf(s);
-      const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
-      // ---- the sorted list of the M best tokens, from the registers --------------------------
-      // (wave_top_sorted_strided's selection: same threshold, same survivors, same order)
-      const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
-      const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
-      const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+      const float mx = wave_max_f(lp == rem ? fmax_raw(lmx, rt) : lmx);
+      // ---- pass B: the tokens that can be among the M best -----------------------------------
+      // The list is ordered by (numerator, token), and exp() is monotone: the M-th largest per-lane
+      // maximum LOGIT bounds the M-th best from below.  Survivors are taken a margin below it -- 2^-16
+      // in the logit is 128 ulps of the numerator, beyond anything rounding can reorder -- so every
+      // token whose numerator ties with or exceeds the M-th best is among them, and ranking the
+      // survivors by their numerators gives the list the other forms build from a row of numerators.
+      const unsigned sorted_max = wave_sort_desc<unsigned>(fkey(lmx));
+      const float tau_x = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1));
+      const float tq = tau_x - fmaxf(0x1p-16f, fabsf(tau_x) * 0x1p-20f);
       int count = 0;
-      auto survivors = [&](const unsigned key, const int v) {
-        const bool pred = key >= tau;  // (tau >= 1: every lane holds a token; absent elements are 0)
+      auto survivors = [&](const float x, const int v, const bool pred) {
         const u64 bal = __ballot(pred);
         if (bal) {
           const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (pred && at < PDT_SURV_CAP) surv[at] = pack_key(key, (unsigned)v);
+          if (pred && at < PDT_SURV_CAP) surv[at] = ((u64)__float_as_uint(x) << 32) | (unsigned)v;
           count += __popcll(bal);
         }
       };
 #pragma unroll
       for (int i = 0; i < NR; ++i)
-        if (i < nt) survivors(r[i], lp + i * PDT_WAVE);
-      survivors(rt, lp + nt * PDT_WAVE);
+        if (i < NF || i < nt) survivors(r[i], lp + i * PDT_WAVE, r[i] >= tq);
+      survivors(rt, lp + nt * PDT_WAVE, is_tok && rt >= tq);
+      // ---- pass C: softmax numerators and their sum (:1093), e[v] = exp(x[v] - max) ----------
+      // per-lane sums over v = lane, lane + 64, ... in order, then the DPP reduction: the other
+      // forms' arithmetic.  A chunk's register is free once its numerator is in the sum: the next
+      // row of this wave moves in behind it (the last rows of an utterance re-read their own).
+      const float *nrow = row_of(t + P < Tn ? t + P : t);
+      float s = 0.0f;
+#pragma unroll
+      for (int i = 0; i < NR; i += 2) {
+        if (i + 1 < NF || i + 1 < nt) {  // two chunks: the range reduction in packed fp32, same bits
+          const f32x2 e2 = exp_nonpos2(f32x2{r[i], r[i + 1]} - f32x2{mx, mx});
+          s += e2.x;
+          s += e2.y;
+          r[i] = nrow[i * PDT_WAVE];
+          r[i + 1] = nrow[(i + 1) * PDT_WAVE];
+        } else if (i < nt) {
+          s += exp_nonpos(r[i] - mx);
+          r[i] = nrow[i * PDT_WAVE];
+        }
+      }
+      const float et = in_row ? exp_nonpos(rt - mx) : 0.0f;  // (lanes beyond the blank add +0: no change)
+      s += et;
+      const float eb = readlane_f(et, rem);
+      if (in_row) rt = nrow[nt * PDT_WAVE];
+      s = wave_sum_f(s);
+      const float inv0 = __builtin_amdgcn_rcpf(s);
+      const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+      // ---- the sorted list: survivors ranked by (numerator key, token) -----------------------
+      wave_sync();
       u64 tk = 0ull;
-      if (count > PDT_SURV_CAP) {
+      if (count <= PDT_SURV_CAP) {
+        const u64 rec = lp < count ? surv[lp] : 0ull;
+        const unsigned key = fkey_nonneg(exp_nonpos(__uint_as_float((unsigned)(rec >> 32)) - mx));
+        tk = wave_sort_desc<u64>(lp < count ? pack_key(key, (unsigned)rec) : 0ull);
+      } else {
         // heavy ties / clustered values: chunked top-64 merge.  Rare, and a register file cannot be
-        // indexed by a loop counter: the row is read again (L2) and its numerators formed again --
-        // the same routine on the same inputs, the same bits
+        // indexed by a loop counter: the row is read again (L2)
         const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
         for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
           const int v = v0 + lp;
-          const unsigned key = v < V ? fkey_nonneg(exp_nonpos(row[(int64_t)v * a.lg_sv] - mx)) : 0u;
-          const bool pred = key >= tau;
-          if (__ballot(pred)) tk = wave_merge_top64(tk, pred ? pack_key(key, (unsigned)v) : 0ull);
+          const float x = v < V ? row[v] : -PDT_INF;
+          const bool pred = v < V && x >= tq;
+          if (__ballot(pred))
+            tk = wave_merge_top64(tk, pred ? pack_key(fkey_nonneg(exp_nonpos(x - mx)), (unsigned)v) : 0ull);
         }
       }
-      // the registers are free: the next row of this wave is on its way while the list is sorted
-      // and handed over
-      if (t + P < Tn) load_row(t + P, nt, in_row);
-      wave_sync();
-      if (count <= PDT_SURV_CAP) tk = wave_sort_desc<u64>(lp < count ? surv[lp] : 0ull);
       // wait for the slot to be free: at most NS frames in flight
       while (t - __hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
         __builtin_amdgcn_s_sleep(2);
@@ -323,16 +327,15 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
 }
 
 // rows of 513 .. 5120 elements, beams the one-kernel search holds; PDT_CTC_ROWREG=0 keeps the LDS
-// rows of ctc_search.hip (comparisons), =2 the one-producer form (two utterances per workgroup)
+// rows of ctc_search.hip (comparisons)
 bool ctc_rowreg_applies(int V, int W) {
   const int mode = switches().ctc_rowreg;
   return mode != 0 && W >= 1 && W <= kMaxWidth && V + 1 > 8 * PDT_WAVE && V / PDT_WAVE <= 80;
 }
 
-RowregLayout plan_ctc_rowreg(int V, int W) {
-  if (switches().ctc_rowreg == 2) return rowreg_layout(V, W, 4, 2, 1);
-  return rowreg_layout(V, W, 4, 1, 3);
-}
+// (one producer per utterance, two utterances per workgroup, was 35 % slower at V = 5000 and 2x at
+// V = 1000: a lone producer cannot keep a frame's latency off its consumer)
+RowregLayout plan_ctc_rowreg(int V, int W) { return rowreg_layout(V, W, 4, 1, 3); }
 
 void ctc_rowreg_plan4(int V, int W, int32_t *plan4) {
   const RowregLayout rl = plan_ctc_rowreg(V, W);
@@ -354,11 +357,20 @@ static int launch_rowreg(const CtcArgs &a, const RowregLayout &rl, hipStream_t s
 
 template <int P>
 static int launch_rowreg_nr(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
-  const int chunks = a.V / PDT_WAVE;  // full token chunks; the chunk with the blank has a register of its own
-  if (chunks <= 16) return launch_rowreg<16, P>(a, rl, stream);
-  if (chunks <= 32) return launch_rowreg<32, P>(a, rl, stream);
-  if (chunks <= 48) return launch_rowreg<48, P>(a, rl, stream);
-  return launch_rowreg<80, P>(a, rl, stream);
+  // full token chunks (the chunk with the blank has a register of its own), in steps of eight: the
+  // instantiation for NR serves NR - 8 < chunks <= NR
+  switch ((a.V / PDT_WAVE + 7) / 8) {
+    case 1: return launch_rowreg<8, P>(a, rl, stream);
+    case 2: return launch_rowreg<16, P>(a, rl, stream);
+    case 3: return launch_rowreg<24, P>(a, rl, stream);
+    case 4: return launch_rowreg<32, P>(a, rl, stream);
+    case 5: return launch_rowreg<40, P>(a, rl, stream);
+    case 6: return launch_rowreg<48, P>(a, rl, stream);
+    case 7: return launch_rowreg<56, P>(a, rl, stream);
+    case 8: return launch_rowreg<64, P>(a, rl, stream);
+    case 9: return launch_rowreg<72, P>(a, rl, stream);
+    default: return launch_rowreg<80, P>(a, rl, stream);
+  }
 }
 
 int launch_ctc_rowreg(CtcArgs a, hipStream_t stream) {
@@ -369,7 +381,7 @@ int launch_ctc_rowreg(CtcArgs a, hipStream_t stream) {
   while (((size_t)(a.T >> sh) + 1) * a.W * sizeof(int2) > room) ++sh;
   a.ckpt_shift = sh;
   a.ckpt_count = (a.T >> sh) + 1;
-  return rl.producers == 1 ? launch_rowreg_nr<1>(a, rl, stream) : launch_rowreg_nr<3>(a, rl, stream);
+  return launch_rowreg_nr<3>(a, rl, stream);
 }
 
 }  // namespace pdt
