@@ -450,9 +450,12 @@ def ctc_kernel_name(V, W):
     """The instantiation the library launches for this row length (include/pdt_amd.h)."""
     from pydrobert_amd import _cabi
 
-    plan = (ctypes.c_int32 * 4)()
+    plan = (ctypes.c_int32 * 5)()
     if _cabi.lib().pdt_ctc_prefix_search_plan(V, W, plan) != 0:
         return "pdt::ctc_search_kernel"
+    if plan[3] == 3:  # long rows held in the producers' registers (ctc_rowreg.hip)
+        nr = plan[4]
+        return "pdt::ctc_rowreg_kernel<{}, {}, {}>".format(nr, nr - (8 if nr <= 80 else 16 if nr <= 128 else 32), plan[0])
     nt = V // 64 if (plan[3] == 1 and V // 64 == 4) else -1
     return "pdt::ctc_search_kernel<{}, {}, {}, {}>".format(
         plan[0], nt, "true" if plan[3] == 1 else "false", "true" if plan[3] == 2 else "false")

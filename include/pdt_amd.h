@@ -176,16 +176,20 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *          (the prefix trie: one (parent, token) record per frame and beam entry, the
  *          checkpoints of the output walk and, for rows beyond the LDS, the rows of the ring).
  *   width <= 32 (wider beams: one pdt_ctc_prefix_search_advance per frame).  S must be at least min(T, max lens): frames beyond S are not decoded.
- *   Rows of up to about 10 000 tokens live in LDS (one row of probabilities per slot of a
- *   three-slot ring); longer ones stay in the workspace (L2-resident), any V below 2^30.
+ *   Rows of up to 511 tokens and of 512 .. 16 447 tokens (contiguous logits) are held in the
+ *   registers of the producer wave that reads them (ctc_search.hip / ctc_rowreg.hip); other rows
+ *   of up to about 10 000 tokens live in LDS (one row of probabilities per slot of a three-slot
+ *   ring); longer ones stay in the workspace (L2-resident), any V below 2^30.
  * pdt_ctc_prefix_search_plan (host only, no device work): the launch configuration the library
- *   picks for rows of V tokens and this width -- plan4 = {producer waves per utterance, ring
- *   slots, utterances per workgroup, where a row is held: 1 the producer's registers, 0 LDS,
- *   2 the workspace}.  Lets callers and tests see where the configurations change.
+ *   picks for rows of V tokens and this width -- plan5 = {producer waves per utterance, ring
+ *   slots, utterances per workgroup, where a row is held: 1 the producer's registers (short
+ *   rows), 3 the same for long rows (the ring then carries lists, not rows), 0 LDS, 2 the
+ *   workspace; for 3: 64-token register chunks of the instantiation, else 0}.  Lets callers and
+ *   tests see where the configurations change.
  * ------------------------------------------------------------------------------------- */
 int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t V, int64_t width);
 
-int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4);
+int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan5);
 
 int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st,
                           int64_t lg_sn, int64_t lg_sv, const int64_t *lens, int64_t width,

@@ -47,11 +47,18 @@ __host__ __device__ inline RowregLayout rowreg_layout(int V, int W, int nstage, 
   return r;
 }
 
-// NR: 64-element chunks of a row the producer's registers hold (V + 1 <= 64 * NR); P producers per
-// utterance take the frames t = p, p + P, ... in turn.  A workgroup is four waves: one utterance with
-// three producers, or two with one each.
-template <int NR, int P>
-__global__ void __launch_bounds__(256, NR <= 16 ? 8 : (NR <= 24 ? 7 : (NR <= 32 ? 6 : (NR <= 48 ? 5 : 4))))
+// waves per SIMD the registers of an instantiation allow (the row + ~36 working registers per lane)
+constexpr int rowreg_waves(int NR) {
+  return NR <= 16 ? 8 : NR <= 24 ? 7 : NR <= 32 ? 6 : NR <= 48 ? 5 : NR <= 80 ? 4 : NR <= 128 ? 3 : NR <= 208 ? 2 : 1;
+}
+
+// NR: 64-token chunks of a row the producer's registers hold; NF: how many of them every row of
+// this instantiation has (the launcher picks the instantiation with NF < V / 64 <= NR, so the first
+// NF need no guard -- a guard per chunk is a scalar branch and, worse, a merge of the two versions
+// of everything the chunk touches).  P producers per utterance take the frames t = p, p + P, ... in
+// turn; a workgroup is one utterance: three producers and the consumer.
+template <int NR, int NF, int P>
+__global__ void __launch_bounds__(256, rowreg_waves(NR))
 ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
@@ -86,10 +93,6 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
     const int pr = role;
     u64 *surv = surv0 + pr * PDT_SURV_CAP;
     const int nt_ = V >> 6, rem_ = V & 63;  // full token chunks; lane of the blank in the chunk after them
-    // chunks every row of this instantiation has: the launcher picks NR with NR - 8 < nt <= NR, so
-    // the first NR - 8 need no guard (a guard per chunk is a scalar branch and, worse, a merge of the
-    // two versions of everything the chunk touches)
-    constexpr int NF = NR > 8 ? NR - 8 : 0;
     // the row's logits: r[i], i < nt: token chunks with every lane in use; rt: the chunk that ends
     // with the blank (lanes 0 .. rem; tokens below rem)
     float r[NR], rt = 0.0f;
@@ -326,51 +329,73 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   }
 }
 
-// rows of 513 .. 5120 elements, beams the one-kernel search holds; PDT_CTC_ROWREG=0 keeps the LDS
+constexpr int kRowregMaxChunks = 256;
+
+// rows of 513 .. 16 448 elements, beams the one-kernel search holds; PDT_CTC_ROWREG=0 keeps the LDS
 // rows of ctc_search.hip (comparisons)
 bool ctc_rowreg_applies(int V, int W) {
   const int mode = switches().ctc_rowreg;
-  return mode != 0 && W >= 1 && W <= kMaxWidth && V + 1 > 8 * PDT_WAVE && V / PDT_WAVE <= 80;
+  return mode != 0 && W >= 1 && W <= kMaxWidth && V + 1 > 8 * PDT_WAVE && V / PDT_WAVE <= kRowregMaxChunks;
 }
 
 // (one producer per utterance, two utterances per workgroup, was 35 % slower at V = 5000 and 2x at
 // V = 1000: a lone producer cannot keep a frame's latency off its consumer)
 RowregLayout plan_ctc_rowreg(int V, int W) { return rowreg_layout(V, W, 4, 1, 3); }
 
-void ctc_rowreg_plan4(int V, int W, int32_t *plan4) {
-  const RowregLayout rl = plan_ctc_rowreg(V, W);
-  plan4[0] = rl.producers; plan4[1] = rl.nstage; plan4[2] = rl.utt_per_wg; plan4[3] = 3;
+// register chunks of the instantiation that serves rows of V tokens (launch_rowreg_nr's table)
+static int rowreg_chunks(int V) {
+  const int c = V / PDT_WAVE;
+  if (c <= 80) return (c + 7) / 8 * 8;
+  if (c <= 128) return (c + 15) / 16 * 16;
+  return (c + 31) / 32 * 32;
 }
 
-template <int NR, int P>
+void ctc_rowreg_plan(int V, int W, int32_t *plan5) {
+  const RowregLayout rl = plan_ctc_rowreg(V, W);
+  plan5[0] = rl.producers; plan5[1] = rl.nstage; plan5[2] = rl.utt_per_wg; plan5[3] = 3;
+  plan5[4] = rowreg_chunks(V);
+}
+
+template <int NR, int NF, int P>
 static int launch_rowreg(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_rowreg_kernel<NR, P>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_rowreg_kernel<NR, NF, P>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL((ctc_rowreg_kernel<NR, P>), dim3(grid), dim3(256), smem, stream, a, rl);
+  hipLaunchKernelGGL((ctc_rowreg_kernel<NR, NF, P>), dim3(grid), dim3(256), smem, stream, a, rl);
   return (int)hipGetLastError();
 }
 
+// full token chunks (the chunk with the blank has a register of its own): instantiations in steps of
+// eight chunks up to 80 (four waves per SIMD and more), of 16 up to 128 (three), of 32 up to 256 (two,
+// then one: the whole register file of a SIMD holds one row)
 template <int P>
 static int launch_rowreg_nr(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
-  // full token chunks (the chunk with the blank has a register of its own), in steps of eight: the
-  // instantiation for NR serves NR - 8 < chunks <= NR
-  switch ((a.V / PDT_WAVE + 7) / 8) {
-    case 1: return launch_rowreg<8, P>(a, rl, stream);
-    case 2: return launch_rowreg<16, P>(a, rl, stream);
-    case 3: return launch_rowreg<24, P>(a, rl, stream);
-    case 4: return launch_rowreg<32, P>(a, rl, stream);
-    case 5: return launch_rowreg<40, P>(a, rl, stream);
-    case 6: return launch_rowreg<48, P>(a, rl, stream);
-    case 7: return launch_rowreg<56, P>(a, rl, stream);
-    case 8: return launch_rowreg<64, P>(a, rl, stream);
-    case 9: return launch_rowreg<72, P>(a, rl, stream);
-    default: return launch_rowreg<80, P>(a, rl, stream);
+  const int c = a.V / PDT_WAVE;
+  if (c <= 80) {
+    switch ((c + 7) / 8) {
+      case 1: return launch_rowreg<8, 0, P>(a, rl, stream);
+      case 2: return launch_rowreg<16, 8, P>(a, rl, stream);
+      case 3: return launch_rowreg<24, 16, P>(a, rl, stream);
+      case 4: return launch_rowreg<32, 24, P>(a, rl, stream);
+      case 5: return launch_rowreg<40, 32, P>(a, rl, stream);
+      case 6: return launch_rowreg<48, 40, P>(a, rl, stream);
+      case 7: return launch_rowreg<56, 48, P>(a, rl, stream);
+      case 8: return launch_rowreg<64, 56, P>(a, rl, stream);
+      case 9: return launch_rowreg<72, 64, P>(a, rl, stream);
+      default: return launch_rowreg<80, 72, P>(a, rl, stream);
+    }
   }
+  if (c <= 96) return launch_rowreg<96, 80, P>(a, rl, stream);
+  if (c <= 112) return launch_rowreg<112, 96, P>(a, rl, stream);
+  if (c <= 128) return launch_rowreg<128, 112, P>(a, rl, stream);
+  if (c <= 160) return launch_rowreg<160, 128, P>(a, rl, stream);
+  if (c <= 192) return launch_rowreg<192, 160, P>(a, rl, stream);
+  if (c <= 224) return launch_rowreg<224, 192, P>(a, rl, stream);
+  return launch_rowreg<256, 224, P>(a, rl, stream);
 }
 
 int launch_ctc_rowreg(CtcArgs a, hipStream_t stream) {

@@ -619,7 +619,7 @@ __host__ inline int plan_ctc_search(int V, int W, CtcPlan *plan, RingLayout *rl)
 
 // rows held in the producers' registers (ctc_rowreg.hip)
 bool ctc_rowreg_applies(int V, int W);
-void ctc_rowreg_plan4(int V, int W, int32_t *plan4);
+void ctc_rowreg_plan(int V, int W, int32_t *plan5);
 int launch_ctc_rowreg(CtcArgs a, hipStream_t stream);
 
 int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &rl, hipStream_t stream) {
@@ -649,15 +649,17 @@ int64_t pdt_ctc_prefix_search_workspace_bytes(int64_t T, int64_t N, int64_t V, i
   return bytes;
 }
 
-int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan4) {
-  if (V < 1 || width < 1 || !plan4) return PDT_E_ARG;
+int pdt_ctc_prefix_search_plan(int64_t V, int64_t width, int32_t *plan5) {
+  int32_t *plan4 = plan5;
+  if (V < 1 || width < 1 || !plan5) return PDT_E_ARG;
   if (V >= (1 << 30)) return PDT_E_TOO_LONG;
   pdt::CtcPlan plan;
   pdt::RingLayout rl;
   const int rc = pdt::plan_ctc_search((int)V, (int)width, &plan, &rl);
   if (rc != PDT_OK) return rc;
   plan4[0] = plan.producers; plan4[1] = plan.nstage; plan4[2] = plan.utt_per_wg; plan4[3] = plan.inreg;
-  if (pdt::ctc_rowreg_applies((int)V, (int)width)) pdt::ctc_rowreg_plan4((int)V, (int)width, plan4);  // (3: rows in registers)
+  plan5[4] = 0;
+  if (pdt::ctc_rowreg_applies((int)V, (int)width)) pdt::ctc_rowreg_plan((int)V, (int)width, plan5);  // (3: long rows in registers)
   return PDT_OK;
 }
 

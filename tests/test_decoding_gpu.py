@@ -51,13 +51,13 @@ def test_ctc_prefix_search_random(device, V, K):
 
 
 def _ctc_plan(V, K):
-    """(status, (producers, ring slots, utterances per workgroup, row in registers)) the library
-    picks for rows of V tokens (host arithmetic only: include/pdt_amd.h)."""
+    """(status, (producers, ring slots, utterances per workgroup, where a row is held, register chunks))
+    the library picks for rows of V tokens (host arithmetic only: include/pdt_amd.h)."""
     import ctypes
 
     from pydrobert_amd import _cabi
 
-    out = (ctypes.c_int32 * 4)()
+    out = (ctypes.c_int32 * 5)()
     rc = _cabi.lib().pdt_ctc_prefix_search_plan(V, K, out)
     return rc, tuple(out)
 
@@ -81,19 +81,31 @@ def _plan_boundaries(K, hi=17000):
 
 
 def _long_row_cases():
-    cases = [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4), (11000, 16), (15000, 8), (40000, 16)]
-    for K in (16, 32):
-        for edge in _plan_boundaries(K, hi=20000):
-            cases += [(edge - 1, K), (edge, K)]  # one V on each side of every change
-    return sorted(set(cases))
+    """(V, K, PDT_CTC_ROWREG): a few fixed row lengths and one V on each side of every change of
+    configuration -- with the long rows in the producers' registers (the default: a change is also
+    every new register-chunk count of ctc_rowreg.hip) and with that form switched off (the LDS /
+    workspace rows of ctc_search.hip, which also serve strided logits)."""
+    from pydrobert_amd import switches
+
+    cases = []
+    for rowreg in (1, 0):
+        with switches.override(PDT_CTC_ROWREG=rowreg):
+            mine = [(513, 16), (700, 8), (1200, 32), (4600, 16), (9000, 4), (11000, 16), (15000, 8), (40000, 16)]
+            for K in (16, 32):
+                for edge in _plan_boundaries(K, hi=20000):
+                    mine += [(edge - 1, K), (edge, K)]  # one V on each side of every change
+        cases += [(V, K, rowreg) for V, K in sorted(set(mine))]
+    return cases
 
 
-@pytest.mark.parametrize("V,K", _long_row_cases())
-def test_ctc_prefix_search_long_rows(device, V, K):
-    """Vocabularies beyond 511: several producer waves share an utterance's frames (three, then
-    two as the ring grows), then one producer with a two-slot ring, finally rows that stay in the
-    HBM workspace because no LDS ring holds them; one V on each side of every change of
-    configuration, ragged lens shorter than the number of producers included."""
+@pytest.mark.parametrize("V,K,rowreg", _long_row_cases())
+def test_ctc_prefix_search_long_rows(device, V, K, rowreg, switch):
+    """Vocabularies beyond 511.  Default: the row of a frame stays in the registers of the producer
+    wave that read it, up to 16 447 tokens (ctc_rowreg.hip, instantiations by register-chunk count).
+    PDT_CTC_ROWREG=0: three producer waves around an LDS ring of rows (four slots, then three),
+    finally rows that stay in the HBM workspace because no LDS ring holds them.  One V on each side of
+    every change of configuration, ragged lens shorter than the number of producers included."""
+    switch("PDT_CTC_ROWREG", rowreg)
     rng = np.random.default_rng(7000 + V)
     for it, (T, N) in enumerate([(2, 3), (25, 5), (61, 2)] if V < 10000 else [(2, 3), (23, 3)]):
         lg = _peaky_logits(rng, T, N, V, scale=11.0 if V < 10000 else 13.0)
@@ -104,13 +116,16 @@ def test_ctc_prefix_search_long_rows(device, V, K):
         _check_search(act, exp, (V, K, T, N, _ctc_plan(V, K)))
 
 
-def test_ctc_prefix_search_workspace_rows_long_input(device):
-    """Rows in the workspace (V beyond the three-slot LDS ring) with an input long enough that the
-    checkpoint table of the output walk, at 32-frame spacing, would not fit the 4 x 8 KiB ring of
-    that form: the spacing has to come from the ring the plan really uses."""
+@pytest.mark.parametrize("rowreg", [1, 0])
+def test_ctc_prefix_search_workspace_rows_long_input(device, rowreg, switch):
+    """Rows in the workspace (V beyond the three-slot LDS ring; PDT_CTC_ROWREG=0) or in registers with
+    a ring of lists (the default) and an input long enough that the checkpoint table of the output
+    walk, at 32-frame spacing, would not fit the LDS it overlays in either form: the spacing has to
+    come from the layout the plan really uses."""
     V, K, T, N = 10400, 32, 4300, 1
+    switch("PDT_CTC_ROWREG", rowreg)
     rc, plan = _ctc_plan(V, K)
-    assert rc == 0 and plan[3] == 2, plan
+    assert rc == 0 and plan[3] == (3 if rowreg else 2), plan
     rng = np.random.default_rng(424242)
     lg = _peaky_logits(rng, T, N, V, scale=19.0)  # p_peak ~ 0.9999: masses survive 4300 frames
     tl = torch.from_numpy(lg).to(device)
@@ -135,7 +150,8 @@ def test_ctc_plan_covers_every_vocabulary():
     for V in (1, 64, 65, 511, 512, 5000, 16000, 16200, 100000, 1 << 20):
         rc, plan = _ctc_plan(V, 16)
         assert rc == 0 and plan[0] >= 1, (V, rc, plan)
-    assert _ctc_plan(1 << 20, 16)[1][3] == 2 and _ctc_plan(256, 16)[1][3] == 1 and _ctc_plan(5000, 16)[1][3] == 0
+    assert _ctc_plan(1 << 20, 16)[1][3] == 2 and _ctc_plan(256, 16)[1][3] == 1 and _ctc_plan(5000, 16)[1][3:] == (3, 80)
+    assert _ctc_plan(16447, 16)[1][3:] == (3, 256) and _ctc_plan(16448, 16)[1][3] == 2
 
 
 def test_ctc_prefix_search_golden_shape(device):
@@ -250,6 +266,17 @@ def test_ctc_strided_logits_and_errors(device):
     t = torch.from_numpy(np.ascontiguousarray(lg.transpose(1, 0, 2))).to(device).transpose(0, 1)
     assert not t.is_contiguous()
     _check_search(F.ctc_prefix_search(t, 3), oracle.ctc_prefix_search(lg, 3), "strided")
+    # long rows: batch-major storage keeps the rows contiguous (the register form), a vocabulary axis
+    # with a stride does not (the LDS rows take it)
+    lg = _peaky_logits(rng, 9, 3, 700, scale=10.0)
+    exp = oracle.ctc_prefix_search(lg, 5)
+    t = torch.from_numpy(np.ascontiguousarray(lg.transpose(1, 0, 2))).to(device).transpose(0, 1)
+    _check_search(F.ctc_prefix_search(t, 5), exp, "batch-major long rows")
+    wide = torch.zeros((9, 3, 2 * 701), device=device)
+    wide[:, :, ::2] = torch.from_numpy(lg).to(device)
+    t = wide[:, :, ::2]
+    assert t.stride(2) == 2
+    _check_search(F.ctc_prefix_search(t, 5), exp, "strided vocabulary axis")
     with pytest.raises(RuntimeError, match="3 dimensional"):
         F.ctc_prefix_search(t[0], 3)
     with pytest.raises(RuntimeError, match="lens must be 1"):
