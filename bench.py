@@ -315,9 +315,9 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
     return out
 
 
-def synthetic_bigram_lm(M, V, device, successors=20, seed=0x5EED0007):
-    """A back-off bigram LookupLanguageModel over V tokens (+ an out-of-vocabulary sos): every
-    token a unigram, `successors` random explicit bigrams per context token."""
+def synthetic_bigram_dicts(V, successors=20, seed=0x5EED0007):
+    """n-gram tables of a back-off bigram model over V tokens (+ an out-of-vocabulary sos): every token
+    a unigram, `successors` random explicit bigrams per context token."""
     rng = np.random.default_rng(seed)
     uni = rng.normal(size=V + 1) - np.log(V)
     bo = rng.normal(size=V + 1) * 0.1 - 0.5
@@ -326,7 +326,44 @@ def synthetic_bigram_lm(M, V, device, successors=20, seed=0x5EED0007):
     for a in range(V + 1):
         for b_ in rng.choice(V, successors, replace=False):
             d2[(a, int(b_))] = float(rng.normal() - 3.0)
-    return M.LookupLanguageModel(V, V, [d1, d2]).to(device)
+    return [d1, d2]
+
+
+def speechlike_logits(T, N, V, device, seed, dicts, rate=0.045):
+    """Logits for the searches WITH a language model: N(0,1) + 12 on one class per frame like
+    peaky_logits, but the peak is the blank in most frames and otherwise the next token of a sequence
+    drawn along the model's explicit bigrams (`rate` tokens per frame).  Probability-space prefix masses
+    (the reference's arithmetic, _decoding.py:1093-1202) then stay above the float32 underflow for the
+    whole input: with a new uniformly random token in every frame -- SURVEY 8(d)'s input for the search
+    WITHOUT a model -- every mass is exactly 0 after ~70 frames of shallow fusion (p_lm^0.2 ~ 0.25 per
+    token) and the rest of the search is a tie among zeros."""
+    rng = np.random.default_rng(seed)
+    succ = {}
+    for (a, b_) in dicts[1]:
+        succ.setdefault(a, []).append(b_)
+    width = max(len(v) for v in succ.values())
+    table = np.zeros((V + 1, width), dtype=np.int64)
+    for a in range(V + 1):
+        opts = succ.get(a) or [0]
+        table[a] = np.resize(np.asarray(opts), width)
+    emit = rng.random((T, N)) < rate
+    n_tok = int(emit.sum(0).max()) if N else 0
+    seq = np.empty((max(n_tok, 1), N), dtype=np.int64)
+    cur = np.full((N,), V, dtype=np.int64)  # the model's sos context
+    for k in range(seq.shape[0]):
+        cur = table[cur, rng.integers(0, width, N)]
+        seq[k] = cur
+    which = np.maximum(np.cumsum(emit, 0) - 1, 0)
+    peak = np.where(emit, np.take_along_axis(seq, which, 0), V)
+    g = torch.Generator(device=device).manual_seed(seed)
+    lg = torch.randn((T, N, V + 1), device=device, generator=g)
+    lg.scatter_add_(2, torch.from_numpy(peak).to(device).unsqueeze(2), torch.full((T, N, 1), 12.0, device=device))
+    return lg
+
+
+def synthetic_bigram_lm(M, V, device, successors=20, seed=0x5EED0007):
+    """The LookupLanguageModel over synthetic_bigram_dicts (sos = V)."""
+    return M.LookupLanguageModel(V, V, synthetic_bigram_dicts(V, successors, seed)).to(device)
 
 
 def make_gru_lm(M, V, hidden=256):

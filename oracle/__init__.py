@@ -237,3 +237,4 @@ from ._img import *  # noqa: E402,F401,F403
 from ._losses import *  # noqa: E402,F401,F403
 from ._seqops import *  # noqa: E402,F401,F403
 from ._lm import backoff_log_probs, trie_log_probs  # noqa: E402,F401
+from ._search import CounterLM, NGramLM, TableLM, beam_search, ctc_prefix_search_lm  # noqa: E402,F401

@@ -466,6 +466,169 @@ if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "swe
     search_sweep_goldens()
 
 
+class CounterLM(M.MixableSequentialLanguageModel):
+    """A model WITH state under the reference's interface (twins: oracle.CounterLM, tests/_toy_lm.py)."""
+
+    def __init__(self, table):
+        super().__init__(table.shape[1])
+        self.register_buffer("table", table)
+
+    def update_input(self, prev, hist):
+        if "count" not in prev:
+            prev = {"count": torch.zeros((hist.size(1),))}
+        return prev
+
+    def calc_idx_log_probs(self, hist, prev, idx):
+        V = self.vocab_size
+        N = hist.shape[1]
+        if idx.dim() == 0:
+            idx = idx.expand(N)
+        prev_tok = torch.full((N,), V, dtype=torch.long)
+        if hist.shape[0]:
+            last = hist.gather(0, (idx - 1).clamp(min=0).unsqueeze(0)).squeeze(0).clamp(0, V - 1)
+            prev_tok = torch.where(idx > 0, last, prev_tok)
+        x = self.table[prev_tok] * (1.0 + 0.1 * prev["count"]).unsqueeze(1)
+        return x.log_softmax(-1), {"count": prev["count"] + 1.0}
+
+    def extract_by_src(self, prev, src):
+        return {"count": prev["count"].index_select(0, src)}
+
+    def mix_by_mask(self, prev_true, prev_false, mask):
+        return {"count": torch.where(mask, prev_true["count"], prev_false["count"])}
+
+
+def _tie_free(p, K, rel):
+    """Beam entries of one batch element far enough apart that their order is not a rounding matter."""
+    fl = p.reshape(-1, K)
+    if not torch.isfinite(fl).all():
+        return False
+    srt = fl.sort(1, descending=True).values
+    gap = srt[:, :-1] - srt[:, 1:]
+    return K == 1 or bool((gap >= rel * srt[:, :-1].abs().clamp(min=1e-30)).all())
+
+
+def lm_search_goldens():
+    """Searches with the SHIPPED n-gram model (LookupLanguageModel) in the loop, from the live reference:
+    CTCPrefixSearch with orders 2-4, shallow fusion and valid mixture, ragged lens, sos inside / outside
+    the vocabulary; BeamSearch with eos / finish_all_paths / neither; and both searches around a model
+    WITH state (CounterLM), which pins extract_by_src / mix_by_mask.  Tables are large enough for int16
+    trie offsets (the reference's builder fails on uint8 ones under NumPy 2)."""
+    rng = np.random.default_rng(0x5EED0009)
+    d = {}
+
+    def make(V, sos, N, counts):
+        toks = list(range(V)) + ([sos] if not (0 <= sos < V) else [])
+        dicts = []
+        for n in range(N):
+            dd = {}
+            if n == 0:
+                for v in toks:
+                    dd[v] = (float(rng.normal() - 2.0), float(rng.normal() * 0.3)) if N > 1 else float(rng.normal())
+            else:
+                keys = set()
+                while len(keys) < counts[n]:
+                    keys.add(tuple(int(toks[i]) for i in rng.integers(0, len(toks), n + 1)))
+                for k in keys:
+                    dd[k] = float(rng.normal() - 1.0) if n == N - 1 else (float(rng.normal() - 1.0), float(rng.normal() * 0.3))
+            dicts.append(dd)
+        return dicts
+
+    def store(tag, V, sos, dicts):
+        N = len(dicts)
+        d[tag + "_cfg"] = np.array([V, sos, N])
+        for n, dd in enumerate(dicts):
+            d["{}_keys{}".format(tag, n)] = np.array(
+                [[k] if n == 0 else list(k) for k in dd.keys()], dtype=np.int64).reshape(len(dd), n + 1)
+            d["{}_vals{}".format(tag, n)] = np.array([[v] if n == N - 1 else list(v) for v in dd.values()], dtype=np.float64)
+
+    models = {"m2in": (24, 5, 2, [0, 400]), "m2out": (24, -1, 2, [0, 400]), "m3in": (20, 0, 3, [0, 250, 500]),
+              "m3out": (20, 20, 3, [0, 250, 500]), "m4out": (16, -3, 4, [0, 200, 400, 400])}
+    lms = {}
+    for tag, (V, sos, N, counts) in models.items():
+        dicts = make(V, sos, N, counts)
+        store(tag, V, sos, dicts)
+        lms[tag] = (V, M.LookupLanguageModel(V, sos, [x.copy() for x in dicts]))
+    n_ctc = n_beam = 0
+    tags = list(models)
+    while n_ctc < 30:
+        tag = tags[n_ctc % len(tags)]
+        V, lm = lms[tag]
+        K = int(rng.integers(1, 9))
+        T, N = int(rng.integers(1, 26)), int(rng.integers(1, 5))
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        peak = rng.integers(0, V + 1, (T, N))
+        np.put_along_axis(lg, peak[..., None], np.take_along_axis(lg, peak[..., None], 2) + 4.0, 2)
+        lens = None if rng.random() < 0.3 else rng.integers(0, T + 1, N)
+        beta = float(rng.uniform(0.05, 0.9))
+        vm = bool((n_ctc // len(tags)) % 2)
+        y, yl, yp = M.CTCPrefixSearch(K, beta, lm, valid_mixture=vm)(
+            torch.from_numpy(lg), None if lens is None else torch.from_numpy(lens))
+        if not _tie_free(yp, K, 1e-4):
+            continue
+        mask = torch.arange(y.shape[0]).view(-1, 1, 1) < yl.unsqueeze(0)
+        t_ = "ctc%d_" % n_ctc
+        d[t_ + "logits"] = lg
+        d[t_ + "lens"] = np.array([-1]) if lens is None else lens
+        d[t_ + "cfg"] = np.array([K, beta, float(vm), tags.index(tag)])
+        d[t_ + "y"], d[t_ + "y_lens"], d[t_ + "y_probs"] = torch.where(mask, y, torch.zeros_like(y)), yl, yp
+        n_ctc += 1
+    while n_beam < 20:
+        tag = tags[n_beam % len(tags)]
+        V, lm = lms[tag]
+        K = int(rng.integers(1, 8))
+        eos = None if n_beam % 4 == 3 else int(rng.integers(-V, V))
+        fin = bool(n_beam % 2)
+        N = None if rng.random() < 0.2 else int(rng.integers(1, 5))
+        iters = int(rng.integers(0, 14))
+        y, yl, lp = M.BeamSearch(lm, K, eos, fin, -7)(dict(), N, iters)
+        fl = lp.reshape(-1, K)
+        fin_ = torch.isfinite(fl)
+        srt = fl.sort(1, descending=True).values
+        if K > 1 and fin_.all() and (srt[:, :-1] - srt[:, 1:]).min() < 1e-4:
+            continue
+        t_ = "beam%d_" % n_beam
+        d[t_ + "cfg"] = np.array([K, -1000 if eos is None else eos, int(fin), -1 if N is None else N, iters, tags.index(tag)])
+        d[t_ + "y"], d[t_ + "y_lens"], d[t_ + "lp"] = y, yl, lp
+        n_beam += 1
+    d["model_tags"] = np.array(tags)
+    # a model with state in both searches
+    n_c = 0
+    while n_c < 12:
+        V, K = int(rng.integers(3, 12)), int(rng.integers(1, 7))
+        if K > V + 1:
+            continue
+        T, N = int(rng.integers(2, 20)), int(rng.integers(1, 4))
+        table = torch.from_numpy((rng.normal(size=(V + 1, V)) * 1.5).astype(np.float32))
+        lm = CounterLM(table)
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        peak = rng.integers(0, V + 1, (T, N))
+        np.put_along_axis(lg, peak[..., None], np.take_along_axis(lg, peak[..., None], 2) + 3.0, 2)
+        lens = None if rng.random() < 0.3 else rng.integers(0, T + 1, N)
+        beta, vm = float(rng.uniform(0.2, 0.9)), bool(n_c % 2)
+        y, yl, yp = M.CTCPrefixSearch(K, beta, lm, valid_mixture=vm)(
+            torch.from_numpy(lg), None if lens is None else torch.from_numpy(lens))
+        if not _tie_free(yp, K, 1e-4):
+            continue
+        eos = None if n_c % 3 == 0 else int(rng.integers(0, V))
+        iters = int(rng.integers(1, 10))
+        by, byl, blp = M.BeamSearch(lm, K, eos, bool(n_c % 2), -9)(dict(), N, iters)
+        if not _tie_free(blp, K, 0.0) and torch.isfinite(blp).all():
+            continue
+        mask = torch.arange(y.shape[0]).view(-1, 1, 1) < yl.unsqueeze(0)
+        t_ = "cnt%d_" % n_c
+        d[t_ + "table"], d[t_ + "logits"] = table, lg
+        d[t_ + "lens"] = np.array([-1]) if lens is None else lens
+        d[t_ + "cfg"] = np.array([K, beta, float(vm), -1000 if eos is None else eos, iters])
+        d[t_ + "y"], d[t_ + "y_lens"], d[t_ + "y_probs"] = torch.where(mask, y, torch.zeros_like(y)), yl, yp
+        d[t_ + "by"], d[t_ + "by_lens"], d[t_ + "blp"] = by, byl, blp
+        n_c += 1
+    save("lm_search", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "lm_search"):
+    lm_search_goldens()
+
+
 def fill_goldens():
     """fill_after_eos (_string.py:30-42): every dim of a 3-D tensor, default and explicit fill,
     a separate value tensor (float and bool), rows with no / several / leading eos."""
