@@ -226,6 +226,23 @@ def cpu_baseline(args, with_decode, op_ms):
 # ------------------------------------------------------------------------------------------
 # the other BASELINE configs, after the timed region
 # ------------------------------------------------------------------------------------------
+def roof(alg_bytes, ms, kernel, note=None):
+    """Roofline entry of one configuration: algorithmic HBM bytes of one call (SURVEY section 8(d)'s
+    per-unit figure x the units of the call), the measured time of that call, and the fraction of the
+    8 TB/s HBM peak the two give."""
+    r = {"algorithmic_bytes": int(alg_bytes), "ms": ms, "achieved": alg_bytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS,
+         "unit": "GB/s", "bound": "hbm", "kernel": kernel}
+    r["frac"] = r["achieved"] / HBM_PEAK_GBS
+    if note:
+        r["note"] = note
+    return r
+
+
+def search_bytes(T, N, V, K):
+    """4 T (V + 1) of logits + 8 T K + 12 K of outputs per utterance."""
+    return (4 * T * (V + 1) + 8 * T * K + 12 * K) * N
+
+
 def other_configs(F, M, device, world, rank, dist, gather_check):
     out = {}
     K = 16
@@ -258,6 +275,9 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
                     "all-gather of rates / lens / probs over {} rank(s)".format(world),
         "ms": ms_all, "error_rate_ms": ms_er, "decode_ms": ms_dec, "utt_per_s_job": world * N / ms_all * 1e3,
         "decode_GBs": lg.numel() * 4 / ms_dec / 1e6, "checked": ok,
+        "roofline": roof(search_bytes(T, N, V, K), ms_dec, ctc_kernel_name(V, K),
+                         "the decode of the shard; error_rate (8 196 B per utterance) is issue-bound, not HBM-bound"),
+        "error_rate_roofline": roof((8 * 2 * T + 4) * N, ms_er, "pdt::lev_classify_kernel<8> + pdt::lev_bitpar_kernel"),
     }
     del lg, ref, hyp
     if rank != 0:
@@ -267,7 +287,8 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
     lg = peaky_logits(T, N, V, device, 0x5EED0003)
     ms = event_ms(lambda: F.ctc_prefix_search(lg, K), reps=3, warm=1)
     out["C3_search"] = {"workload": "ctc_prefix_search N=1024 T=1000 V=1000 K=16", "ms": ms,
-                        "utt_per_s": N / ms * 1e3, "GBs": lg.numel() * 4 / ms / 1e6}
+                        "utt_per_s": N / ms * 1e3, "GBs": lg.numel() * 4 / ms / 1e6,
+                        "roofline": roof(search_bytes(T, N, V, K), ms, ctc_kernel_name(V, K))}
     # C3: the bare step functions with S=100 rows of real history
     S = 100
     nb, b = torch.zeros((N, 1), device=device), torch.ones((N, 1), device=device)
@@ -282,14 +303,18 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
         if t < S:
             yh, last, lens, (nb, b), isp, _, _ = F.ctc_prefix_search_advance(*step_args)
     ms = event_ms(lambda: F.ctc_prefix_search_advance(*step_args))
-    out["C3_ctc_prefix_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms}
+    step_bytes = (4 * (V + 1) + 8 * S * K + 8 * (S + 1) * K + K * K + 5 * 8 * K) * N
+    out["C3_ctc_prefix_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms,
+                                           "roofline": roof(step_bytes, ms, "pdt::ctc_advance_kernel")}
     g = torch.Generator(device=device).manual_seed(4)
     lpt = torch.randn((N, K, V), device=device, generator=g).log_softmax(-1)
     lpp = torch.randn((N, K), device=device, generator=g)
     yb = torch.randint(0, V, (S, N, K), device=device, generator=g)
     ybl = torch.full((N, K), S, device=device)
     ms = event_ms(lambda: F.beam_search_advance(lpt, K, lpp, yb, ybl))
-    out["C3_beam_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms}
+    out["C3_beam_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms,
+                                     "roofline": roof((4 * K * V + 8 * S * K + 8 * (S + 1) * K + 4 * 8 * K) * N, ms,
+                                                      "pdt::beam_advance_kernel")}
     del lg, lpt, yb, step_args
     # C4: SpecAugment N=2048 x 1000 x 80
     N, T, Fq = 2048, 1000, 80
@@ -302,7 +327,9 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
     params = sa.draw_parameters(feats, lens)
     ms = event_ms(lambda: sa.apply_parameters(feats, params, lens))
     out["C4_spec_augment_apply"] = {"workload": "N=2048 T=1000 F=80, 2 time + 2 freq masks + time warp", "ms": ms,
-                                    "utt_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6}
+                                    "utt_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6,
+                                    "roofline": roof(2 * 4 * feats.numel(), ms,
+                                                     "pdt::spline_solve_kernel + pdt::warp_1d_grid + pdt::spec_augment_rows_kernel")}
     ms = event_ms(lambda: sa(feats, lens))
     out["C4_SpecAugment_forward"] = {"workload": "draw + apply", "ms": ms, "utt_per_s": N / ms * 1e3}
     img = feats.view(N, 1, T, Fq)
@@ -311,7 +338,9 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
     ms = event_ms(lambda: F.sparse_image_warp(img, src, dst, pinned_boundary_points=1, include_flow=False),
                   reps=3, warm=1)
     out["C4_sparse_image_warp"] = {"workload": "(2048,1,1000,80), 3 control + 4 pinned points, order 2", "ms": ms,
-                                   "img_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6}
+                                   "img_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6,
+                                   "roofline": roof(2 * 4 * feats.numel(), ms,
+                                                    "pdt::spline_solve_kernel + pdt::sparse_warp_fast_kernel<2, border>")}
     return out
 
 
@@ -421,6 +450,9 @@ def lm_configs(F, M, device, args, ref, hyp):
     C = F.optimal_completion(rr, hh, eos=V, warn=False).shape[-1]
     rag["optimal_completion_C"] = C
     rag["optimal_completion_GBs"] = 8 * (T + 1) * C * N / rag["optimal_completion_ms"] / 1e6
+    rag["roofline"] = roof((8 * 2 * T + 8 * (T + 1) * C) * N, rag["optimal_completion_ms"],
+                           "pdt::lev_classify_kernel<8> + pdt::oc_bitpar_kernel<3> + pdt::oc_expand_tiles_kernel<8>",
+                           "optimal_completion of the ragged pair (the HBM-write-bound operator of the three)")
     rag["ms"] = rag["error_rate_ms"] + rag["prefix_error_rates_ms"] + rag["optimal_completion_ms"]
     rag["workload"] = "C2 shapes, eos={} at len ~ U{{T/2..T}} in ref and hyp".format(V)
     out["C2_ragged"] = rag
@@ -440,45 +472,84 @@ def lm_configs(F, M, device, args, ref, hyp):
         "workload": "error_rate + prefix_error_rates + optimal_completion of the step, default arguments (warn=True)",
         "ms": event_ms(strings_default, reps=5, warm=1), "ms_warn_false": event_ms(strings_nowarn, reps=5, warm=1),
     }
-    # C3 with the shipped n-gram model in the loop (shallow fusion)
+    # C3 with the shipped n-gram model in the loop (shallow fusion).  Two inputs: "speechlike" -- blank-
+    # dominated frames, tokens drawn along the model's bigrams, every prefix mass stays above the
+    # float32 underflow for all 1000 frames (speechlike_logits) -- and SURVEY 8(d)'s input for the search
+    # without a model (a new uniformly random token peaks in every frame), on which every mass is
+    # exactly 0 from frame ~70 on: the second is kept for continuity with rounds 2-3 and is NOT a
+    # meaningful decode.
     T3, N3, V3, K = 1000, 1024, 1000, 16
+    dicts = synthetic_bigram_dicts(V3)
+    lm = M.LookupLanguageModel(V3, V3, [d.copy() for d in dicts]).to(device)
+    lg_speech = speechlike_logits(T3, N3, V3, device, 0x5EED0009, dicts)
     lg = peaky_logits(T3, N3, V3, device, 0x5EED0003)
-    lm = synthetic_bigram_lm(M, V3, device)
     search = M.CTCPrefixSearch(K, 0.2, lm)
+    lm_kernel = "pdt::ctc_lm_search_kernel"
     with torch.no_grad():
         search(lg[:8])
-        ms = event_ms(lambda: search(lg), reps=1, warm=0)
+        ms_speech = event_ms(lambda: search(lg_speech), reps=3, warm=1)
+        alive = float((search(lg_speech)[2][:, 0] > 0).float().mean())
+        ms = event_ms(lambda: search(lg), reps=3, warm=0)
+        dead = float((search(lg)[2][:, 0] == 0).float().mean())
     out["C3_search_lookup_lm"] = {
         "workload": "CTCPrefixSearch(16, beta=0.2, LookupLanguageModel bigram, 20 explicit successors per token), "
-                    "N=1024 T=1000 V=1000", "ms": ms, "ms_per_frame": ms / T3, "utt_per_s": N3 / ms * 1e3,
-        "GBs": lg.numel() * 4 / ms / 1e6,
+                    "N=1024 T=1000 V=1000, speechlike logits (~45 tokens per utterance among blank frames)",
+        "ms": ms_speech, "ms_per_frame": ms_speech / T3, "utt_per_s": N3 / ms_speech * 1e3,
+        "GBs": lg.numel() * 4 / ms_speech / 1e6, "utterances_with_positive_best_mass": alive, "reps": 3,
+        "roofline": roof(search_bytes(T3, N3, V3, K), ms_speech, lm_kernel),
+        "survey_input": {
+            "workload": "the same search on SURVEY 8(d)'s no-model input (a new random token peaks in every frame): "
+                        "masses underflow to 0 after ~70 frames of shallow fusion; rounds 2-3 quoted this number",
+            "ms": ms, "utterances_with_zero_best_mass": dead, "reps": 3,
+        },
     }
 
     torch.manual_seed(5)
     gru = make_gru_lm(M, V3).to(device)
     search = M.CTCPrefixSearch(K, 0.2, gru)
     with torch.no_grad():
-        search(lg[:8])
-        ms = event_ms(lambda: search(lg), reps=1, warm=0)
+        search(lg_speech[:8])
+        ms = event_ms(lambda: search(lg_speech), reps=3, warm=0)
         h = torch.randn((N3 * K, 256), device=device)
         gemm_ms = event_ms(lambda: gru.out(h), reps=5, warm=2)
     out["C3_search_gru_lm"] = {
-        "workload": "CTCPrefixSearch(16, beta=0.2, GRU-cell LM hidden 256 -> Linear(256, 1000)), N=1024 T=1000 V=1000",
-        "ms": ms, "ms_per_frame": ms / T3, "utt_per_s": N3 / ms * 1e3, "GBs": lg.numel() * 4 / ms / 1e6,
+        "workload": "CTCPrefixSearch(16, beta=0.2, GRU-cell LM hidden 256 -> Linear(256, 1000)), N=1024 T=1000 V=1000, "
+                    "speechlike logits (an untrained model: p_lm ~ 1/V per token, masses still underflow by frame ~400)",
+        "ms": ms, "ms_per_frame": ms / T3, "utt_per_s": N3 / ms * 1e3, "GBs": lg.numel() * 4 / ms / 1e6, "reps": 3,
         "logit_gemm_ms_per_frame": gemm_ms, "logit_gemm_share": gemm_ms * T3 / ms,
         "logit_gemm_TFLOPs": 2.0 * N3 * K * 256 * V3 / gemm_ms / 1e9,
         "gemm_kernel": "hipBLASLt / rocBLAS through torch.nn.Linear (kernel name: profiles/r03_gru_lm_kernel_stats.csv)",
+        "roofline": {"bound": "mfma", "kernel": "Tensile GEMM (N K x 256 x V, fp32) inside torch.nn.Linear",
+                     "achieved": 2.0 * N3 * K * 256 * V3 / gemm_ms / 1e9, "peak": 157.3, "unit": "TFLOP/s",
+                     "frac": 2.0 * N3 * K * 256 * V3 / gemm_ms / 1e9 / 157.3,
+                     "note": "the path's only GEMM, priced against the fp32 matrix peak (MI355X_MICROARCH.md); the "
+                             "frame loop around it is launch- and glue-bound, see ms_per_frame"},
     }
-    del lg
+    del lg, lg_speech
     # BeamSearch end to end: N=1024 paths x 16, V=1000, 100 iterations of the n-gram model
     bs = M.BeamSearch(lm, K, eos=0).to(device)
+    from pydrobert_amd import _decoding as _dec
+
     with torch.no_grad():
         bs(None, 8, 4)
-        ms = event_ms(lambda: bs(None, N3, 100), reps=1, warm=0)
+        _dec._BIGRAM_TABLES.clear()
+        t0 = time.perf_counter()
+        bs._bigram_table(device)
+        torch.cuda.synchronize()
+        table_ms = (time.perf_counter() - t0) * 1e3
+        ms = event_ms(lambda: bs(None, N3, 100), reps=3, warm=1)
+    # what an iteration really moves through HBM: the history, copied (t, N, K) -> (t + 1, N, K) int64;
+    # the prefixes' rows come out of the model's 4 MB table (L2 / Infinity Cache), once built
+    hist_bytes = sum(8 * N3 * K * (2 * t + 1) for t in range(100))
     out["BeamSearch_end_to_end"] = {
         "workload": "BeamSearch(LookupLanguageModel bigram, width 16, eos=0), batch 1024, 100 iterations, V=1000",
-        "ms": ms, "ms_per_iteration": ms / 100, "paths_per_s": N3 * K / ms * 1e3,
-        "GBs": 4.0 * N3 * K * V3 * 100 / ms / 1e6,
+        "ms": ms, "ms_per_iteration": ms / 100, "paths_per_s": N3 * K / ms * 1e3, "reps": 3,
+        "table_build_ms": table_ms,
+        "table_build_note": "the model's dense (context, token) table + row statistics, built once per model (not in `ms`)",
+        "row_bytes_from_cache": 4.0 * N3 * K * V3 * 100,
+        "roofline": roof(hist_bytes + 4 * (V3 + 1) * V3, ms, "pdt::beam_step_kernel (table form)",
+                         "HBM bytes = the history copies + one read of the table; 6.5 GB of score rows come from the "
+                         "table in cache and are not HBM traffic: the loop is bound by the step kernel's latency"),
     }
     return out
 
@@ -649,6 +720,15 @@ def run_rank(args):
     for i, name in enumerate(ops):
         op_ms[name] = float(np.mean([evs[s][i].elapsed_time(evs[s][i + 1]) for s in range(args.steps)]))
 
+    # per-rank spread of the op times (the line's op_ms are rank 0's; a SCALE record then shows whether
+    # the slowest rank or the exchange sets the step): min / max over ranks of every op, the gather's
+    # own event time among them
+    op_ms_ranks = None
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, op_ms)
+        op_ms_ranks = {o: {"min": min(r[o] for r in per_rank), "max": max(r[o] for r in per_rank)} for o in ops}
+
     # algorithmic HBM bytes per utterance
     C = C_seen[0]
     alg_bytes = {
@@ -669,7 +749,10 @@ def run_rank(args):
     # HBM bytes per launch and instruction counts from the rocprofv3 PMC passes (profiles/), only
     # when they were collected for this very configuration
     traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "r03_ctc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r04_ctc_traffic.json")
+    if not os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "r03_ctc_traffic.json")
+    tname = os.path.basename(tpath)
     if dom == "ctc_prefix_search" and os.path.exists(tpath):
         rec = json.load(open(tpath))
         if rec.get("config") == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
@@ -681,9 +764,9 @@ def run_rank(args):
                     "wave_insts_per_launch": insts,
                     "issue_ns_per_wave_inst": ns,
                     "pipe_busy_frac": None if ns is None else insts * ns * 1e-9 / (1024 * op_ms[dom] * 1e-3),
-                    "source": "profiles/r03_ctc_traffic.json (SQ_INSTS_VALU: profiles/collect_r03.sh; the kernel's static "
-                              "instruction mix priced by profiles/tools/valu_mix.py with the issue costs of "
-                              "profiles/r03_valu_issue_cost.txt, measured by profiles/tools/micro/valu_cost.hip)",
+                    "source": "profiles/" + tname + " (SQ_INSTS_VALU PMC pass; the kernel's static instruction mix priced "
+                              "by profiles/tools/valu_mix.py with the issue costs measured by "
+                              "profiles/tools/micro/valu_cost.hip)",
                 }
 
     def say(msg):
@@ -720,6 +803,7 @@ def run_rank(args):
                 "gather_verified": world > 1,
             },
             "op_ms": op_ms,
+            "op_ms_over_ranks": op_ms_ranks,
             "roofline": {
                 "kernel": kernel_names[dom],
                 "op": dom,
@@ -732,8 +816,8 @@ def run_rank(args):
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": None if traffic is None else
-                    "profiles/r03_ctc_traffic.json: FETCH_SIZE / WRITE_SIZE PMC passes of profiles/collect_r03.sh over this "
-                    "configuration (2 x FETCH + WRITE), a committed record -- not collected in this run",
+                    "profiles/" + tname + ": FETCH_SIZE / WRITE_SIZE PMC passes over this configuration "
+                    "(2 x FETCH + WRITE), a committed record -- not collected in this run",
                 "valu": valu,
                 "note": "priced against HBM as the contract asks; the kernel's own limiter is vector-"
                         "instruction issue (valu.pipe_busy_frac; DESIGN.md section 4.3)",
