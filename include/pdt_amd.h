@@ -163,6 +163,33 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
                           void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * CTC prefix beam search with a BIGRAM language model in the loop, every frame from one launch
+ * (reference _decoding.py:1064-1202 with shallow fusion / valid mixture, :1113-1135, around a
+ * LookupLanguageModel of order two, _lm.py:403-515).
+ *
+ *   pdt_lm_factor_table: the model's factor of the mix for every context token, from its scores
+ *     lm_log_probs (rows, V) contiguous (row c = the model's scores after context token c):
+ *     out[c][v] = exp(beta * log_softmax(lm_log_probs[c])[v])   (valid_mixture = 0; ext = p * out)
+ *              or softmax(lm_log_probs[c])[v]                    (valid_mixture = 1;
+ *                 ext = (1 - beta) * p + beta * (out * (1 - p_blank))) -- pdt_fusion_ext's expressions.
+ *     Built once per model and mix by the host; rows out_stride floats apart.
+ *   pdt_ctc_lm_table_search: logits / lens / width / S / y / y_lens / y_probs as
+ *     pdt_ctc_prefix_search (the softmax of :1093 is fused); factors (contexts, V) the table above,
+ *     factor_max (contexts,) the largest value of every row (it bounds a prefix's extension masses:
+ *     lists are built only for prefixes whose extensions can be among a frame's winners);
+ *     sos_row the row of the empty prefix's context; a prefix's context is its last token.
+ *     width <= 32, V <= 5119.  workspace: pdt_ctc_lm_table_search_workspace_bytes (trie + checkpoints).
+ * ------------------------------------------------------------------------------------- */
+int pdt_lm_factor_table(const float *lm_log_probs, int64_t rows, int64_t V, float beta, int valid_mixture,
+                        float *out, int64_t out_stride, void *stream);
+int64_t pdt_ctc_lm_table_search_workspace_bytes(int64_t T, int64_t N, int64_t V, int64_t width);
+int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st, int64_t lg_sn,
+                            int64_t lg_sv, const int64_t *lens, int64_t width, int64_t S, const float *factors,
+                            const float *factor_max, int64_t contexts, int64_t f_stride, int64_t sos_row, float beta,
+                            int valid_mixture,
+                            int64_t *y, int64_t *y_lens, float *y_probs, void *workspace, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * CTC prefix beam search without a language model: CTCPrefixSearch(width)(logits, lens)
  * (reference _decoding.py:1064-1202; the per-frame step is ctc_prefix_search_advance,
  * :636-934; the softmax of :1093 is fused).

@@ -95,6 +95,13 @@ struct DenseCtx {
   // the same history as 16-bit tokens (a caller that keeps its own, narrower copy between frames)
   const int16_t *y_prev16 = nullptr;
   const int *slot = nullptr;  // history column of old entry k (null: k itself)
+  // prefixes that share their language-model context share ONE list and one etab row: list_id[k] =
+  // the list of prefix k (LDS, [Kp]; null: prefix k has list k).  etab row r then belongs to list r.
+  const int *list_id = nullptr;
+  // bit k: no extension of prefix k can be among the frame's winners (the caller has a strict bound:
+  // every extension mass of k lies below a lower bound of the K-th winner) -- its extension streams
+  // are closed and its list is not read for candidates (it need not have been built)
+  unsigned closed = 0u;
 };
 
 // ints per next-token table: W * W, but at least 128 so that the table not in use (nxt_new
@@ -182,7 +189,10 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 // list -- the search kernel's producers send short lists only while that stays rare).
 // ROWLESS (shared-list form only): there is no row `p` to read -- the list is complete (M entries)
 // and FrameLds::pl_in / pblank_in carry the two other probabilities of the frame.
-template <bool DENSE, bool ROWLESS = false>
+// TRIE: prefix histories are the trie in HBM + the next-token tables in LDS (the one-kernel searches);
+// otherwise the dense (S, N, K') history of the step functions.  Per-prefix lists with a trie: the
+// search with a bigram model's factor table (ctc_lm_table.hip).
+template <bool DENSE, bool ROWLESS = false, bool TRIE = !DENSE>
 __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float inv, const int V,
                                           const int W, const int Kp, const int t,
                                           const int64_t n, const CtcArgs &a, const DenseCtx &dc,
@@ -213,14 +223,17 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     }
   }
   PDT_STAMP(1);
-  const int *mt = L.tl_tok + (DENSE ? me : 0) * PDT_WAVE;
+  // the list of prefix k (a wave-uniform or per-lane k alike: an LDS read when lists are shared)
+  auto list_of = [&](const int k) -> int { return DENSE ? (dc.list_id ? dc.list_id[k] : k) : 0; };
+  const int my_list = list_of(me);
+  const int *mt = L.tl_tok + my_list * PDT_WAVE;
 
   // ---- candidate masses that do not depend on the token (:777-794) ----------------------
   static_assert(!(DENSE && ROWLESS), "the row-less form reads the shared list");
   const float p_blank = ROWLESS ? L.pblank_in : p[V] * inv;
   const int lastc = min(max(bm.last, 0), V - 1);
   const float pl = ROWLESS ? L.pl_in : p[lastc] * inv;  // non-extension probability of my last token
-  const float e_last = DENSE ? (dc.etab ? dc.etab[me * dc.etab_stride + me] : dc.ext[me * dc.ext_sk + lastc * dc.ext_sv]) : pl;
+  const float e_last = DENSE ? (dc.etab ? dc.etab[my_list * dc.etab_stride + me] : dc.ext[me * dc.ext_sk + lastc * dc.ext_sv]) : pl;
   const float tot = bm.nb + bm.b;
   const float B = tot * p_blank;
   float NB = bm.nb * pl;
@@ -268,16 +281,17 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       if (cm == 0ull) continue;
       const int last_kk = min(max(__builtin_amdgcn_readlane(bm.last, kk), 0), V - 1);
       int jc = jl;  // index of my last token in kk's list
+      const int list_kk = list_of(kk);
       if (DENSE) {
         jc = -1;
-        for (int j = 0; j < M; ++j) jc = L.tl_tok[kk * PDT_WAVE + j] == lastc ? j : jc;
+        for (int j = 0; j < M; ++j) jc = L.tl_tok[list_kk * PDT_WAVE + j] == lastc ? j : jc;
       }
       if (accumulate) {
         const float nb_kk = readlane_f(bm.nb, kk), b_kk = readlane_f(bm.b, kk);
         if (child) {
           // to_match = the last token of the child (whose length is len_kk + 1)
           const float w = (lastc == last_kk ? 0.0f : nb_kk) + b_kk;
-          const float e = DENSE ? (dc.etab ? dc.etab[kk * dc.etab_stride + me] : dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv]) : pl;
+          const float e = DENSE ? (dc.etab ? dc.etab[list_kk * dc.etab_stride + me] : dc.ext[kk * dc.ext_sk + lastc * dc.ext_sv]) : pl;
           add += w * e;
         }
       }
@@ -297,6 +311,10 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     }
   };
   index_pass(c_list, true);
+  if (DENSE && ((dc.closed >> lane) & 1u)) {
+    avail = 0ull;
+    s1_open = false;
+  }
   NB = NB + add;
   PDT_STAMP(2);
 
@@ -346,8 +364,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     const float ms = rr == 2 ? ms1 : ms2;
     const bool os = ((open12 >> (rr == 2 ? 0 : 1)) & 1) != 0;
     const int j = av ? __builtin_ctz(av) : (hidden ? c_list - 1 : 0);
-    const int tokj = L.tl_tok[(DENSE ? ksrc : 0) * PDT_WAVE + j];
-    const float pj = L.tl_p[(DENSE ? ksrc : 0) * PDT_WAVE + j];
+    const int list_k = list_of(ksrc);
+    const int tokj = L.tl_tok[list_k * PDT_WAVE + j];
+    const float pj = L.tl_p[list_k * PDT_WAVE + j];
     const bool has = kvalid && (rr < 2 ? (av != 0u || hidden) : os);
     const unsigned keyL = has ? fkey_nonneg(rr < 2 ? tot_k * pj : ms) + (hidden ? 1u : 0u) : 0u;
     const int tokL = rr < 2 ? tokj : lastc_k;
@@ -390,7 +409,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       a2 &= a2 - 1u;
       a2 &= a2 - 1u;  // entries 0 and 1 gone
       const int j2 = a2 ? __builtin_ctz(a2) : c_list - 1;
-      const float p2 = L.tl_p[(DENSE ? kw : 0) * PDT_WAVE + j2];
+      const float p2 = L.tl_p[list_of(kw) * PDT_WAVE + j2];
       unsigned key2 = 0u;
       if (a2 != 0u) key2 = fkey_nonneg(tot2 * p2);
       else if (!full_list) key2 = fkey_nonneg(tot2 * p2) + 1u;  // upper bound of a hidden entry
@@ -448,8 +467,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // last probability, key + 1): if a bound is ever taken as a winner the list is completed and
   // the tiers run again; otherwise the short list was all this frame needed.
   auto fill_main = [&](bool mine) {
-    const int *lt = L.tl_tok + (DENSE ? ksrc : 0) * PDT_WAVE;
-    const float *lp = L.tl_p + (DENSE ? ksrc : 0) * PDT_WAVE;
+    const int list_k = list_of(ksrc);
+    const int *lt = L.tl_tok + list_k * PDT_WAVE;
+    const float *lp = L.tl_p + list_k * PDT_WAVE;
     if (M <= 32) {  // the usual case (K + K' <= 32): half the work per bit operation
       unsigned av = (unsigned)shfl_i((int)(unsigned)avail, ksrc);
       const int n_av = __popc(av);
@@ -520,7 +540,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       j = jl_k >= 0 ? jl_k : 63;
     } else if (tk >= 0 && e < n_main) {
       if (DENSE) {
-        const int *lt = L.tl_tok + ksrc * PDT_WAVE;
+        const int *lt = L.tl_tok + list_of(ksrc) * PDT_WAVE;
         for (int q = 0; q < M; ++q) j = lt[q] == tk ? q : j;
       } else {
         const int q = L.pos[tk];
@@ -537,7 +557,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   // not resident: more than 64 survivors, or a winner that is the last resident stream-0
   // entry of its prefix (the rounds would refill that prefix's slots).
   if (!selected) {
-    u64 *sel = DENSE ? L.surv : reinterpret_cast<u64 *>(L.nxt_new);
+    u64 *sel = TRIE ? reinterpret_cast<u64 *>(L.nxt_new) : L.surv;
     unsigned tau = tau_hint;
     if (tau == 0u) {
       const unsigned lk = max(max(key0, key1), key2);
@@ -682,8 +702,8 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   nw.last = !is_valid ? 0 : (is_ext ? new_tok : last_s);
   nw.len = !is_valid ? 0 : len_s + (is_ext ? 1 : 0);
   nw.node = !is_valid ? -1 : (is_ext ? t * W + lane : node_s);
-  if (!DENSE) nw.origin = shfl_i(bm.origin, srcl);
-  if (!DENSE && is_valid && is_ext)
+  if (TRIE) nw.origin = shfl_i(bm.origin, srcl);
+  if (TRIE && is_valid && is_ext)
     // (uniform base + 32-bit byte offset: T * W * 8 < 2^32 is checked on the host.  The full
     // 64-bit index was ~20 scalar instructions and five reloads of spilled scalars per frame.)
     *reinterpret_cast<int2 *>(reinterpret_cast<char *>(L.trie_u) + (unsigned)(t * W + lane) * 8u) = make_int2(node_s, new_tok);
@@ -722,14 +742,14 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       if (nw.len > len_b) continue;
       int tok_at;  // token of new prefix b at position len_s (the length of my source prefix)
       if (lenB > len_s)
-        tok_at = DENSE ? (dc.y_prev16 ? (int)dc.y_prev16[(int64_t)len_s * dc.yp_ss + (dc.slot ? dc.slot[src_b] : src_b) * dc.yp_sk]
+        tok_at = !TRIE ? (dc.y_prev16 ? (int)dc.y_prev16[(int64_t)len_s * dc.yp_ss + (dc.slot ? dc.slot[src_b] : src_b) * dc.yp_sk]
                                       : (int)dc.y_prev[(int64_t)len_s * dc.yp_ss + (dc.slot ? dc.slot[src_b] : src_b) * dc.yp_sk])
                        : L.nxt_old[new_src * W + src_b];
       else
         tok_at = ext_b ? tok_b : -1;  // lenB == len_s
       if (is_ext && tok_at != new_tok) continue;
       isp_new |= 1u << b;
-      if (!DENSE && nw.len < len_b) {  // strict prefix: the token that follows me inside b
+      if (TRIE && nw.len < len_b) {  // strict prefix: the token that follows me inside b
         int nx;
         if (!is_ext) {
           nx = tok_at;
@@ -743,7 +763,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       }
     }
   }
-  if (!DENSE && __ballot(need_walk)) {
+  if (TRIE && __ballot(need_walk)) {
     // rare: a re-created intermediate prefix.  Token of b at position nw.len = token of the
     // ancestor of b's source node at depth nw.len + 1.
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");

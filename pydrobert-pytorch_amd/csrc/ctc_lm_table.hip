@@ -1,0 +1,436 @@
+// CTC prefix beam search with a BIGRAM language model in the loop, the whole search in one launch.
+//
+// Replaces CTCPrefixSearch.forward with shallow fusion / valid mixture (reference
+// _decoding.py:1064-1202; the mix :1113-1135) when the model's factor of the mix depends on the
+// prefix's last token only -- a bigram LookupLanguageModel (_lm.py:403-515): then
+//     shallow fusion   ext[k, v] = p[v] * F[c_k][v],   F[c] = exp(beta * log_softmax(lm(. | c)))
+//     valid mixture    ext[k, v] = (1 - beta) * p[v] + beta * (G[c_k][v] * (1 - p_blank)),  G[c] = softmax(lm(. | c))
+// with c_k the last token of prefix k (the start-of-sequence row for the empty prefix).  The rows
+// F / G are a (contexts, V) table built ONCE per model and mix (fusion_ext.hip: pdt_lm_factor_table,
+// the expressions of pdt_fusion_ext) -- nothing is published between workgroups inside the search.
+//
+// A workgroup is one utterance: a consumer wave and three worker waves.
+//   * Acoustic rows: a worker loads frame t's logits into registers, forms the softmax there (the
+//     arithmetic of the searches without a model: per-lane strided sums, DPP reduction, reciprocal
+//     with one Newton step) and leaves the NORMALISED row in a three-slot LDS ring, two frames ahead.
+//   * Per frame, the consumer publishes the beam's distinct contexts (prefixes that share their last
+//     token share everything below); the four waves take the contexts in turn: read the context's
+//     factor row (L2: the table is a few MB), mix it with the LDS row, select the sorted list of
+//     the K + K' best tokens (threshold = M-th largest per-lane maximum, compaction, one sort) and
+//     the etab row (the mixed probability at every prefix's last token).
+//   * The consumer then runs the frame routine of ctc_frame.hpp on the per-context lists with the
+//     beam in its registers, prefix histories in the trie (no history copies, no state through
+//     memory), and publishes the next frame's contexts.
+// Per frame and utterance: one frame routine + ceil(D / 4) list selections + one row pass off the
+// critical path, against K' row-sized selections on one wave plus the beam's round trip through a
+// workspace in ctc_lm_step.hip (which keeps serving n-gram orders above two and tables that do not
+// fit).
+#include "ctc_ring.hpp"
+#include "switches.hpp"
+
+namespace pdt {
+
+struct LmTabArgs {
+  CtcArgs c;
+  const float *factors;  // (contexts, V) rows, f_stride floats apart
+  const float *fmax;     // (contexts,) the largest factor of every row
+  int64_t f_stride;
+  int sos_row;           // the row of the empty prefix's context
+  float beta;
+  int valid_mixture;
+};
+
+struct LmTabLayout {
+  int row_floats;  // V + 1 padded to 4
+  int rows_bytes;  // three ring slots
+  int utt_bytes;
+};
+
+constexpr int kLmTabRows = 3, kLmTabWaves = 4;
+
+__host__ __device__ inline LmTabLayout lmtab_layout(int V, int W) {
+  LmTabLayout l;
+  l.row_floats = (V + 1 + 3) & ~3;
+  l.rows_bytes = l.row_floats * 4 * kLmTabRows;
+  const int lists = W * PDT_WAVE * 8, etab = W * W * 4, ctx = 3 * W * 4;
+  const int consumer = 2 * nxt_stride(W) * 4 + W * 4 * 3;
+  l.utt_bytes = (l.rows_bytes + lists + etab + ctx + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + 15) & ~15;  // (64: flags, row_p1)
+  return l;
+}
+
+// NR: 64-element chunks a row takes in registers (V + 1 <= 64 * NR)
+template <int NR>
+__global__ void __launch_bounds__(256, NR <= 16 ? 4 : 2)
+ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const CtcArgs &a = A.c;
+  const int lane = lane_id();
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x);
+  const int V = a.V, W = a.W;
+  float *rows = reinterpret_cast<float *>(smem);
+  int *tl_tok = reinterpret_cast<int *>(smem + ly.rows_bytes);       // [W lists x 64]
+  float *tl_p = reinterpret_cast<float *>(tl_tok + W * PDT_WAVE);     // [W lists x 64]
+  float *etab = tl_p + W * PDT_WAVE;                                  // [W lists x W prefixes]
+  int *ctx_tok = reinterpret_cast<int *>(etab + W * W);               // [W] factor row of every list
+  int *list_id = ctx_tok + W;                                         // [W] the list of every prefix
+  int *lastc_pub = list_id + W;                                       // [W] clamped last token of every prefix
+  unsigned char *cs = reinterpret_cast<unsigned char *>(lastc_pub + W);  // consumer scratch
+  u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
+  int *flags = reinterpret_cast<int *>(surv0 + kLmTabWaves * PDT_SURV_CAP);
+  int *row_ready = flags;      // [3] frame + 1 held by a ring slot
+  int *ctx_pub = flags + 3;    // frames whose contexts are published
+  int *ctx_count = flags + 4;  // lists of the published frame (0: the beam is dead, nothing to build)
+  int *kp_pub = flags + 5;     // prefixes of the published frame
+  int *done = flags + 6;       // [4] frames whose lists a wave has finished
+  float *row_p1 = reinterpret_cast<float *>(flags + 10);  // [3] the largest token probability of a slot's row
+  const int Tn = min(a.S, a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T);
+  const float keep = 1.0f - A.beta;
+
+  if (wave == 0 && lane < 10) __hip_atomic_store(&flags[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  __syncthreads();  // flags initialised (the only workgroup barrier)
+
+  auto ld_flag = [&](int *f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto st_flag = [&](int *f, int v) {
+    wave_sync();
+    if (lane_id() == 0) __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto wait_above = [&](int *f, int v) {
+    while (ld_flag(f) <= v) __builtin_amdgcn_s_sleep(1);
+  };
+
+  // ---- a frame's softmax, normalised, into its ring slot (:1093-1095) ------------------------
+  auto produce_row = [&](const int t) {
+    int lp = lane;
+    asm volatile("" : "+v"(lp));
+    const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn + (int64_t)lp * a.lg_sv;
+    float x[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i * PDT_WAVE <= V) x[i] = lp + i * PDT_WAVE <= V ? row[(int64_t)(i * PDT_WAVE) * a.lg_sv] : -PDT_INF;
+    float mx = -PDT_INF;
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+      if (i * PDT_WAVE <= V) mx = fmax_raw(mx, x[i]);
+    mx = wave_max_f(mx);
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (i * PDT_WAVE <= V) {
+        const bool in = lp + i * PDT_WAVE <= V;
+        x[i] = in ? exp_nonpos(x[i] - mx) : 0.0f;
+        s += x[i];  // (lanes beyond the row add +0: no change)
+      }
+    }
+    s = wave_sum_f(s);
+    const float inv0 = __builtin_amdgcn_rcpf(s);
+    const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+    float *p = rows + (t % kLmTabRows) * ly.row_floats;
+    float p1 = 0.0f;  // the largest token probability AS STORED (the bound of publish() rests on it)
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      if (i * PDT_WAVE <= V && lp + i * PDT_WAVE <= V) {
+        const float pv = a.exact_div ? x[i] / s : x[i] * inv;
+        p[lp + i * PDT_WAVE] = pv;
+        if (lp + i * PDT_WAVE < V) p1 = fmax_raw(p1, pv);
+      }
+    }
+    p1 = wave_max_f(p1);
+    if (lp == 0) row_p1[t % kLmTabRows] = p1;
+    st_flag(&row_ready[t % kLmTabRows], t + 1);
+  };
+
+  // ---- the lists of the published frame this wave is responsible for --------------------------
+  auto build_lists = [&](const int t) {
+    wait_above(ctx_pub, t);
+    const int D = __builtin_amdgcn_readfirstlane(*ctx_count);
+    const int Kp = __builtin_amdgcn_readfirstlane(*kp_pub);
+    if (D > 0) {
+      wait_above(&row_ready[t % kLmTabRows], t);
+      const float *p = rows + (t % kLmTabRows) * ly.row_floats;
+      const int M = ctc_list_len(V, W, Kp);
+      const float scale = 1.0f - p[V];  // (valid mixture: the mass the blank leaves)
+      auto mix = [&](const float pv, const float fv) {
+        return A.valid_mixture ? keep * pv + A.beta * (fv * scale) : pv * fv;
+      };
+      u64 *surv = surv0 + wave * PDT_SURV_CAP;
+      for (int d = wave; d < D; d += kLmTabWaves) {
+        int lp = lane;
+        asm volatile("" : "+v"(lp));
+        const int cw = __builtin_amdgcn_readfirstlane(ctx_tok[d]);
+        const float *frow = A.factors + (int64_t)(cw & ((1 << 30) - 1)) * A.f_stride;
+        if (lp < Kp) {  // the mixed probability at every prefix's last token (merges, last-token streams)
+          const int tok = lastc_pub[lp];
+          etab[d * W + lp] = mix(p[tok], frow[tok]);
+        }
+        if (!(cw >> 30)) continue;  // no prefix of this context can extend into the winners: no list
+        unsigned key[NR];
+        unsigned lmax = 0u;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+          if (i * PDT_WAVE < V) {
+            const int v = lp + i * PDT_WAVE;
+            key[i] = v < V ? fkey_nonneg(mix(p[v], frow[v])) : 0u;
+            lmax = max(lmax, key[i]);
+          }
+        }
+        // sorted top-M of the mixed row (wave_top_sorted's selection on registers)
+        u64 tk;
+        if (V <= PDT_WAVE) {
+          tk = wave_sort_desc<u64>(lp < V ? pack_key(key[0], (unsigned)lp) : 0ull);
+        } else {
+          const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
+          const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+          int count = 0;
+#pragma unroll
+          for (int i = 0; i < NR; ++i) {
+            if (i * PDT_WAVE < V) {
+              const bool pred = key[i] >= tau && key[i] != 0u;
+              const u64 bal = __ballot(pred);
+              if (bal) {
+                const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                if (pred && at < PDT_SURV_CAP) surv[at] = pack_key(key[i], (unsigned)(lp + i * PDT_WAVE));
+                count += __popcll(bal);
+              }
+            }
+          }
+          wave_sync();
+          if (count <= PDT_SURV_CAP) {
+            tk = wave_sort_desc<u64>(lp < count ? surv[lp] : 0ull);
+          } else {  // heavy ties: chunked top-64 merge, the row formed again
+            tk = 0ull;
+            for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
+              const int v = v0 + lp;
+              const unsigned k = v < V ? fkey_nonneg(mix(p[v], frow[v])) : 0u;
+              const bool pred = k >= tau && k != 0u;
+              if (__ballot(pred)) tk = wave_merge_top64(tk, pred ? pack_key(k, (unsigned)v) : 0ull);
+            }
+          }
+          wave_sync();
+        }
+        if (lp < M) {
+          tl_tok[d * PDT_WAVE + lp] = (int)idx_of(tk);
+          tl_p[d * PDT_WAVE + lp] = fkey_nonneg_inv(key_of(tk));
+        }
+      }
+    }
+    st_flag(&done[wave], t + 1);
+  };
+
+  if (wave != 0) {
+    // ---- workers: acoustic rows two frames ahead, lists of every frame -------------------------
+    if (wave - 1 < min(2, Tn)) produce_row(wave - 1);
+    for (int t = 0; t < Tn; ++t) {
+      build_lists(t);
+      if (t + 2 < Tn && 1 + (t + 2) % 3 == wave) produce_row(t + 2);
+    }
+    return;
+  }
+
+  // ---- consumer: the sequential beam update ----------------------------------------------------
+  FrameLds L;
+  L.surv = surv0;
+  L.tl_tok = tl_tok;
+  L.tl_p = tl_p;
+  L.trie_u = a.trie + (int64_t)n * a.T * W;
+  L.nxt_old = reinterpret_cast<int *>(cs);
+  L.nxt_new = L.nxt_old + nxt_stride(W);
+  L.chm = reinterpret_cast<unsigned *>(L.nxt_new + nxt_stride(W));
+  L.info = reinterpret_cast<int *>(L.chm + W);
+  DenseCtx dc{};
+  dc.lists_ready = 1;
+  dc.etab = etab;
+  dc.etab_stride = W;
+  dc.list_id = list_id;
+  Beam bm;  // :1097-1105: one empty prefix with all the mass on "ends in blank"
+  bm.nb = lane == 0 ? 0.0f : -PDT_INF;
+  bm.b = lane == 0 ? 1.0f : -PDT_INF;
+  bm.last = 0;
+  bm.len = 0;
+  bm.node = -1;
+  bm.isp = lane == 0 ? 1u : 0u;
+  bm.origin = lane;
+  int Kp = 1;
+  // The contexts of a beam: prefixes with the same last token (or none) share a list.  A list is only
+  // built for prefixes whose extensions CAN be among the frame's winners: with every beam entry valid,
+  // the K non-extension candidates are K candidates, so the K-th winner is at least the smallest of
+  // them (tau, formed from the masses without the merges' additions: a lower bound of what the frame
+  // computes, float addition and multiplication being monotone); every extension mass of prefix k is at
+  // most tot_k * (largest token probability of the frame mixed with the largest factor of k's row) --
+  // the same float operations on larger operands.  ub_k < tau closes prefix k's extension streams
+  // (DenseCtx::closed).  In blank-dominated frames that leaves a list or two instead of one per context.
+  unsigned closed = 0u;
+  auto publish = [&](const int t) {
+    int lp = lane;
+    asm volatile("" : "+v"(lp));
+    wait_above(&row_ready[t % kLmTabRows], t);
+    const float *p = rows + (t % kLmTabRows) * ly.row_floats;
+    const float tot = bm.nb + bm.b;
+    const bool valid = lp < Kp && tot > -PDT_INF;
+    const int lastc = min(max(bm.last, 0), V - 1);
+    const int c = bm.len > 0 ? lastc : A.sos_row;
+    const bool dead = readlane_f(tot, 0) == 0.0f;  // every mass underflowed: nothing left to decide
+    const float p_blank = p[V], p1 = row_p1[t % kLmTabRows];
+    const float m2_lb = bm.nb * p[lastc] + tot * p_blank;
+    const int n_valid = __popcll(__ballot(valid));
+    const float tau = n_valid >= min(W, Kp * (V + 1)) ? wave_min(valid ? m2_lb : PDT_INF) : 0.0f;
+    const float fm = A.fmax[c];
+    const float ext_max = A.valid_mixture ? keep * p1 + A.beta * (fm * (1.0f - p_blank)) : p1 * fm;
+    const bool open = valid && !(tot * ext_max < tau);
+    closed = (unsigned)__ballot(valid && !open);
+    // (every valid prefix keeps its context's etab row -- a closed prefix still feeds the merges with
+    // its extension masses at its children's tokens; only the LIST is skipped when no prefix of the
+    // context is open: bit 30 of ctx_tok)
+    int leader = lp;
+    bool group_open = false;
+    for (int j = W - 1; j >= 0; --j) {
+      const int cj = __builtin_amdgcn_readlane(c, j);
+      const int fj = __builtin_amdgcn_readlane((int)valid | ((int)open << 1), j);
+      if ((fj & 1) && c == cj) leader = j;
+      group_open = group_open || ((fj & 2) && c == cj);
+    }
+    const u64 leaders = __ballot(valid && leader == lp);
+    const int my_rank = __popcll(leaders & ((1ull << lp) - 1ull));
+    const int id = shfl_i(my_rank, leader);
+    if (lp < W) {
+      list_id[lp] = valid ? id : 0;
+      lastc_pub[lp] = lastc;
+      if (valid && leader == lp) ctx_tok[my_rank] = c | (group_open ? (1 << 30) : 0);
+    }
+    if (lp == 0) {
+      *ctx_count = dead ? 0 : __popcll(leaders);
+      *kp_pub = Kp;
+    }
+    st_flag(ctx_pub, t + 1);
+  };
+  if (Tn > 0) publish(0);
+  for (int t = 0; t < Tn; ++t) {
+    build_lists(t);
+    for (int w = 1; w < kLmTabWaves; ++w) wait_above(&done[w], t);
+    const float *p = rows + (t % kLmTabRows) * ly.row_floats;
+    int ns, nt_, nk;
+    if (!(readlane_f(bm.nb + bm.b, 0) == 0.0f)) {
+      dc.closed = closed;
+      ctc_frame<true, false, true>(bm, p, 1.0f, V, W, Kp, t, n, a, dc, L, ns, nt_, nk PDT_STAMP_ARG);
+      int *tmp = L.nxt_old;
+      L.nxt_old = L.nxt_new;
+      L.nxt_new = tmp;
+      Kp = W;
+    }
+    if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
+      const int c = ((t + 1) >> a.ckpt_shift) - 1;
+      if (lane < W)
+        a.ckpt[((int64_t)n * a.ckpt_count + c) * W + lane] = make_int2(bm.node, bm.len | (bm.origin << 24));
+      bm.origin = lane;
+    }
+    if (t + 1 < Tn) publish(t + 1);
+  }
+
+  // ---- outputs (:1188-1200): probabilities, lengths, and the prefixes read off the trie ------
+  if (lane < W) {
+    a.y_probs[n * W + lane] = bm.nb + bm.b;
+    a.y_lens[n * W + lane] = bm.len;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  {
+    // the walk of ctc_search.hip: checkpoint table in the freed row ring (the workers have left)
+    const int C = Tn >> a.ckpt_shift;
+    int2 *tab = reinterpret_cast<int2 *>(smem);  // [(C + 1) x W]: fits, see launch_ctc_lm_table
+    wave_sync();
+    if (lane < W) {
+      const bool ok = bm.node >= 0;
+      tab[C * W + lane] = make_int2(bm.node, bm.len);
+      int cur = bm.origin;
+      for (int c = C - 1; c >= 0; --c) {
+        const int2 *rec = a.ckpt + (((int64_t)n * a.ckpt_count + c) * W + cur);
+        const int nd = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int lo = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tab[c * W + lane] = ok ? make_int2(nd, lo & 0xFFFFFF) : make_int2(-1, 0);
+        cur = lo >> 24;
+      }
+    }
+    wave_sync();
+    for (int sg = lane; sg < (C + 1) * W; sg += PDT_WAVE) {
+      const int c = sg / W, k = sg - c * W;
+      const int2 top = tab[sg];
+      const int stop = c > 0 ? tab[sg - W].y : 0;
+      int node = top.x;
+      for (int ps = top.y - 1; ps >= stop && node >= 0; --ps) {
+        const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
+        const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.y[((int64_t)ps * a.N + n) * W + k] = tok;
+        node = par;
+      }
+    }
+    int lmin = lane < W ? bm.len : 0x7fffffff;
+    for (int off = 32; off > 0; off >>= 1) lmin = min(lmin, shfl_i(lmin, lane ^ off));
+    for (int f = lmin * W + lane; f < a.S * W; f += PDT_WAVE) {
+      const int ps = f / W, k = f - ps * W;
+      if (ps >= tab[C * W + k].y) a.y[((int64_t)ps * a.N + n) * W + k] = 0;
+    }
+  }
+}
+
+template <int NR>
+static int launch_lm_table(const LmTabArgs &A, const LmTabLayout &ly, hipStream_t stream) {
+  const size_t smem = (size_t)ly.utt_bytes;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_lm_table_kernel<NR>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL((ctc_lm_table_kernel<NR>), dim3((unsigned)A.c.N), dim3(256), smem, stream, A, ly);
+  return (int)hipGetLastError();
+}
+
+}  // namespace pdt
+
+extern "C" {
+
+static int64_t lm_table_trie_bytes(int64_t T, int64_t N, int64_t width) {
+  return ((T + T / 32 + 1) * N * width * (int64_t)sizeof(int2) + 255) & ~(int64_t)255;
+}
+
+int64_t pdt_ctc_lm_table_search_workspace_bytes(int64_t T, int64_t N, int64_t V, int64_t width) {
+  if (T < 0 || N < 0 || V < 1 || width < 1) return 0;
+  return lm_table_trie_bytes(T, N, width) + 16;
+}
+
+int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st, int64_t lg_sn,
+                            int64_t lg_sv, const int64_t *lens, int64_t width, int64_t S, const float *factors,
+                            const float *factor_max, int64_t contexts, int64_t f_stride, int64_t sos_row, float beta,
+                            int valid_mixture,
+                            int64_t *y, int64_t *y_lens, float *y_probs, void *workspace, void *stream) {
+  using namespace pdt;
+  if (T < 0 || N < 0 || V < 1 || width < 1 || S < 0 || contexts < 1 || f_stride < V) return PDT_E_ARG;
+  if (sos_row < 0 || sos_row >= contexts || contexts < V) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!y_lens || !y_probs || !factors || !factor_max || (T > 0 && (!logits || !workspace)) || (S > 0 && !y)) return PDT_E_ARG;
+  if (width > kMaxWidth || V + 1 > 80 * PDT_WAVE) return PDT_E_TOO_LONG;
+  if (T * width >= (1ll << 31) || N >= (1ll << 31) || T >= (1 << 24)) return PDT_E_TOO_LONG;
+  LmTabArgs A{};
+  CtcArgs &a = A.c;
+  a.logits = logits; a.lg_st = lg_st; a.lg_sn = lg_sn; a.lg_sv = lg_sv;
+  a.lens = lens;
+  a.T = (int)T; a.N = (int)N; a.V = (int)V; a.W = (int)width; a.S = (int)S;
+  a.y = y; a.y_lens = y_lens; a.y_probs = y_probs;
+  a.trie = reinterpret_cast<int2 *>(workspace);
+  a.ckpt = a.trie + T * N * width;
+  a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
+  A.factors = factors; A.fmax = factor_max; A.f_stride = f_stride; A.sos_row = (int)sos_row; A.beta = beta; A.valid_mixture = valid_mixture;
+  const LmTabLayout ly = lmtab_layout((int)V, (int)width);
+  if ((size_t)ly.utt_bytes > 160 * 1024) return PDT_E_TOO_LONG;
+  int sh = 5;  // checkpoint spacing: the (C + 1) x W table of the output walk overlays the row ring
+  while (((size_t)(T >> sh) + 1) * width * sizeof(int2) > (size_t)ly.rows_bytes) ++sh;
+  a.ckpt_shift = sh;
+  a.ckpt_count = (int)(T >> sh) + 1;
+  const int chunks = (int)((V + 1 + PDT_WAVE - 1) / PDT_WAVE);
+  if (chunks <= 8) return launch_lm_table<8>(A, ly, (hipStream_t)stream);
+  if (chunks <= 16) return launch_lm_table<16>(A, ly, (hipStream_t)stream);
+  if (chunks <= 32) return launch_lm_table<32>(A, ly, (hipStream_t)stream);
+  if (chunks <= 48) return launch_lm_table<48>(A, ly, (hipStream_t)stream);
+  return launch_lm_table<80>(A, ly, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -79,6 +79,12 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _F, _INT]
         + [_P, _P, _P, _P, _P, _I64, _P],
     ),
+    "pdt_lm_factor_table": (_INT, [_P, _I64, _I64, _F, _INT, _P, _I64, _P]),
+    "pdt_ctc_lm_table_search_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),
+    "pdt_ctc_lm_table_search": (
+        _INT,
+        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, _I64, _I64, _F, _INT, _P, _P, _P, _P, _P],
+    ),
     "pdt_beam_search_step": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]

@@ -640,6 +640,46 @@ class CTCPrefixSearch(torch.nn.Module):
                 _cabi.check(rc, "pdt_ctc_lookup_lm_search")
         return y, y_lens, nb + b
 
+    @torch.jit.unused
+    def _searches_through_a_factor_table(self, logits: torch.Tensor) -> bool:
+        """A bigram LookupLanguageModel whose (contexts, V) factor table stays in the Infinity Cache:
+        the search of csrc/ctc_lm_table.hip (PDT_CTC_LM_TABLE=0: the other routes, for comparisons)."""
+        lm = self.lm
+        if not switches.get("PDT_CTC_LM_TABLE") or not self._fuses_lookup_lm(logits) or lm.max_ngram != 2:
+            return False
+        V = lm.vocab_size
+        return V + 1 <= 80 * 64 and (V + 1) * V * 4 <= _FACTOR_TABLE_MAX_BYTES and logits.dtype == torch.float
+
+    @torch.jit.unused
+    def _lm_table_search(
+        self, logits: torch.Tensor, lens: Optional[torch.Tensor], n_frames: int
+    ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The whole search in one launch, the softmax of the logits included, the model's factor rows
+        read from a table (include/pdt_amd.h: pdt_ctc_lm_table_search)."""
+        lm, W = self.lm, self.width
+        T, N, V = logits.size(0), logits.size(1), logits.size(2) - 1
+        device = _cabi.require_hip(logits, lens, *_lm_buffers(lm))
+        logits = _f32(logits)
+        factors, fmax, sos_row = _factor_table(lm, self.beta, self.valid_mixture, device)
+        L = _cabi.lib()
+        with torch.cuda.device(device):
+            y = torch.empty((n_frames, N, W), device=device, dtype=torch.long)
+            y_lens = torch.empty((N, W), device=device, dtype=torch.long)
+            y_probs = torch.empty((N, W), device=device, dtype=torch.float)
+            if N:
+                ws = torch.empty(int(L.pdt_ctc_lm_table_search_workspace_bytes(n_frames, N, V, W)), device=device,
+                                 dtype=torch.uint8)
+                lens_dev = None if lens is None else _i64(lens).contiguous()
+                rc = L.pdt_ctc_lm_table_search(
+                    _cabi.ptr(logits), n_frames, N, V, logits.stride(0), logits.stride(1), logits.stride(2),
+                    _cabi.ptr(lens_dev), W, n_frames, _cabi.ptr(factors), _cabi.ptr(fmax), factors.size(0),
+                    factors.stride(0), sos_row,
+                    float(self.beta), int(self.valid_mixture), _cabi.ptr(y), _cabi.ptr(y_lens), _cabi.ptr(y_probs),
+                    _cabi.ptr(ws), _cabi.stream_ptr(device),
+                )  # fmt: skip
+                _cabi.check(rc, "pdt_ctc_lm_table_search")
+        return y, y_lens, y_probs
+
     def _frame_by_frame(
         self, logits: torch.Tensor, lens: Optional[torch.Tensor], state: Dict[str, torch.Tensor]
     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -656,6 +696,9 @@ class CTCPrefixSearch(torch.nn.Module):
             if lens.size(0) != N:
                 raise RuntimeError("expected dim 0 of lens to be {}, got {}".format(N, lens.size(0)))
             n_frames = min(T, int(lens.max().item())) if N else 0
+        if not torch.jit.is_scripting():
+            if self.lm is not None and self.beta != 0.0 and n_frames > 0 and self._searches_through_a_factor_table(logits):
+                return self._lm_table_search(logits, lens, n_frames)
         probs = logits.softmax(2)
         # beam state: one empty prefix per utterance, all of its mass on "ends in blank"
         nb = torch.zeros((N, 1), device=device, dtype=dtype)
@@ -763,6 +806,48 @@ def _identity_of(*tensors):
 
 # dense tables of bigram LookupLanguageModels, per model object (BeamSearch._bigram_table)
 _BIGRAM_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+# ... and the factor tables of the mixes they have been searched with (_factor_table)
+_FACTOR_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+_FACTOR_TABLE_MAX_BYTES = 256 << 20  # (the table should stay in the Infinity Cache)
+
+
+def _bigram_scores(lm: "LookupLanguageModel", device: torch.device):
+    """``(scores (U, V) float32, sos_row)`` of a bigram model: row ``c`` = its scores after context
+    token ``c`` (the start-of-sequence token's row last when it lies outside the vocabulary) -- one
+    call of the model's own scoring kernel over every context."""
+    V = lm.vocab_size
+    shift = 0 if (0 <= lm.sos < V) else 1
+    with torch.no_grad():
+        toks = torch.arange(V, device=device)
+        if shift:
+            toks = torch.cat([toks, torch.tensor([lm.sos], device=device)])
+        table, _ = lm.calc_idx_log_probs(toks.unsqueeze(0), dict(), torch.tensor(1, device=device))
+    return _f32(table).contiguous(), (lm.sos if shift == 0 else V)
+
+
+def _factor_table(lm: "LookupLanguageModel", beta: float, valid_mixture: bool, device: torch.device):
+    """``(factors (U, V), row maxima (U,), sos_row)``: the model's factor of CTCPrefixSearch's mix for every context token
+    (include/pdt_amd.h: pdt_lm_factor_table), built once per model, mix and device and kept while every
+    trie buffer of the model is the same tensor at the same version (see BeamSearch._bigram_table for
+    what that does not see)."""
+    ident = _identity_of(*_lm_buffers(lm))
+    key = None if ident is None else (ident, str(device), float(beta), bool(valid_mixture))
+    ent = _FACTOR_TABLES.get(lm)
+    if key is not None and ent is not None and ent[0] == key:
+        return ent[1], ent[2], ent[3]
+    scores, sos_row = _bigram_scores(lm, device)
+    U, V = scores.shape
+    factors = torch.empty((U, V), device=device, dtype=torch.float)
+    with torch.cuda.device(device):
+        rc = _cabi.lib().pdt_lm_factor_table(
+            _cabi.ptr(scores), U, V, float(beta), int(valid_mixture), _cabi.ptr(factors), factors.stride(0),
+            _cabi.stream_ptr(device),
+        )
+    _cabi.check(rc, "pdt_lm_factor_table")
+    fmax = factors.max(1)[0].contiguous()
+    if key is not None:
+        _FACTOR_TABLES[lm] = (key, factors, fmax, sos_row)
+    return factors, fmax, sos_row
 
 
 class BeamSearch(torch.nn.Module):
@@ -870,12 +955,8 @@ class BeamSearch(torch.nn.Module):
         ent = _BIGRAM_TABLES.get(lm)
         if key is not None and ent is not None and ent[0] == key:
             return ent[1], ent[2], ent[3]
+        table, _ = _bigram_scores(lm, device)
         with torch.no_grad():
-            toks = torch.arange(V, device=device)
-            if shift:
-                toks = torch.cat([toks, torch.tensor([lm.sos], device=device)])
-            table, _ = lm.calc_idx_log_probs(toks.unsqueeze(0), dict(), torch.tensor(1, device=device))
-            table = _f32(table).contiguous()
             stats = torch.empty((U, 2), device=device, dtype=torch.float)
             with torch.cuda.device(device):
                 rc = _cabi.lib().pdt_row_log_softmax_stats(

@@ -5,7 +5,9 @@ vocabulary, eos / finish_all_paths; and a model WITH state) and (2) the oracle's
 loops (oracle/_search.py, itself pinned to those fixtures on the CPU) at the C3 sample size -- so a
 mistake shared by the host loop and the fused kernels cannot pass: neither is the other's reference.
 
-Routes of CTCPrefixSearch + LookupLanguageModel: "search" = every frame from one library call
+Routes of CTCPrefixSearch + LookupLanguageModel: "table" = the whole search in one launch with a
+bigram model's factor rows read from a table (pdt_ctc_lm_table_search; the default for order two --
+higher orders take "search"), "search" = every frame from one library call
 (pdt_ctc_lookup_lm_search), "frame" = the host's loop around the one-kernel frame
 (pdt_ctc_lookup_lm_advance), "three" = lookup scores -> fusion_ext -> ctc_prefix_search_advance.
 Routes of BeamSearch: "table" = fused iterations reading a bigram model's dense table, "fused" = fused
@@ -22,8 +24,10 @@ from _toy_lm import CounterLM
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
-CTC_ROUTES = {"search": dict(PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=1), "frame": dict(PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=0),
-              "three": dict(PDT_CTC_LM_FUSED=0)}
+CTC_ROUTES = {"table": dict(PDT_CTC_LM_TABLE=1, PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=1),
+              "search": dict(PDT_CTC_LM_TABLE=0, PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=1),
+              "frame": dict(PDT_CTC_LM_TABLE=0, PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=0),
+              "three": dict(PDT_CTC_LM_TABLE=0, PDT_CTC_LM_FUSED=0)}
 BEAM_ROUTES = {"table": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=1), "fused": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=0),
                "loop": dict(PDT_BEAM_FUSED=0)}
 
