@@ -36,6 +36,7 @@ struct LmTabArgs {
   const float *fmax;     // (contexts,) the largest factor of every row
   int64_t f_stride;
   int sos_row;           // the row of the empty prefix's context
+  int contexts;
   float beta;
   int valid_mixture;
 };
@@ -43,18 +44,20 @@ struct LmTabArgs {
 struct LmTabLayout {
   int row_floats;  // V + 1 padded to 4
   int rows_bytes;  // three ring slots
+  int fmax_floats; // the contexts' largest factors, staged once (0: read from the table's side array)
   int utt_bytes;
 };
 
 constexpr int kLmTabRows = 3, kLmTabWaves = 4;
 
-__host__ __device__ inline LmTabLayout lmtab_layout(int V, int W) {
+__host__ __device__ inline LmTabLayout lmtab_layout(int V, int W, int contexts) {
   LmTabLayout l;
+  l.fmax_floats = contexts <= 4096 ? (contexts + 3) & ~3 : 0;  // (16 KB at most: four workgroups share a CU)
   l.row_floats = (V + 1 + 3) & ~3;
   l.rows_bytes = l.row_floats * 4 * kLmTabRows;
   const int lists = W * PDT_WAVE * 8, etab = W * W * 4, ctx = 3 * W * 4;
   const int consumer = 2 * nxt_stride(W) * 4 + W * 4 * 3;
-  l.utt_bytes = (l.rows_bytes + lists + etab + ctx + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + 15) & ~15;  // (64: flags, row_p1)
+  l.utt_bytes = (l.rows_bytes + lists + etab + ctx + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + l.fmax_floats * 4 + 15) & ~15;  // (64: flags, row_p1)
   return l;
 }
 
@@ -84,10 +87,12 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   int *kp_pub = flags + 5;     // prefixes of the published frame
   int *done = flags + 6;       // [4] frames whose lists a wave has finished
   float *row_p1 = reinterpret_cast<float *>(flags + 10);  // [3] the largest token probability of a slot's row
+  float *fmax_lds = reinterpret_cast<float *>(flags + 16);
   const int Tn = min(a.S, a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T);
   const float keep = 1.0f - A.beta;
 
   if (wave == 0 && lane < 10) __hip_atomic_store(&flags[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  for (int i = (int)threadIdx.x; i < ly.fmax_floats && i < A.contexts; i += 256) fmax_lds[i] = A.fmax[i];
   __syncthreads();  // flags initialised (the only workgroup barrier)
 
   auto ld_flag = [&](int *f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -274,7 +279,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
     const float m2_lb = bm.nb * p[lastc] + tot * p_blank;
     const int n_valid = __popcll(__ballot(valid));
     const float tau = n_valid >= min(W, Kp * (V + 1)) ? wave_min(valid ? m2_lb : PDT_INF) : 0.0f;
-    const float fm = A.fmax[c];
+    const float fm = ly.fmax_floats ? fmax_lds[c] : A.fmax[c];  // (LDS: the look-up is on every frame's critical path)
     const float ext_max = A.valid_mixture ? keep * p1 + A.beta * (fm * (1.0f - p_blank)) : p1 * fm;
     const bool open = valid && !(tot * ext_max < tau);
     closed = (unsigned)__ballot(valid && !open);
@@ -418,8 +423,8 @@ int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V
   a.trie = reinterpret_cast<int2 *>(workspace);
   a.ckpt = a.trie + T * N * width;
   a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
-  A.factors = factors; A.fmax = factor_max; A.f_stride = f_stride; A.sos_row = (int)sos_row; A.beta = beta; A.valid_mixture = valid_mixture;
-  const LmTabLayout ly = lmtab_layout((int)V, (int)width);
+  A.factors = factors; A.fmax = factor_max; A.f_stride = f_stride; A.contexts = (int)contexts; A.sos_row = (int)sos_row; A.beta = beta; A.valid_mixture = valid_mixture;
+  const LmTabLayout ly = lmtab_layout((int)V, (int)width, (int)contexts);
   if ((size_t)ly.utt_bytes > 160 * 1024) return PDT_E_TOO_LONG;
   int sh = 5;  // checkpoint spacing: the (C + 1) x W table of the output walk overlays the row ring
   while (((size_t)(T >> sh) + 1) * width * sizeof(int2) > (size_t)ly.rows_bytes) ++sh;

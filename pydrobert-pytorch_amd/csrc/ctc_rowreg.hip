@@ -1,4 +1,4 @@
-// CTC prefix beam search over LONG rows (513 .. 5120 elements): the row of a frame never leaves
+// CTC prefix beam search over LONG rows (320 .. 16 447 tokens): the row of a frame never leaves
 // the registers of the producer wave that read it.
 //
 // Replaces CTCPrefixSearch.forward without a language model (reference _decoding.py:1064-1202;
@@ -331,15 +331,22 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
 
 constexpr int kRowregMaxChunks = 256;
 
-// rows of 513 .. 16 448 elements, beams the one-kernel search holds; PDT_CTC_ROWREG=0 keeps the LDS
+// rows of 320 .. 16 447 tokens, beams the one-kernel search holds; PDT_CTC_ROWREG=0 keeps the LDS
 // rows of ctc_search.hip (comparisons)
 bool ctc_rowreg_applies(int V, int W) {
   const int mode = switches().ctc_rowreg;
-  return mode != 0 && W >= 1 && W <= kMaxWidth && V + 1 > 8 * PDT_WAVE && V / PDT_WAVE <= kRowregMaxChunks;
+  // From five token chunks on (V >= 320): below, the one-producer form of ctc_search.hip -- short exact
+  // lists the consumer completes on demand, position tables built by the producer, the chunk count a
+  // compile-time constant for V = 256 .. 319 -- is faster (V = 256: 2.13 ms against 2.69; V = 320: 2.71
+  // against 2.62; V = 511: 3.26 against 2.74; N = 4096, T = 512).  =2: from two chunks on (comparisons).
+  const int lo = mode >= 2 ? 2 : 5;
+  return mode != 0 && W >= 1 && W <= kMaxWidth && V / PDT_WAVE >= lo && V / PDT_WAVE <= kRowregMaxChunks;
 }
 
 // (one producer per utterance, two utterances per workgroup, was 35 % slower at V = 5000 and 2x at
 // V = 1000: a lone producer cannot keep a frame's latency off its consumer)
+// (... and for rows of 200-384 tokens: 2.38-2.67 ms against the three-producer form's 2.56-2.74 and the
+// LDS-row form's 2.11 at V = 200-256, N = 4096, T = 512)
 RowregLayout plan_ctc_rowreg(int V, int W) { return rowreg_layout(V, W, 4, 1, 3); }
 
 // register chunks of the instantiation that serves rows of V tokens (launch_rowreg_nr's table)

@@ -11,7 +11,7 @@ struct Switches {
   int oc_bitpar;       // PDT_OC_BITPAR      1  bit-parallel optimal-completion mask (0: row-synchronous kernel)
   int oc_waves;        // PDT_OC_WAVES       0  waves per workgroup of the expansion kernel (0: by shape; 4 or 8)
   int ctc_exact_div;   // PDT_CTC_EXACT_DIV  0  probabilities as the IEEE quotient e / sum (1) instead of e * (1 / sum)
-  int ctc_rowreg;      // PDT_CTC_ROWREG     1  long rows of the CTC search held in the producers' registers (0: LDS ring of rows)
+  int ctc_rowreg;      // PDT_CTC_ROWREG     1  rows of 320+ tokens of the CTC search held in the producers' registers (0: LDS ring of rows; 2: from 128 tokens)
   int step_wide;       // PDT_STEP_WIDE      0  step functions always on the radix-select kernels (1)
   int lm_cache;        // PDT_LM_CACHE       1  n-gram search: bigram factor rows kept per context (0: scored per frame)
   int lm_persistent;   // PDT_LM_PERSISTENT  1  n-gram search: every frame in one launch (0: a launch per frame)
