@@ -1,8 +1,11 @@
 // Issue cost of single VALU instruction kinds on gfx950 with 4 waves per SIMD (every CU busy):
-// ns per wave64 instruction per SIMD, relative to v_add_u32.
+// ns per wave64 instruction per SIMD, relative to v_add_u32 -- and in shader CYCLES: every kernel stamps
+// s_memtime (shader clock) and s_memrealtime (100 MHz) around its loop, the in-kernel clock is their
+// ratio (MI355X_MICROARCH.md, DVFS give-back item 6), cycles = ns x that clock.
 //   hipcc --offload-arch=gfx950 -O3 valu_cost.hip -o valu_cost && ./valu_cost
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <algorithm>
 
 #define REP8(X) X(a0) X(a1) X(a2) X(a3) X(a4) X(a5) X(a6) X(a7)
 
@@ -104,15 +107,18 @@
 #define K_MOV_DPP_BC(r) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:0" : "=v"(r) : "v"(b0));
 
 #define KERNEL(NAME, K)                                                                     \
-  __global__ void NAME(unsigned *out, int iters) {                                          \
+  __global__ void NAME(unsigned *out, int iters, unsigned long long *stamps) {              \
     unsigned a0 = threadIdx.x, a1 = a0 * 3 + 1, a2 = a0 * 5 + 2, a3 = a0 * 7 + 3, a4 = a0 + 11, a5 = a0 + 13, \
              a6 = a0 + 17, a7 = a0 + 19, b0 = a0 ^ 0x55, b1 = a0 ^ 0x33, s0 = 7;           \
     unsigned long long sm = 0x5555, sm2 = 0x3333, pa0 = a0, pa1 = a1, pa2 = a2, pa3 = a3, pa4 = a4, pa5 = a5, pa6 = a6, pa7 = a7, pb0 = b0, pb1 = b1; \
     asm volatile("" : "+v"(pa0), "+v"(pa1), "+v"(pa2), "+v"(pa3), "+v"(pa4), "+v"(pa5), "+v"(pa6), "+v"(pa7), "+v"(pb0), "+v"(pb1));                                            \
     asm volatile("" : "+s"(sm), "+s"(sm2), "+s"(s0));                                       \
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime(); \
     for (int i = 0; i < iters; ++i) {                                                        \
       REP8(K) REP8(K) REP8(K) REP8(K) REP8(K) REP8(K) REP8(K) REP8(K)                         \
     }                                                                                        \
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime(); \
+    if (threadIdx.x == 0) { stamps[2 * blockIdx.x] = c1 - c0; stamps[2 * blockIdx.x + 1] = r1 - r0; } \
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + s0 + (unsigned)sm + (unsigned)(pa0 + pa1 + pa2 + pa3 + pa4 + pa5 + pa6 + pa7); \
   }
 
@@ -135,22 +141,28 @@ LIST(DEF)
 int main() {
   unsigned *out;
   if (hipMalloc(&out, 256 * 1024 * 4) != hipSuccess) return 1;
+  unsigned long long *stamps, hst[512];
+  if (hipMalloc(&stamps, sizeof(hst)) != hipSuccess) return 1;
   const int iters = 1000;
   double base = 0;
 #define RUN(n, k)                                                                                  \
   for (int wps : {1, 4}) {                                                                         \
     hipEvent_t e0, e1;                                                                              \
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);                                           \
-    kern_##n<<<256, 256 * wps>>>(out, iters);                                                       \
+    kern_##n<<<256, 256 * wps>>>(out, iters, stamps);                                               \
     (void)hipEventRecord(e0);                                                                       \
-    kern_##n<<<256, 256 * wps>>>(out, iters);                                                       \
+    kern_##n<<<256, 256 * wps>>>(out, iters, stamps);                                               \
     (void)hipEventRecord(e1);                                                                       \
     (void)hipDeviceSynchronize();                                                                   \
     float ms;                                                                                       \
     (void)hipEventElapsedTime(&ms, e0, e1);                                                         \
     const double ns = ms * 1e6 / ((double)iters * 64 * wps);                                        \
+    (void)hipMemcpy(hst, stamps, sizeof(hst), hipMemcpyDeviceToHost);                               \
+    double ghz[256];                                                                                \
+    for (int b = 0; b < 256; ++b) ghz[b] = (double)hst[2 * b] / (double)hst[2 * b + 1] * 0.1;         \
+    std::sort(ghz, ghz + 256);                                                                      \
     if (wps == 4 && base == 0) base = ns;                                                           \
-    printf("%-16s waves/SIMD %d: %6.3f ns per instruction per SIMD%s\n", #n, wps, ns, wps == 4 ? "" : "  (one wave alone)"); \
+    printf("%-16s waves/SIMD %d: %6.3f ns per instruction per SIMD = %5.2f cycles at the %.3f GHz the kernel ran at%s\n", #n, wps, ns, ns * ghz[128], ghz[128], wps == 4 ? "" : "  (one wave alone)"); \
     if (wps == 4) printf("%-16s   relative to v_add_u32: %.2f\n", #n, ns / base);                   \
   }
   LIST(RUN)

@@ -102,6 +102,11 @@ struct DenseCtx {
   // every extension mass of k lies below a lower bound of the K-th winner) -- its extension streams
   // are closed and its list is not read for candidates (it need not have been built)
   unsigned closed = 0u;
+  // lpos[r * lpos_stride + j] = position of prefix j's (clamped) last token in list r, -1 if it is
+  // not among the list's entries -- built with the lists by a caller that knows the prefixes' last
+  // tokens (null: the frame searches the lists, M reads per look-up)
+  const int *lpos = nullptr;
+  int lpos_stride = 0;
 };
 
 // ints per next-token table: W * W, but at least 128 so that the table not in use (nxt_new
@@ -257,6 +262,8 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     if (!DENSE) {
       const int q = L.pos[lastc];
       jl = q == 0xFF ? -1 : q;
+    } else if (dc.lpos) {
+      jl = dc.lpos[my_list * dc.lpos_stride + me];
     } else {
       for (int j = 0; j < M; ++j) jl = mt[j] == lastc ? j : jl;
     }
@@ -284,7 +291,8 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       const int list_kk = list_of(kk);
       if (DENSE) {
         jc = -1;
-        for (int j = 0; j < M; ++j) jc = L.tl_tok[list_kk * PDT_WAVE + j] == lastc ? j : jc;
+        if (dc.lpos) jc = dc.lpos[list_kk * dc.lpos_stride + me];
+        else for (int j = 0; j < M; ++j) jc = L.tl_tok[list_kk * PDT_WAVE + j] == lastc ? j : jc;
       }
       if (accumulate) {
         const float nb_kk = readlane_f(bm.nb, kk), b_kk = readlane_f(bm.b, kk);

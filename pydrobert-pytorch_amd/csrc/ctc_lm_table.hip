@@ -50,12 +50,27 @@ struct LmTabLayout {
 
 constexpr int kLmTabRows = 3, kLmTabWaves = 4;
 
+// Diagnostic build only (-DPDT_LMTAB_STAMPS): shader cycles of the consumer wave by segment, summed over
+// frames and utterances (profiles/tools/stamps_lm_table.py): 0 own lists, 1 waiting for the workers'
+// lists, 2 the frame routine, 3 publishing the next frame's contexts (its wait for the row included)
+#ifdef PDT_LMTAB_STAMPS
+__device__ unsigned long long g_lmtab_stamps[8];
+#define LMTAB_STAMP(i)                                            \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime(); \
+    acc_[i] += now_ - last_;                                      \
+    last_ = now_;                                                 \
+  } while (0)
+#else
+#define LMTAB_STAMP(i) do {} while (0)
+#endif
+
 __host__ __device__ inline LmTabLayout lmtab_layout(int V, int W, int contexts) {
   LmTabLayout l;
   l.fmax_floats = contexts <= 4096 ? (contexts + 3) & ~3 : 0;  // (16 KB at most: four workgroups share a CU)
   l.row_floats = (V + 1 + 3) & ~3;
   l.rows_bytes = l.row_floats * 4 * kLmTabRows;
-  const int lists = W * PDT_WAVE * 8, etab = W * W * 4, ctx = 3 * W * 4;
+  const int lists = W * PDT_WAVE * 8, etab = 2 * W * W * 4, ctx = 3 * W * 4;  // (etab + lpos)
   const int consumer = 2 * nxt_stride(W) * 4 + W * 4 * 3;
   l.utt_bytes = (l.rows_bytes + lists + etab + ctx + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + l.fmax_floats * 4 + 15) & ~15;  // (64: flags, row_p1)
   return l;
@@ -75,7 +90,8 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   int *tl_tok = reinterpret_cast<int *>(smem + ly.rows_bytes);       // [W lists x 64]
   float *tl_p = reinterpret_cast<float *>(tl_tok + W * PDT_WAVE);     // [W lists x 64]
   float *etab = tl_p + W * PDT_WAVE;                                  // [W lists x W prefixes]
-  int *ctx_tok = reinterpret_cast<int *>(etab + W * W);               // [W] factor row of every list
+  int *lpos = reinterpret_cast<int *>(etab + W * W);                  // [W lists x W prefixes] see DenseCtx::lpos
+  int *ctx_tok = lpos + W * W;                                        // [W] factor row of every list
   int *list_id = ctx_tok + W;                                         // [W] the list of every prefix
   int *lastc_pub = list_id + W;                                       // [W] clamped last token of every prefix
   unsigned char *cs = reinterpret_cast<unsigned char *>(lastc_pub + W);  // consumer scratch
@@ -159,6 +175,9 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
         return A.valid_mixture ? keep * pv + A.beta * (fv * scale) : pv * fv;
       };
       u64 *surv = surv0 + wave * PDT_SURV_CAP;
+#ifdef PDT_LMTAB_TWICE  // timing experiment (same results): every list built twice
+      for (int rep = 0; rep < 2; ++rep)
+#endif
       for (int d = wave; d < D; d += kLmTabWaves) {
         int lp = lane;
         asm volatile("" : "+v"(lp));
@@ -168,7 +187,11 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
           const int tok = lastc_pub[lp];
           etab[d * W + lp] = mix(p[tok], frow[tok]);
         }
-        if (!(cw >> 30)) continue;  // no prefix of this context can extend into the winners: no list
+        if (!(cw >> 30)) {  // no prefix of this context can extend into the winners: no list
+          if (lp < Kp) lpos[d * W + lp] = -1;
+          continue;
+        }
+
         unsigned key[NR];
         unsigned lmax = 0u;
 #pragma unroll
@@ -213,9 +236,15 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
           }
           wave_sync();
         }
+        const int my_tok = lp < M ? (int)idx_of(tk) : -1;
         if (lp < M) {
-          tl_tok[d * PDT_WAVE + lp] = (int)idx_of(tk);
+          tl_tok[d * PDT_WAVE + lp] = my_tok;
           tl_p[d * PDT_WAVE + lp] = fkey_nonneg_inv(key_of(tk));
+        }
+        // where every prefix's last token sits in this list (the frame's index look-ups)
+        for (int j = 0; j < Kp; ++j) {
+          const u64 hit = __ballot(my_tok == lastc_pub[j]);
+          if (lp == 0) lpos[d * W + j] = hit ? (int)__builtin_ctzll(hit) : -1;
         }
       }
     }
@@ -247,6 +276,8 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   dc.etab = etab;
   dc.etab_stride = W;
   dc.list_id = list_id;
+  dc.lpos = lpos;
+  dc.lpos_stride = W;
   Beam bm;  // :1097-1105: one empty prefix with all the mass on "ends in blank"
   bm.nb = lane == 0 ? 0.0f : -PDT_INF;
   bm.b = lane == 0 ? 1.0f : -PDT_INF;
@@ -309,9 +340,14 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
     st_flag(ctx_pub, t + 1);
   };
   if (Tn > 0) publish(0);
+#ifdef PDT_LMTAB_STAMPS
+  unsigned long long acc_[4] = {0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
+#endif
   for (int t = 0; t < Tn; ++t) {
     build_lists(t);
+    LMTAB_STAMP(0);
     for (int w = 1; w < kLmTabWaves; ++w) wait_above(&done[w], t);
+    LMTAB_STAMP(1);
     const float *p = rows + (t % kLmTabRows) * ly.row_floats;
     int ns, nt_, nk;
     if (!(readlane_f(bm.nb + bm.b, 0) == 0.0f)) {
@@ -328,8 +364,14 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
         a.ckpt[((int64_t)n * a.ckpt_count + c) * W + lane] = make_int2(bm.node, bm.len | (bm.origin << 24));
       bm.origin = lane;
     }
+    LMTAB_STAMP(2);
     if (t + 1 < Tn) publish(t + 1);
+    LMTAB_STAMP(3);
   }
+#ifdef PDT_LMTAB_STAMPS
+  if (lane == 0)
+    for (int i = 0; i < 4; ++i) atomicAdd(&g_lmtab_stamps[i], acc_[i]);
+#endif
 
   // ---- outputs (:1188-1200): probabilities, lengths, and the prefixes read off the trie ------
   if (lane < W) {
@@ -439,3 +481,14 @@ int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V
 }
 
 }  // extern "C"
+
+#ifdef PDT_LMTAB_STAMPS
+extern "C" int pdt_debug_read_lmtab_stamps(unsigned long long *host8, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host8, HIP_SYMBOL(pdt::g_lmtab_stamps), sizeof(unsigned long long) * 8);
+  if (e == hipSuccess && reset) {
+    unsigned long long z[8] = {0};
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_lmtab_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
