@@ -16,6 +16,7 @@
 #include <type_traits>
 
 #include "pdt_common.hpp"
+#include "switches.hpp"
 
 namespace pdt {
 
@@ -796,6 +797,128 @@ __global__ void __launch_bounds__(256) sparse_warp_fast_kernel(const WarpArgs a)
   }
 }
 
+// The same call shape with a lane = one COLUMN of a band of four rows: the four pixels (h .. h + 3, w)
+// share x, so a centre's dx, dx^2 and the x part of the affine term are formed once per lane, the
+// pixel -> (h, w) split once instead of four times, and the four chains are written as two float2
+// chains (v_pk_add / v_pk_mul / v_pk_fma carry two pixels per instruction; v_log_f32 stays scalar).
+// A wave's lanes are consecutive columns (bands flattened with their columns: lane order = memory
+// order within a row), so each of the four row-rounds of taps and stores is coalesced.  Taps are
+// buffer loads: the plane's base in scalar registers, a 32-bit byte offset per lane.
+typedef float wf2 __attribute__((ext_vector_type(2)));
+template <int ORDER>
+__device__ __forceinline__ wf2 phi2_from_d2(const wf2 d2, const int order) {
+  if (ORDER == 2) {  // (phi_from_d2's order-2 form, two at a time)
+    const wf2 t = d2 + wf2{1e-37f, 1e-37f};
+    const wf2 l = {__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
+    return d2 * (l * wf2{0.34657359f, 0.34657359f});
+  }
+  return wf2{phi_from_d2<ORDER>(d2.x, order), phi_from_d2<ORDER>(d2.y, order)};
+}
+
+// MC: centres the spline loop runs over, unconditionally -- a compile-time count (with a run-time
+// guard per centre the compiler re-rolls the loop and moves the centres through registers by index).
+// Calls with fewer centres pad with zero weights: fma(phi, 0, s) = s exactly, phi finite everywhere.
+template <int ORDER, int PADDING, int MC>
+__global__ void __launch_bounds__(256) sparse_warp_bands_kernel(const WarpArgs a) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  float *lk = reinterpret_cast<float *>(smem);
+  float *lw = lk + 2 * a.M;
+  const int64_t n = blockIdx.y;
+  const int H = a.H, W = a.W, M = a.M;
+  for (int i = (int)threadIdx.x; i < 2 * M; i += 256) lk[i] = a.knots[n * 2 * M + i];
+  for (int i = (int)threadIdx.x; i < 2 * (M + 3); i += 256) lw[i] = a.wv[n * 2 * (M + 3) + i];
+  __syncthreads();
+  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  float kx[MC], ky[MC], wx[MC], wy[MC];
+#pragma unroll
+  for (int m = 0; m < MC; ++m) {
+    const bool in = m < M;
+    kx[m] = uni(in ? lk[2 * m] : 0.0f);
+    ky[m] = uni(in ? lk[2 * m + 1] : 0.0f);
+    wx[m] = uni(in ? lw[2 * m] : 0.0f);
+    wy[m] = uni(in ? lw[2 * m + 1] : 0.0f);
+  }
+  const float ax = uni(lw[2 * M]), ay = uni(lw[2 * M + 1]), bx = uni(lw[2 * (M + 1)]), by = uni(lw[2 * (M + 1) + 1]);
+  const float cx = uni(lw[2 * (M + 2)]), cy = uni(lw[2 * (M + 2) + 1]);
+  const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
+  const int HW = H * W, bands = (H + 3) >> 2;
+  // (one column per lane: four columns per lane, amortising the set-up above, measured the same)
+  const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (idx >= bands * W) return;  // (no barrier below)
+  int band = (int)(((float)idx + 0.5f) * inv_w), w = idx - band * W;  // (bands * W < 2^23: checked by the launcher)
+  if (w < 0) { --band; w += W; }
+  if (w >= W) { ++band; w -= W; }
+  const int h0 = band * 4;
+  const float x = (float)w, yb = (float)h0;
+  const wf2 y01 = {yb, yb + 1.0f}, y23 = {yb + 2.0f, yb + 3.0f};
+  // spline: the affine part, then the centres
+  const float axc = __builtin_fmaf(ax, x, cx), ayc = __builtin_fmaf(ay, x, cy);
+  wf2 sx01 = __builtin_elementwise_fma(y01, wf2{bx, bx}, wf2{axc, axc}), sx23 = __builtin_elementwise_fma(y23, wf2{bx, bx}, wf2{axc, axc});
+  wf2 sy01 = __builtin_elementwise_fma(y01, wf2{by, by}, wf2{ayc, ayc}), sy23 = __builtin_elementwise_fma(y23, wf2{by, by}, wf2{ayc, ayc});
+#pragma unroll
+  for (int m = 0; m < MC; ++m) {
+    const float dx = x - kx[m], dx2 = dx * dx;
+    const wf2 dy01 = y01 - wf2{ky[m], ky[m]}, dy23 = y23 - wf2{ky[m], ky[m]};
+    const wf2 p01 = phi2_from_d2<ORDER>(__builtin_elementwise_fma(dy01, dy01, wf2{dx2, dx2}), a.order);
+    const wf2 p23 = phi2_from_d2<ORDER>(__builtin_elementwise_fma(dy23, dy23, wf2{dx2, dx2}), a.order);
+    sx01 = __builtin_elementwise_fma(p01, wf2{wx[m], wx[m]}, sx01);
+    sx23 = __builtin_elementwise_fma(p23, wf2{wx[m], wx[m]}, sx23);
+    sy01 = __builtin_elementwise_fma(p01, wf2{wy[m], wy[m]}, sy01);
+    sy23 = __builtin_elementwise_fma(p23, wf2{wy[m], wy[m]}, sy23);
+  }
+  const float sxs[4] = {sx01.x, sx01.y, sx23.x, sx23.y}, sys[4] = {sy01.x, sy01.y, sy23.x, sy23.y};
+  float ix[4], iy[4], x0f[4], y0f[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float y = yb + (float)j;
+    float gx, gy;
+    if (a.as_grid) {
+      gx = sxs[j];
+      gy = sys[j];
+    } else {
+      gx = (2.0f * x - 2.0f * sxs[j] + 1.0f) * inv_w - 1.0f;  // _img.py:432
+      gy = (2.0f * y - 2.0f * sys[j] + 1.0f) * inv_h - 1.0f;
+    }
+    ix[j] = source_index(gx, W, PADDING);
+    iy[j] = source_index(gy, H, PADDING);
+    x0f[j] = floorf(ix[j]);
+    y0f[j] = floorf(iy[j]);
+  }
+  for (int c = 0; c < a.C; ++c) {
+    const float *pl = a.image + (n * a.C + c) * (int64_t)HW;
+    // (base in scalar registers, 32-bit byte offsets; reads beyond the plane cannot happen: the
+    // offsets are clamped into it)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl), 0, HW * 4, 0x00020000);
+    float t00[4], t01[4], t10[4], t11[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // all the taps in flight (taps outside the image: any valid address)
+      const int x0 = (int)x0f[j], y0 = (int)y0f[j];
+      const int xc0 = PADDING == PAD_ZEROS ? min(max(x0, 0), W - 1) : x0, xc1 = min(max(x0 + 1, 0), W - 1);
+      const int yc0 = (PADDING == PAD_ZEROS ? min(max(y0, 0), H - 1) : y0) * W, yc1 = min(max(y0 + 1, 0), H - 1) * W;
+      t00[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc0 + xc0) << 2, 0, 0);
+      t01[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc0 + xc1) << 2, 0, 0);
+      t10[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc1 + xc0) << 2, 0, 0);
+      t11[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc1 + xc1) << 2, 0, 0);
+    }
+    float *po = a.out + (n * a.C + c) * (int64_t)HW;
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, HW * 4, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int x0 = (int)x0f[j], y0 = (int)y0f[j], x1 = x0 + 1, y1 = y0 + 1;
+      const float wx1 = ix[j] - x0f[j], wy1 = iy[j] - y0f[j], wx0 = (x0f[j] + 1.0f) - ix[j], wy0 = (y0f[j] + 1.0f) - iy[j];
+      const bool vx0 = PADDING != PAD_ZEROS || (x0 >= 0 && x0 < W), vx1 = x1 >= 0 && x1 < W;
+      const bool vy0 = PADDING != PAD_ZEROS || (y0 >= 0 && y0 < H), vy1 = y1 >= 0 && y1 < H;
+      // (a tap outside the image is left out, as image_warp_kernel does -- a select, not a product
+      // with 0: that would turn an inf / NaN pixel into NaN)
+      float acc = (vx0 && vy0) ? __int_as_float(t00[j]) * (wx0 * wy0) : 0.0f;
+      acc += (vx1 && vy0) ? __int_as_float(t01[j]) * (wx1 * wy0) : 0.0f;
+      acc += (vx0 && vy1) ? __int_as_float(t10[j]) * (wx0 * wy1) : 0.0f;
+      acc += (vx1 && vy1) ? __int_as_float(t11[j]) * (wx1 * wy1) : 0.0f;
+      if (h0 + j < H) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc), ro, ((h0 + j) * W + w) << 2, 0, 0);
+    }
+  }
+}
+
 // copy the double solution into float (w, v) laid out (N, M+3, 2) for image_warp_kernel
 __global__ void cast_wv_kernel(const double *__restrict__ wv, float *__restrict__ out, int64_t total) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
@@ -1022,11 +1145,25 @@ static int sparse_warp_launch(const float *image, const float *train_points,
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
   } else if (mode == INTERP_BILINEAR && !flow_out && M <= kWarpFastM && H * W < (1 << 23)) {
-    // several pixels per lane, centres in scalar registers (sparse_warp_fast_kernel)
+    // a lane = a column of four rows, centres in scalar registers (sparse_warp_bands_kernel);
+    // PDT_WARP_BANDS=0: four pixels 256 apart per lane (sparse_warp_fast_kernel, for comparisons)
+    const bool rows4 = switches().warp_bands != 0;
     const int per_wg = 256 * kWarpPix;
-    const dim3 gf((unsigned)((H * W + per_wg - 1) / per_wg), (unsigned)N);
+    const int64_t lanes = ((H + 3) / 4) * W;
+    const dim3 gf(rows4 ? (unsigned)((lanes + 255) / 256) : (unsigned)((H * W + per_wg - 1) / per_wg), (unsigned)N);
     auto go = [&](auto ord) {
       constexpr int O = decltype(ord)::value;
+      if (rows4) {
+        auto bands = [&](auto mc) {
+          constexpr int MC = decltype(mc)::value;
+          if (padding == PAD_BORDER) hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_BORDER, MC>), gf, dim3(256), smem, (hipStream_t)stream, a);
+          else if (padding == PAD_ZEROS) hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_ZEROS, MC>), gf, dim3(256), smem, (hipStream_t)stream, a);
+          else hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_REFLECTION, MC>), gf, dim3(256), smem, (hipStream_t)stream, a);
+        };
+        // (seven centres = three control points + four pinned corners, the SpecAugment-style call)
+        if (M == 7) bands(std::integral_constant<int, 7>{}); else bands(std::integral_constant<int, kWarpFastM>{});
+        return;
+      }
       if (padding == PAD_BORDER) hipLaunchKernelGGL((sparse_warp_fast_kernel<O, PAD_BORDER>), gf, dim3(256), smem, (hipStream_t)stream, a);
       else if (padding == PAD_ZEROS) hipLaunchKernelGGL((sparse_warp_fast_kernel<O, PAD_ZEROS>), gf, dim3(256), smem, (hipStream_t)stream, a);
       else hipLaunchKernelGGL((sparse_warp_fast_kernel<O, PAD_REFLECTION>), gf, dim3(256), smem, (hipStream_t)stream, a);

@@ -15,6 +15,7 @@ struct Switches {
   int step_wide;       // PDT_STEP_WIDE      0  step functions always on the radix-select kernels (1)
   int lm_cache;        // PDT_LM_CACHE       1  n-gram search: bigram factor rows kept per context (0: scored per frame)
   int lm_persistent;   // PDT_LM_PERSISTENT  1  n-gram search: every frame in one launch (0: a launch per frame)
+  int warp_bands;      // PDT_WARP_BANDS     1  sparse_image_warp: a lane = a column of four rows (0: four pixels 256 apart)
   int lm_step_waves;   // PDT_LM_STEP_WAVES  0  waves per utterance of the n-gram frame kernel (0: by shape; 1, 2, 4 or 8)
 };
 
