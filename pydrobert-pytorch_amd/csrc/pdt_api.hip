@@ -66,7 +66,7 @@ const SwitchName kSwitchNames[] = {
     {"PDT_LEV_BITPAR", &Switches::lev_bitpar, 1},       {"PDT_OC_BITPAR", &Switches::oc_bitpar, 1},
     {"PDT_OC_WAVES", &Switches::oc_waves, 0},           {"PDT_CTC_EXACT_DIV", &Switches::ctc_exact_div, 0},
     {"PDT_CTC_ROWREG", &Switches::ctc_rowreg, 1},       {"PDT_STEP_WIDE", &Switches::step_wide, 0},
-    {"PDT_LM_CACHE", &Switches::lm_cache, 1},           {"PDT_LM_PERSISTENT", &Switches::lm_persistent, 1},
+    {"PDT_LM_CACHE", &Switches::lm_cache, 0},           {"PDT_LM_PERSISTENT", &Switches::lm_persistent, 1},
     {"PDT_LM_STEP_WAVES", &Switches::lm_step_waves, 0}, {"PDT_WARP_BANDS", &Switches::warp_bands, 1},
 };
 }  // namespace

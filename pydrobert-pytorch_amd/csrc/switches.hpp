@@ -13,7 +13,9 @@ struct Switches {
   int ctc_exact_div;   // PDT_CTC_EXACT_DIV  0  probabilities as the IEEE quotient e / sum (1) instead of e * (1 / sum)
   int ctc_rowreg;      // PDT_CTC_ROWREG     1  rows of 320+ tokens of the CTC search held in the producers' registers (0: LDS ring of rows; 2: from 128 tokens)
   int step_wide;       // PDT_STEP_WIDE      0  step functions always on the radix-select kernels (1)
-  int lm_cache;        // PDT_LM_CACHE       1  n-gram search: bigram factor rows kept per context (0: scored per frame)
+  int lm_cache;        // PDT_LM_CACHE       0  ctc_lm_step.hip's search: bigram factor rows kept per context across workgroups behind a
+                       //                       relaxed flag (outside the HIP memory model; comparisons only -- bigram models take
+                       //                       ctc_lm_table.hip, whose table is built before the launch)
   int lm_persistent;   // PDT_LM_PERSISTENT  1  n-gram search: every frame in one launch (0: a launch per frame)
   int warp_bands;      // PDT_WARP_BANDS     1  sparse_image_warp: a lane = a column of four rows (0: four pixels 256 apart)
   int lm_step_waves;   // PDT_LM_STEP_WAVES  0  waves per utterance of the n-gram frame kernel (0: by shape; 1, 2, 4 or 8)
