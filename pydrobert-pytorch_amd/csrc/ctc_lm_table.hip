@@ -65,14 +65,18 @@ __device__ unsigned long long g_lmtab_stamps[8];
 #define LMTAB_STAMP(i) do {} while (0)
 #endif
 
+// ints of the per-frame tables between the lists and the consumer's scratch, padded to 16 bytes: the
+// scratch behind them is read and written as 64-bit words (odd widths would leave it 4-byte aligned)
+__host__ __device__ inline int lmtab_small_ints(int W) { return (2 * W * W + 3 * W + 3) & ~3; }
+
 __host__ __device__ inline LmTabLayout lmtab_layout(int V, int W, int contexts) {
   LmTabLayout l;
   l.fmax_floats = contexts <= 4096 ? (contexts + 3) & ~3 : 0;  // (16 KB at most: four workgroups share a CU)
   l.row_floats = (V + 1 + 3) & ~3;
   l.rows_bytes = l.row_floats * 4 * kLmTabRows;
-  const int lists = W * PDT_WAVE * 8, etab = 2 * W * W * 4, ctx = 3 * W * 4;  // (etab + lpos)
+  const int lists = W * PDT_WAVE * 8, small = lmtab_small_ints(W) * 4;  // (small: etab, lpos, ctx_tok, list_id, lastc)
   const int consumer = 2 * nxt_stride(W) * 4 + W * 4 * 3;
-  l.utt_bytes = (l.rows_bytes + lists + etab + ctx + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + l.fmax_floats * 4 + 15) & ~15;  // (64: flags, row_p1)
+  l.utt_bytes = (l.rows_bytes + lists + small + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + l.fmax_floats * 4 + 15) & ~15;  // (64: flags, row_p1)
   return l;
 }
 
@@ -94,7 +98,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   int *ctx_tok = lpos + W * W;                                        // [W] factor row of every list
   int *list_id = ctx_tok + W;                                         // [W] the list of every prefix
   int *lastc_pub = list_id + W;                                       // [W] clamped last token of every prefix
-  unsigned char *cs = reinterpret_cast<unsigned char *>(lastc_pub + W);  // consumer scratch
+  unsigned char *cs = reinterpret_cast<unsigned char *>(etab) + lmtab_small_ints(W) * 4;  // consumer scratch (16-byte aligned)
   u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
   int *flags = reinterpret_cast<int *>(surv0 + kLmTabWaves * PDT_SURV_CAP);
   int *row_ready = flags;      // [3] frame + 1 held by a ring slot
