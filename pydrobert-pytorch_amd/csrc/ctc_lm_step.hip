@@ -10,12 +10,9 @@
 // One workgroup per batch element; the waves take the prefixes in turn; wave 0 runs the frame; all
 // waves copy the histories.  Scores follow lm_lookup.hip operation for operation, the mix follows
 // fusion_ext.hip: the same bits as the three-kernel route.
-#ifndef PDT_LM_TWICE
-#define PDT_LM_TWICE 0  // timing experiments (same results): 1 the cached row read twice, 2 the list selection twice, 4 the frame twice
-#endif
-#ifndef PDT_LMDBG
-#define PDT_LMDBG 0  // timing experiments (results change): skip 2 list selection, 4 the frame, 8 the history copy
-#endif
+// (The timing experiments of round 3 -- a phase run twice with identical results, phases skipped --
+// are described in EXPERIMENTS.md section 9.16; their macro families left the file in round 4.  What
+// stays is the per-phase stamp build, -DPDT_LM_STAMPS.)
 #include <cstdlib>
 
 #include "advance_args.hpp"
@@ -273,9 +270,6 @@ __device__ __forceinline__ void lm_frame(const CtcLmAdvArgs &A, unsigned char *s
       hit = __builtin_amdgcn_readlane(row_state, k) == 2;
     }
     if (hit) {
-#if (PDT_LM_TWICE & 1)
-      for (int rep = 0; rep < 2; ++rep)
-#endif
       for (int v0 = lane; v0 < V; v0 += 8 * PDT_WAVE) {  // (eight loads in flight)
         float f[8];
 #pragma unroll
@@ -324,14 +318,7 @@ __device__ __forceinline__ void lm_frame(const CtcLmAdvArgs &A, unsigned char *s
       const int lj = (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)0), (int64_t)(V - 1));
       etab[k * Kp + lane] = row[lj];
     }
-#if (PDT_LMDBG & 2)
-    const u64 tk = (u64)lane;
-#else
-#if (PDT_LM_TWICE & 2)
-    { const u64 tk0 = wave_top_sorted<false, true>(row, V, M, my_surv, &lmax); asm volatile("" :: "v"(tk0)); wave_sync(); }
-#endif
     const u64 tk = wave_top_sorted<false, true>(row, V, M, my_surv, V > PDT_WAVE ? &lmax : nullptr);
-#endif
     if (lane < M) {
       L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
       L.tl_p[k * PDT_WAVE + lane] = fkey_nonneg_inv(key_of(tk));
@@ -385,20 +372,7 @@ __device__ __forceinline__ void lm_frame(const CtcLmAdvArgs &A, unsigned char *s
 #ifdef PDT_STAMPS
     unsigned pdt_stamp_acc[14] = {0};
 #endif
-#if (PDT_LMDBG & 4)
-    new_src = lane & 15; new_tok = 1; new_kind = 2;
-#else
-#if (PDT_LM_TWICE & 4)
-    {
-      Beam bm2 = bm;
-      int s2, t2, k2;
-      ctc_frame<true>(bm2, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, s2, t2, k2 PDT_STAMP_ARG);
-      asm volatile("" :: "v"(s2), "v"(t2), "v"(k2), "v"(bm2.nb));
-      wave_sync();
-    }
-#endif
     ctc_frame<true>(bm, p, 1.0f, V, W, Kp, 0, n, dummy, dc, L, new_src, new_tok, new_kind PDT_STAMP_ARG);
-#endif
 
     // ---- outputs (:855-934) --------------------------------------------------------------
     if (lane < W) {
@@ -423,9 +397,6 @@ __device__ __forceinline__ void lm_frame(const CtcLmAdvArgs &A, unsigned char *s
   // host's frame loop keeps them as (N, K, S) int16: yp_ss = yn_ss = 1) move 16 bytes at a time --
   // a column of the new beam is a plain copy of its source's column; the (S, N, K) layout of the
   // step functions is a permutation inside every row and goes token by token.
-#if (PDT_LMDBG & 8)
-  return;
-#endif
   if (slots) {
     // the new beam's slots: survivors keep theirs, extensions take the slots that were free before the
     // frame in rank order (2 W slots, at most W of them in use: there are always enough)
