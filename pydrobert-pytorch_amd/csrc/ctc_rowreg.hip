@@ -22,6 +22,8 @@
 // An utterance takes ~11 KB of LDS at V = 5000, so the residency is set by the registers: 128 per
 // lane (80 of them the row) = four waves per SIMD, every CU holding four utterances x (three
 // producers + consumer).
+#include <type_traits>
+
 #include "ctc_ring.hpp"
 #include "switches.hpp"
 
@@ -119,13 +121,21 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       const bool in_row = lp <= rem, is_tok = lp < rem;
       const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
       // ---- pass A: per-lane maximum over the tokens; with the blank, the row maximum ---------
-      float lmx = is_tok ? rt : -PDT_INF;
+      float lmx = is_tok ? rt : -PDT_INF, lmn = in_row ? rt : PDT_INF;
 #pragma unroll
       for (int i = 0; i < NR; i += 2) {
-        if (i + 1 < NF || i + 1 < nt) lmx = fmax3_raw(lmx, r[i], r[i + 1]);
-        else if (i < nt) lmx = fmax_raw(lmx, r[i]);
+        if (i + 1 < NF || i + 1 < nt) {
+          lmx = fmax3_raw(lmx, r[i], r[i + 1]);
+          lmn = fmin3_raw(lmn, r[i], r[i + 1]);
+        } else if (i < nt) {
+          lmx = fmax_raw(lmx, r[i]);
+          lmn = fmin3_raw(lmn, r[i], r[i]);
+        }
       }
       const float mx = wave_max_f(lp == rem ? fmax_raw(lmx, rt) : lmx);
+      // A TAME row -- every element within 86 of the maximum, i.e. every numerator a normal float32 --
+      // takes exp_tame2 below; rows with masked (-inf) or far-off elements the general routine
+      const bool tame = wave_min(lmn) - mx >= -86.0f;
       // ---- pass B: the tokens that can be among the M best -----------------------------------
       // The list is ordered by (numerator, token), and exp() is monotone: the M-th largest per-lane
       // maximum LOGIT bounds the M-th best from below.  Survivors are taken a margin below it -- 2^-16
@@ -154,18 +164,29 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       // row of this wave moves in behind it (the last rows of an utterance re-read their own).
       const float *nrow = row_of(t + P < Tn ? t + P : t);
       float s = 0.0f;
+      // (ONE version of the unrolled pass, the tame one: a branch around two copies -- or a branch per
+      // pair -- makes every chunk's register, reloaded behind its use, a merge of two versions, and the
+      // row spills.  A row that is not tame gets its sum again below; what this pass made of it --
+      // anything, NaN included -- is dropped.)
 #pragma unroll
       for (int i = 0; i < NR; i += 2) {
         if (i + 1 < NF || i + 1 < nt) {  // two chunks: the range reduction in packed fp32, same bits
-          const f32x2 e2 = exp_nonpos2(f32x2{r[i], r[i + 1]} - f32x2{mx, mx});
+          const f32x2 e2 = exp_tame2(f32x2{r[i], r[i + 1]} - f32x2{mx, mx});
           s += e2.x;
           s += e2.y;
           r[i] = nrow[i * PDT_WAVE];
           r[i + 1] = nrow[(i + 1) * PDT_WAVE];
         } else if (i < nt) {
-          s += exp_nonpos(r[i] - mx);
+          s += exp_tame2(f32x2{r[i] - mx, 0.0f}).x;
           r[i] = nrow[i * PDT_WAVE];
         }
+      }
+      if (!tame) {
+        // masked (-inf) or far-off elements: the general routine over the row read again (L2), the
+        // same per-lane order of additions
+        const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+        s = 0.0f;
+        for (int v = lp; v < nt * PDT_WAVE; v += PDT_WAVE) s += exp_nonpos(row[v] - mx);
       }
       const float et = in_row ? exp_nonpos(rt - mx) : 0.0f;  // (lanes beyond the blank add +0: no change)
       s += et;
