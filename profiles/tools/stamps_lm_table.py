@@ -22,3 +22,6 @@ for vm in (False, True):
     tot = sum(buf[:4])
     print("valid_mixture" if vm else "fusion", "%.2f ms" % ms, "cycles per frame and utterance:",
           {n: round(buf[i] / (T * N)) for i, n in enumerate(names)}, "sum", round(tot / (T * N)))
+    lnames = ["wait contexts / row", "etab + mixed row", "threshold + survivors", "sort + list + positions"]
+    print("   list builder, all four waves, cycles per frame and utterance:",
+          {n: round(buf[4 + i] / (T * N)) for i, n in enumerate(lnames)})

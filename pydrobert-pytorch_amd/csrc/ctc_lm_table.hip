@@ -61,8 +61,19 @@ __device__ unsigned long long g_lmtab_stamps[8];
     acc_[i] += now_ - last_;                                      \
     last_ = now_;                                                 \
   } while (0)
+// inside the list builder (every wave; summed): 4 waiting for contexts / the row, 5 etab + the mixed
+// row (factor row from L2), 6 threshold + survivors, 7 sort, list, positions
+#define LMTAB_LSTAMP(i)                                                      \
+  do {                                                                       \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();            \
+    if (lane_id() == 0) atomicAdd(&g_lmtab_stamps[i], now_ - llast_);        \
+    llast_ = now_;                                                           \
+  } while (0)
+#define LMTAB_LSTAMP_BEGIN unsigned long long llast_ = __builtin_amdgcn_s_memtime()
 #else
 #define LMTAB_STAMP(i) do {} while (0)
+#define LMTAB_LSTAMP(i) do {} while (0)
+#define LMTAB_LSTAMP_BEGIN do {} while (0)
 #endif
 
 // ints of the per-frame tables between the lists and the consumer's scratch, padded to 16 bytes: the
@@ -167,6 +178,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
 
   // ---- the lists of the published frame this wave is responsible for --------------------------
   auto build_lists = [&](const int t) {
+    LMTAB_LSTAMP_BEGIN;
     wait_above(ctx_pub, t);
     const int D = __builtin_amdgcn_readfirstlane(*ctx_count);
     const int Kp = __builtin_amdgcn_readfirstlane(*kp_pub);
@@ -179,9 +191,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
         return A.valid_mixture ? keep * pv + A.beta * (fv * scale) : pv * fv;
       };
       u64 *surv = surv0 + wave * PDT_SURV_CAP;
-#ifdef PDT_LMTAB_TWICE  // timing experiment (same results): every list built twice
-      for (int rep = 0; rep < 2; ++rep)
-#endif
+      LMTAB_LSTAMP(4);
       for (int d = wave; d < D; d += kLmTabWaves) {
         int lp = lane;
         asm volatile("" : "+v"(lp));
@@ -206,29 +216,62 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
             lmax = max(lmax, key[i]);
           }
         }
+        LMTAB_LSTAMP(5);
         // sorted top-M of the mixed row (wave_top_sorted's selection on registers)
         u64 tk;
         if (V <= PDT_WAVE) {
           tk = wave_sort_desc<u64>(lp < V ? pack_key(key[0], (unsigned)lp) : 0ull);
         } else {
-          const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
-          const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
-          int count = 0;
+          // Threshold: any value that at least M per-lane maxima reach bounds the M-th best from
+          // below.  Cheap form (M <= 32): every DPP row of 16 lanes sorted by itself -- ten stages,
+          // none through the crossbar -- and the smallest of the four rows' ceil(M / 4)-th largest:
+          // at least 4 * ceil(M / 4) lanes reach it.  It lies at or below the exact M-th largest, so a
+          // few more survive; if more than 64 do (or M > 32), the exact one from the 64-key sort.
+          auto collect = [&](const unsigned tau) {
+            int count = 0;
 #pragma unroll
-          for (int i = 0; i < NR; ++i) {
-            if (i * PDT_WAVE < V) {
-              const bool pred = key[i] >= tau && key[i] != 0u;
-              const u64 bal = __ballot(pred);
-              if (bal) {
-                const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-                if (pred && at < PDT_SURV_CAP) surv[at] = pack_key(key[i], (unsigned)(lp + i * PDT_WAVE));
-                count += __popcll(bal);
+            for (int i = 0; i < NR; ++i) {
+              if (i * PDT_WAVE < V) {
+                const bool pred = key[i] >= tau && key[i] != 0u;
+                const u64 bal = __ballot(pred);
+                if (bal) {
+                  const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
+                  if (pred && at < PDT_SURV_CAP) surv[at] = pack_key(key[i], (unsigned)(lp + i * PDT_WAVE));
+                  count += __popcll(bal);
+                }
               }
             }
+            wave_sync();
+            return count;
+          };
+          unsigned tau = 0u;
+          int count = PDT_SURV_CAP + 1;
+          if (M <= 32) {
+            const unsigned rs = row_sort_desc<unsigned>(lmax);
+            const int q = (M + 3) >> 2;
+            tau = min(min((unsigned)__builtin_amdgcn_readlane((int)rs, q - 1), (unsigned)__builtin_amdgcn_readlane((int)rs, 16 + q - 1)),
+                      min((unsigned)__builtin_amdgcn_readlane((int)rs, 32 + q - 1), (unsigned)__builtin_amdgcn_readlane((int)rs, 48 + q - 1)));
+            count = collect(max(tau, 1u));
           }
-          wave_sync();
+          if (count > PDT_SURV_CAP) {
+            const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
+            tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+            count = collect(tau);
+          }
+          LMTAB_LSTAMP(6);
           if (count <= PDT_SURV_CAP) {
-            tk = wave_sort_desc<u64>(lp < count ? surv[lp] : 0ull);
+            // one sort of 32-bit keys: the mass key rounded up to a multiple of 64 with the survivor's
+            // slot in the freed bits (the lean tier's trick); exact unless two of the first M + 1 agree
+            // in the upper 26 bits -- then the (key, token) pairs themselves are sorted
+            const u64 mine = lp < count ? surv[lp] : 0ull;
+            const unsigned k32 = lp < count ? (((key_of(mine) + 63u) & ~63u) | (63u - (unsigned)lp)) : 0u;
+            const unsigned st = wave_sort_desc<unsigned>(k32);
+            const unsigned st_next = (unsigned)__builtin_amdgcn_mov_dpp((int)st, 0x130, 0xf, 0xf, true);  // wave_shl:1
+            if (__ballot(lp < M && lp + 1 < count && (st >> 6) == (st_next >> 6)) == 0ull) {
+              tk = lp < count ? surv[63 - (int)(st & 63u)] : 0ull;
+            } else {
+              tk = wave_sort_desc<u64>(mine);
+            }
           } else {  // heavy ties: chunked top-64 merge, the row formed again
             tk = 0ull;
             for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
@@ -250,6 +293,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
           const u64 hit = __ballot(my_tok == lastc_pub[j]);
           if (lp == 0) lpos[d * W + j] = hit ? (int)__builtin_ctzll(hit) : -1;
         }
+        LMTAB_LSTAMP(7);
       }
     }
     st_flag(&done[wave], t + 1);
