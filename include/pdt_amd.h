@@ -441,6 +441,18 @@ int pdt_polyharmonic_spline(const float *train_points, const float *train_values
 int pdt_warp_1d_grid(const float *src, const float *flow, const float *lengths, int64_t N, int64_t T,
                      int order, float *grid, void *stream);
 
+/* spec_augment_draw_parameters (_img.py:1056-1139) from one (N, R) tensor of uniform draws u in
+ * [0, 1): column c is utterance n's c-th draw in the reference's order (w_0, w | v_0, v | t x MT,
+ * t_0 x MT | f x MF, f_0 x MF; groups the configuration disables take no columns and their outputs
+ * may be NULL); every parameter is the reference's float32 expression of its uniform.  lengths (N,)
+ * int64 or NULL (all T).  is_double: the features are float64 (the reference's eps follows them). */
+int pdt_spec_augment_draw(const float *u, int64_t N, int64_t R, const int64_t *lengths, int64_t T,
+                          int64_t F, float max_time_warp, float max_freq_warp, int64_t max_time_mask,
+                          int64_t max_freq_mask, float max_time_mask_proportion, int64_t num_time_mask,
+                          float num_time_mask_proportion, int64_t num_freq_mask, int is_double,
+                          float *w_0, float *w, float *v_0, float *v, int64_t *t_0, int64_t *t,
+                          int64_t *f_0, int64_t *f, void *stream);
+
 int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, int64_t f_sn,
                            int64_t f_st, int64_t f_sf, const float *time_grid,
                            const float *freq_grid, const int64_t *t_0, const int64_t *t_len,

@@ -14,6 +14,7 @@ meaningful.
 import numpy as np
 
 __all__ = [
+    "spec_augment_parameters_from_uniforms",
     "dense_image_warp",
     "grid_sample",
     "pad_variable",
@@ -260,3 +261,47 @@ def pad_variable(x, lens, pad, mode="constant", value=0.0):
             raise ValueError(mode)
         out[n, : a + L + b] = np.concatenate([left, seq, right], 0)
     return out
+
+
+def spec_augment_parameters_from_uniforms(u, T, F, max_time_warp, max_freq_warp, max_time_mask, max_freq_mask,
+                                          max_time_mask_proportion, num_time_mask, num_time_mask_proportion,
+                                          num_freq_mask, lengths=None, double_feats=False):
+    """spec_augment_draw_parameters (_img.py:1056-1139) as a function of its uniform draws: column c of
+    ``u`` (N, R) is the c-th ``torch.rand`` value of an utterance in the reference's call order (w_0, w,
+    v_0, v, t x MT, t_0 x MT, f x MF, f_0 x MF; disabled groups take no columns).  float32 expressions in
+    the reference's order; returns the 8-tuple with zero-size arrays for disabled groups."""
+    f32 = np.float32
+    u = np.asarray(u, dtype=f32)
+    N = u.shape[0]
+    eps = 2.220446049250313e-16 if double_feats else 1.1920928955078125e-07
+    omeps = f32(1 - eps)
+    ln = np.full((N,), T, dtype=f32) if lengths is None else np.asarray(lengths).astype(f32)
+    e = np.zeros((0,), f32)
+    ei = np.zeros((0,), np.int64)
+    w_0 = w = v_0 = v = e
+    t_0 = t = f_0 = f = ei
+    c = 0
+    if max_time_warp != 0.0:
+        Wt = np.clip(ln / f32(2) - f32(eps), f32(0), f32(max_time_warp)).astype(f32)
+        w_0 = (u[:, c] * (ln - f32(2) * Wt) + Wt).astype(f32)
+        w = (u[:, c + 1] * (f32(2) * Wt) - Wt).astype(f32)
+        c += 2
+    if max_freq_warp != 0.0:
+        Vf = f32(min(max(F / 2 - eps, 0.0), max_freq_warp))
+        v_0 = (u[:, c] * f32(f32(F) - f32(2) * Vf) + Vf).astype(f32)
+        v = (u[:, c + 1] * (f32(2) * Vf) - Vf).astype(f32)
+        c += 2
+    if max_time_mask != 0 and max_time_mask_proportion != 0.0 and num_time_mask != 0 and num_time_mask_proportion != 0.0:
+        MT = num_time_mask
+        max_ = np.floor(np.minimum(ln * f32(max_time_mask_proportion), f32(max_time_mask))).astype(f32)
+        nums_ = np.floor(np.minimum(ln * f32(num_time_mask_proportion), f32(num_time_mask))).astype(f32)
+        t = (u[:, c : c + MT] * (max_ + omeps)[:, None]).astype(np.int64)
+        t = np.where(nums_[:, None] <= np.arange(MT, dtype=f32)[None], 0, t)
+        t_0 = (u[:, c + MT : c + 2 * MT] * ((ln[:, None] - t.astype(f32)) + omeps)).astype(np.int64)
+        c += 2 * MT
+    if max_freq_mask != 0 and num_freq_mask != 0:
+        MF = num_freq_mask
+        maxf = f32(min(max_freq_mask, F))
+        f = (u[:, c : c + MF] * (maxf + omeps)).astype(np.int64)
+        f_0 = (u[:, c + MF : c + 2 * MF] * ((f32(F) - f.astype(f32)) + omeps)).astype(np.int64)
+    return w_0, w, v_0, v, t_0, t, f_0, f

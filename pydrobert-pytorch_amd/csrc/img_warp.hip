@@ -12,6 +12,8 @@
 // The small dense systems are solved in float64 (partial pivoting); gathers follow
 // torch.nn.functional.grid_sample(align_corners=False) arithmetic in float32.
 #include <cfloat>
+#include <cmath>
+#include <algorithm>
 
 #include <type_traits>
 
@@ -889,7 +891,7 @@ __global__ void __launch_bounds__(256) sparse_warp_bands_kernel(const WarpArgs a
     // (base in scalar registers, 32-bit byte offsets; reads beyond the plane cannot happen: the
     // offsets are clamped into it)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl), 0, HW * 4, 0x00020000);
-    float t00[4], t01[4], t10[4], t11[4];
+    unsigned t00[4], t01[4], t10[4], t11[4];  // (the pixels' BITS: the loads return integers)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {  // all the taps in flight (taps outside the image: any valid address)
       const int x0 = (int)x0f[j], y0 = (int)y0f[j];
@@ -910,11 +912,67 @@ __global__ void __launch_bounds__(256) sparse_warp_bands_kernel(const WarpArgs a
       const bool vy0 = PADDING != PAD_ZEROS || (y0 >= 0 && y0 < H), vy1 = y1 >= 0 && y1 < H;
       // (a tap outside the image is left out, as image_warp_kernel does -- a select, not a product
       // with 0: that would turn an inf / NaN pixel into NaN)
-      float acc = (vx0 && vy0) ? __int_as_float(t00[j]) * (wx0 * wy0) : 0.0f;
-      acc += (vx1 && vy0) ? __int_as_float(t01[j]) * (wx1 * wy0) : 0.0f;
-      acc += (vx0 && vy1) ? __int_as_float(t10[j]) * (wx0 * wy1) : 0.0f;
-      acc += (vx1 && vy1) ? __int_as_float(t11[j]) * (wx1 * wy1) : 0.0f;
+      float acc = (vx0 && vy0) ? __uint_as_float(t00[j]) * (wx0 * wy0) : 0.0f;
+      acc += (vx1 && vy0) ? __uint_as_float(t01[j]) * (wx1 * wy0) : 0.0f;
+      acc += (vx0 && vy1) ? __uint_as_float(t10[j]) * (wx0 * wy1) : 0.0f;
+      acc += (vx1 && vy1) ? __uint_as_float(t11[j]) * (wx1 * wy1) : 0.0f;
       if (h0 + j < H) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc), ro, ((h0 + j) * W + w) << 2, 0, 0);
+    }
+  }
+}
+
+// spec_augment_draw_parameters (_img.py:1056-1139) from ONE tensor of uniform draws: the reference
+// makes six torch.rand calls and ~30 tiny tensor ops around them (clamp, floor, masked_fill, long) --
+// launch-bound, 0.2-0.5 ms at N = 2048 against the 0.25 ms of the kernel that applies the parameters.
+// Here column c of u (N, R) is the c-th draw of utterance n, in the reference's order (w_0, w, v_0, v,
+// then the time masks' t, t_0, the frequency masks' f, f_0), and every expression is the reference's
+// float32 expression.  (Bitwise parity of the DRAWS with the reference is no goal -- different
+// generators per device, SURVEY A.12 -- the mapping from a uniform to a parameter is.)
+struct SpecDrawArgs {
+  const float *u;
+  int R;
+  const int64_t *lengths;  // (N,) or null (all T)
+  int N, T, F, MT, MF;
+  int time_warp, freq_warp, time_mask, freq_mask;  // which groups are drawn
+  float max_time_warp, Vf, max_time_mask, max_time_mask_proportion, num_time_mask, num_time_mask_proportion;
+  float maxf, eps, omeps;
+  float *w_0, *w, *v_0, *v;
+  int64_t *t_0, *t, *f_0, *f;
+};
+
+__global__ void __launch_bounds__(256) spec_augment_draw_kernel(const SpecDrawArgs a) {
+  const int n = (int)(blockIdx.x * 256 + threadIdx.x);
+  if (n >= a.N) return;
+  const float *u = a.u + (int64_t)n * a.R;
+  const float len = a.lengths ? (float)a.lengths[n] : (float)a.T;
+  int c = 0;
+  if (a.time_warp) {  // :1082-1090
+    const float Wt = fminf(fmaxf(len / 2.0f - a.eps, 0.0f), a.max_time_warp);
+    a.w_0[n] = u[c] * (len - 2.0f * Wt) + Wt;
+    a.w[n] = u[c + 1] * (2.0f * Wt) - Wt;
+    c += 2;
+  }
+  if (a.freq_warp) {  // :1091-1098
+    a.v_0[n] = u[c] * ((float)a.F - 2.0f * a.Vf) + a.Vf;
+    a.v[n] = u[c + 1] * (2.0f * a.Vf) - a.Vf;
+    c += 2;
+  }
+  if (a.time_mask) {  // :1099-1126
+    const float max_ = floorf(fminf(len * a.max_time_mask_proportion, a.max_time_mask));
+    const float nums_ = floorf(fminf(len * a.num_time_mask_proportion, a.num_time_mask));
+    for (int m = 0; m < a.MT; ++m) {
+      int64_t t = (int64_t)(u[c + m] * (max_ + a.omeps));
+      if (nums_ <= (float)m) t = 0;
+      a.t[(int64_t)n * a.MT + m] = t;
+      a.t_0[(int64_t)n * a.MT + m] = (int64_t)(u[c + a.MT + m] * ((len - (float)t) + a.omeps));
+    }
+    c += 2 * a.MT;
+  }
+  if (a.freq_mask) {  // :1127-1137
+    for (int m = 0; m < a.MF; ++m) {
+      const int64_t f = (int64_t)(u[c + m] * (a.maxf + a.omeps));
+      a.f[(int64_t)n * a.MF + m] = f;
+      a.f_0[(int64_t)n * a.MF + m] = (int64_t)(u[c + a.MF + m] * (((float)a.F - (float)f) + a.omeps));
     }
   }
 }
@@ -1004,6 +1062,45 @@ int pdt_warp_1d_grid(const float *src, const float *flow, const float *lengths, 
   if (!src || !flow || !lengths || !grid) return PDT_E_ARG;
   hipLaunchKernelGGL(warp_1d_grid_kernel, dim3((unsigned)N), dim3(256), 0, (hipStream_t)stream, src,
                      flow, lengths, (int)T, order, grid);
+  return (int)hipGetLastError();
+}
+
+int pdt_spec_augment_draw(const float *u, int64_t N, int64_t R, const int64_t *lengths, int64_t T,
+                          int64_t F, float max_time_warp, float max_freq_warp, int64_t max_time_mask,
+                          int64_t max_freq_mask, float max_time_mask_proportion, int64_t num_time_mask,
+                          float num_time_mask_proportion, int64_t num_freq_mask, int is_double,
+                          float *w_0, float *w, float *v_0, float *v, int64_t *t_0, int64_t *t,
+                          int64_t *f_0, int64_t *f, void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 0 || F < 0 || R < 0 || num_time_mask < 0 || num_freq_mask < 0) return PDT_E_ARG;
+  SpecDrawArgs a{};
+  a.time_warp = max_time_warp != 0.0f;
+  a.freq_warp = max_freq_warp != 0.0f;
+  a.time_mask = max_time_mask != 0 && max_time_mask_proportion != 0.0f && num_time_mask != 0 &&
+                num_time_mask_proportion != 0.0f;
+  a.freq_mask = max_freq_mask != 0 && num_freq_mask != 0;
+  a.MT = a.time_mask ? (int)num_time_mask : 0;
+  a.MF = a.freq_mask ? (int)num_freq_mask : 0;
+  if (R < 2 * a.time_warp + 2 * a.freq_warp + 2 * a.MT + 2 * a.MF) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!u || (a.time_warp && (!w_0 || !w)) || (a.freq_warp && (!v_0 || !v)) || (a.time_mask && (!t_0 || !t)) ||
+      (a.freq_mask && (!f_0 || !f)))
+    return PDT_E_ARG;
+  // (the reference's eps is that of the features' dtype; its arithmetic on the draws is float32 either way)
+  const double eps = is_double ? 2.220446049250313e-16 : 1.1920928955078125e-07;
+  a.u = u; a.R = (int)R; a.lengths = lengths;
+  a.N = (int)N; a.T = (int)T; a.F = (int)F;
+  a.eps = (float)eps;
+  a.omeps = (float)(1.0 - eps);
+  a.max_time_warp = max_time_warp;
+  a.Vf = (float)std::fmin(std::fmax((double)F / 2.0 - eps, 0.0), (double)max_freq_warp);
+  a.max_time_mask = (float)max_time_mask;
+  a.max_time_mask_proportion = max_time_mask_proportion;
+  a.num_time_mask = (float)num_time_mask;
+  a.num_time_mask_proportion = num_time_mask_proportion;
+  a.maxf = (float)std::min<int64_t>(max_freq_mask, F);
+  a.w_0 = w_0; a.w = w; a.v_0 = v_0; a.v = v; a.t_0 = t_0; a.t = t; a.f_0 = f_0; a.f = f;
+  hipLaunchKernelGGL(spec_augment_draw_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
 

@@ -109,6 +109,10 @@ SIGNATURES = {
         _INT, [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _P, _P, _P],
     ),
     "pdt_warp_1d_grid": (_INT, [_P, _P, _P, _I64, _I64, _INT, _P, _P]),
+    "pdt_spec_augment_draw": (
+        _INT,
+        [_P, _I64, _I64, _P, _I64, _I64, _F, _F, _I64, _I64, _F, _I64, _F, _I64, _INT, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    ),
     "pdt_spec_augment_apply": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P],

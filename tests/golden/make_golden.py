@@ -681,3 +681,63 @@ def c4_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "c4"):
     c4_goldens()
+
+
+def spec_draw_goldens():
+    """spec_augment_draw_parameters of the live reference with its uniform draws PINNED: torch.rand is
+    replaced, for the duration of the call, by a function that hands out the columns of a known (N, R)
+    tensor in the reference's call order -- so the mapping from draws to parameters (not the generator)
+    is what the fixture holds.  Several configurations, groups enabled and disabled, the extreme draws 0
+    and 1 - 2^-24, ragged lengths and none."""
+    rng = np.random.default_rng(0x5EED000B)
+    d = {}
+    cfgs = [
+        dict(max_time_warp=80.0, max_freq_warp=0.0, max_time_mask=100, max_freq_mask=27, max_time_mask_proportion=0.04,
+             num_time_mask=2, num_time_mask_proportion=1.0, num_freq_mask=2),  # C4
+        dict(max_time_warp=10.0, max_freq_warp=2.0, max_time_mask=20, max_freq_mask=5, max_time_mask_proportion=0.1,
+             num_time_mask=3, num_time_mask_proportion=0.02, num_freq_mask=2),
+        dict(max_time_warp=0.0, max_freq_warp=3.5, max_time_mask=0, max_freq_mask=8, max_time_mask_proportion=0.2,
+             num_time_mask=4, num_time_mask_proportion=0.5, num_freq_mask=1),
+        dict(max_time_warp=5.0, max_freq_warp=0.0, max_time_mask=7, max_freq_mask=0, max_time_mask_proportion=1.0,
+             num_time_mask=5, num_time_mask_proportion=0.01, num_freq_mask=3),
+    ]
+    real_rand = torch.rand
+    for i, cfg in enumerate(cfgs):
+        N, T, Fq = 9, 60 + 17 * i, 12 + 5 * i
+        tw, fw = cfg["max_time_warp"] != 0.0, cfg["max_freq_warp"] != 0.0
+        tm = all(cfg[k] != 0 for k in ("max_time_mask", "max_time_mask_proportion", "num_time_mask", "num_time_mask_proportion"))
+        fm = cfg["max_freq_mask"] != 0 and cfg["num_freq_mask"] != 0
+        MT, MF = (cfg["num_time_mask"] if tm else 0), (cfg["num_freq_mask"] if fm else 0)
+        R = 2 * tw + 2 * fw + 2 * MT + 2 * MF
+        u = rng.random((N, R)).astype(np.float32)
+        u[0] = 0.0
+        u[1] = np.float32(1.0 - 2.0 ** -24)
+        lens = None if i == 2 else torch.from_numpy(rng.integers(T // 3, T + 1, N))
+        cols = [0]
+        tu = torch.from_numpy(u)
+
+        def fake_rand(shape, *a, **k):
+            n = 1 if len(shape) == 1 else shape[1]
+            out = tu[:, cols[0] : cols[0] + n]
+            cols[0] += n
+            return out.reshape(shape).clone()
+
+        torch.rand = fake_rand
+        try:
+            out = F.spec_augment_draw_parameters(torch.zeros((N, T, Fq)), lengths=lens, **cfg)
+        finally:
+            torch.rand = real_rand
+        assert cols[0] == R, (cols[0], R)
+        t_ = "d%d_" % i
+        d[t_ + "u"], d[t_ + "shape"] = u, np.array([N, T, Fq])
+        d[t_ + "lens"] = np.array([-1]) if lens is None else lens
+        d[t_ + "cfg"] = np.array([cfg[k] for k in ("max_time_warp", "max_freq_warp", "max_time_mask", "max_freq_mask",
+                                                    "max_time_mask_proportion", "num_time_mask",
+                                                    "num_time_mask_proportion", "num_freq_mask")], dtype=np.float64)
+        for name, o in zip(("w_0", "w", "v_0", "v", "t_0", "t", "f_0", "f"), out):
+            d[t_ + name] = o
+    save("spec_draw", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "spec_draw"):
+    spec_draw_goldens()

@@ -179,22 +179,16 @@ def test_lm_interface_forward_idx_normalisation():
         M.SequentialLanguageModel(3)  # abstract
 
 
-def test_spec_augment_draw_parameters_on_cpu_ranges():
-    """Parameter draws are plain torch ops and run anywhere (reference tests/test_img.py:226-281)."""
-    torch.manual_seed(0)
-    N, T, Fq = 50, 120, 16
-    feats = torch.zeros(N, T, Fq)
-    lens = torch.randint(40, T + 1, (N,))
-    w_0, w, v_0, v, t_0, t, f_0, f = F.spec_augment_draw_parameters(feats, 8.0, 2.0, 12, 4, 0.1, 3, 0.03, 2, lens)
-    lf = lens.float()
-    Wm = (lf / 2).clamp(max=8.0)
-    assert ((w_0 >= Wm - 1e-4) & (w_0 <= lf - Wm + 1e-4)).all() and (w.abs() <= Wm + 1e-4).all()
-    assert ((v_0 >= 2 - 1e-4) & (v_0 <= Fq - 2 + 1e-4)).all() and (v.abs() <= 2 + 1e-4).all()
-    assert (t <= (lf * 0.1).clamp(max=12).floor().unsqueeze(1)).all() and (t_0 + t <= lens.unsqueeze(1)).all()
-    assert ((t > 0).sum(1) <= (lf * 0.03).clamp(max=3).floor()).all()
-    assert (f <= 4).all() and (f_0 >= 0).all() and (f_0 + f <= Fq).all()
-    out = F.spec_augment_draw_parameters(feats, 0.0, 0.0, 0, 0, 0.1, 3, 0.03, 0)
-    assert all(p.numel() == 0 for p in out)
+def test_spec_augment_draw_parameters_refuses_cpu_tensors():
+    """The draw is one HIP kernel (csrc/img_warp.hip spec_augment_draw_kernel): like every operator of
+    the package it refuses CPU tensors loudly instead of falling back (the ranges of the drawn
+    parameters -- reference tests/test_img.py:226-281 -- are checked on the GPU, tests/test_img_gpu.py);
+    a call that draws nothing needs no kernel and returns the reference's zero-size pairs."""
+    feats = torch.zeros(5, 12, 6)
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.spec_augment_draw_parameters(feats, 8.0, 2.0, 12, 4, 0.1, 3, 0.03, 2, torch.full((5,), 12))
+    with pytest.raises(RuntimeError, match="ROCm"):
+        F.spec_augment_draw_parameters(feats, 0.0, 0.0, 0, 0, 0.1, 3, 0.03, 0)
 
 
 # ---- language model host logic (SURVEY section 8 row f3) ---------------------------------------

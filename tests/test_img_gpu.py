@@ -135,6 +135,37 @@ def test_spec_augment_module_statistics_and_grad(device):
     assert torch.allclose(lhs, rhs, rtol=1e-3, atol=1e-2), (lhs.item(), rhs.item())
 
 
+def test_spec_augment_draw_kernel_maps_draws_like_the_reference(device):
+    """The one-kernel draw (pydrobert_amd::spec_augment_draw): given the SAME uniform draws it returns
+    the live reference's parameters bit for bit (tests/golden/spec_draw.npz: torch.rand pinned while the
+    reference ran), and on a large random batch the oracle's restatement of that mapping; the functional
+    returns zero-size pairs for disabled groups like the reference."""
+    from test_oracle_golden import spec_draw_cases
+
+    def run(u, T, Fq, cfg, lens):
+        out = torch.ops.pydrobert_amd.spec_augment_draw(
+            _t(u, device), None if lens is None else _t(np.asarray(lens), device), T, Fq, float(cfg["max_time_warp"]),
+            float(cfg["max_freq_warp"]), cfg["max_time_mask"], cfg["max_freq_mask"], float(cfg["max_time_mask_proportion"]),
+            cfg["num_time_mask"], float(cfg["num_time_mask_proportion"]), cfg["num_freq_mask"], False)
+        return [o.cpu().numpy() for o in out]
+
+    for u, T, Fq, cfg, lens, exp in spec_draw_cases():
+        for o, e in zip(run(u, T, Fq, cfg, lens), exp):
+            assert o.size == e.size and (o.size == 0 or np.array_equal(o.reshape(e.shape), e)), cfg
+    rng = np.random.default_rng(12)
+    cfg = dict(max_time_warp=80.0, max_freq_warp=3.0, max_time_mask=100, max_freq_mask=27, max_time_mask_proportion=0.04,
+               num_time_mask=2, num_time_mask_proportion=1.0, num_freq_mask=2)
+    N, T, Fq = 2048, 1000, 80
+    u = rng.random((N, 12)).astype(np.float32)
+    lens = rng.integers(1, T + 1, N)
+    exp = oracle.spec_augment_parameters_from_uniforms(u, T, Fq, lengths=lens, **cfg)
+    for o, e in zip(run(u, T, Fq, cfg, lens), exp):
+        assert np.array_equal(o, e)
+    feats = torch.zeros((4, 30, 6), device=device)
+    out = F.spec_augment_draw_parameters(feats, 0.0, 0.0, 5, 0, 0.5, 2, 1.0, 3)
+    assert [o.numel() for o in out] == [0, 0, 0, 0, 8, 8, 0, 0]
+
+
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
 @pytest.mark.parametrize("padding", ["border", "zeros", "reflection"])
 def test_dense_image_warp(device, mode, padding):
@@ -154,7 +185,7 @@ def test_dense_image_warp(device, mode, padding):
 def test_sparse_image_warp(device, pinned, include_flow):
     rng = np.random.default_rng(7 + pinned)
     N, C, H, W, Mp = 2, 2, 12, 9, 4
-    img = rng.uniform(size=(N, C, H, W)).astype(np.float32)
+    img = rng.normal(size=(N, C, H, W)).astype(np.float32)  # (pixels of both signs: the fast kernels move their bits)
     src = (rng.uniform(size=(N, Mp, 2)) * [H - 1, W - 1]).astype(np.float32)
     dst = (src + rng.normal(size=(N, Mp, 2))).astype(np.float32)
     for indexing in ("hw", "wh"):
