@@ -561,6 +561,7 @@ struct WarpArgs {
   const float *knots;  // sparse: (N,M,2) spline centres (x, y), float
   const float *wv;     // sparse: (N, M+3, 2) float weights (w, then v_x, v_y, v_1)
   int M, order, as_grid;  // as_grid: the spline yields the normalised grid itself (no-flow form)
+  float inv_w;         // 1 / W (sparse_warp_bands_kernel)
   float *flow_out;     // sparse, optional (N,H,W,2)
   int flow_out_flip;
   float *grad_image;   // BACKWARD: (N,C,H,W), zeroed by the caller; `out` then holds grad_out
@@ -799,124 +800,177 @@ __global__ void __launch_bounds__(256) sparse_warp_fast_kernel(const WarpArgs a)
   }
 }
 
-// The same call shape with a lane = one COLUMN of a band of four rows: the four pixels (h .. h + 3, w)
+// The same call shape with a lane = one COLUMN of a band of ROWS rows: the pixels (h .. h + ROWS - 1, w)
 // share x, so a centre's dx, dx^2 and the x part of the affine term are formed once per lane, the
-// pixel -> (h, w) split once instead of four times, and the four chains are written as two float2
-// chains (v_pk_add / v_pk_mul / v_pk_fma carry two pixels per instruction; v_log_f32 stays scalar).
-// A wave's lanes are consecutive columns (bands flattened with their columns: lane order = memory
-// order within a row), so each of the four row-rounds of taps and stores is coalesced.  Taps are
-// buffer loads: the plane's base in scalar registers, a 32-bit byte offset per lane.
+// pixel -> (h, w) split once, and the chains are written as float2 chains (v_pk_add / v_pk_mul /
+// v_pk_fma carry two pixels per instruction; v_log_f32 stays scalar).  A wave's lanes are consecutive
+// columns (bands flattened with their columns: lane order = memory order within a row), so each
+// row-round of taps and stores is coalesced.
+//
+// What the lanes do NOT do: everything that is the same for a whole image sits in a TABLE that
+// warp_table_kernel writes once per call (per image: MC centres x (kx, ky, wx, wy), then ax, ay, bx,
+// by, cx, cy) and the kernel reads with scalar loads -- no LDS staging, no barrier, no readfirstlane.
+// The table's weights carry (a) grid_sample's un-normalisation ((g + 1) * size - 1) / 2 -- or, in
+// the flow form, pixel - flow -- so the spline's value IS the source pixel coordinate, (b) order 2's
+// ln 2 / 2, so phi is d2 * log2(d2) here; both products are formed in double before the cast.
+// Centres beyond M have zero weights: fma(phi, 0, s) = s exactly, phi finite everywhere.
+//
+// Taps (border / reflection padding, coordinates inside [0, size - 1]): buffer loads with the plane's
+// base in scalar registers and 32-bit byte offsets; the first tap's offset is one float fma + convert
+// (exact below 2^23 pixels), the others add 4 / 4W -- or, where the neighbour lies outside the image,
+// an offset beyond the buffer: the load returns 0 and the tap drops out as in image_warp_kernel
+// (never a product of an inf / NaN pixel with a zero weight).
 typedef float wf2 __attribute__((ext_vector_type(2)));
+constexpr int kBandRows = 4;  // (8 measured slower: 0.42 ms against 0.40 at C4)
+constexpr int kWarpTableFloats = 40;  // per image: 4 * 8 + 6, rounded up to 16 bytes (workspace stride)
+__host__ __device__ constexpr int warp_table_stride(int MC) { return (4 * MC + 6 + 3) & ~3; }
+
+__global__ void warp_table_kernel(const double *__restrict__ wv, const float *__restrict__ knots, float *__restrict__ tab,
+                                  int64_t N, int M, int MC, int as_grid, int H, int W, int order) {
+  const int stride = warp_table_stride(MC);
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= N * stride) return;
+  const int64_t n = i / stride;
+  const int e = (int)(i - n * stride);
+  const double *sol = wv + n * (int64_t)(M + 3) * 2;
+  const int d = e & 1;                                     // 0: x (columns), 1: y (rows)
+  const double size = d ? (double)H : (double)W;
+  // source coordinate = scale * spline + (identity part) + shift
+  const double scale = as_grid ? 0.5 * size : -1.0;
+  const double phi_scale = order == 2 ? 0.34657359027997264 : 1.0;
+  float v = 0.0f;
+  if (e < 4 * MC) {
+    const int m = e >> 2, k = e & 3;
+    if (m < M) v = k < 2 ? knots[(n * M + m) * 2 + k] : (float)(sol[m * 2 + (k - 2)] * scale * phi_scale);
+  } else if (e < 4 * MC + 6) {
+    const int r = (e - 4 * MC) >> 1;                       // 0: coefficient of x, 1: of y, 2: constant
+    double t = sol[(M + r) * 2 + d] * scale;
+    if (as_grid) {
+      if (r == 2) t += 0.5 * (size - 1.0);
+    } else if (r == d) {
+      t += 1.0;
+    }
+    v = (float)t;
+  }
+  tab[i] = v;
+}
+
 template <int ORDER>
-__device__ __forceinline__ wf2 phi2_from_d2(const wf2 d2, const int order) {
-  if (ORDER == 2) {  // (phi_from_d2's order-2 form, two at a time)
+__device__ __forceinline__ wf2 phi2_unscaled(const wf2 d2, const int order) {
+  if (ORDER == 2) {  // d2 * log2(d2); d2 + 1e-37 is d2 for every distance but 0, and 0 * log2(1e-37) = 0
     const wf2 t = d2 + wf2{1e-37f, 1e-37f};
-    const wf2 l = {__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
-    return d2 * (l * wf2{0.34657359f, 0.34657359f});
+    return d2 * wf2{__builtin_amdgcn_logf(t.x), __builtin_amdgcn_logf(t.y)};
   }
   return wf2{phi_from_d2<ORDER>(d2.x, order), phi_from_d2<ORDER>(d2.y, order)};
 }
 
-// MC: centres the spline loop runs over, unconditionally -- a compile-time count (with a run-time
-// guard per centre the compiler re-rolls the loop and moves the centres through registers by index).
-// Calls with fewer centres pad with zero weights: fma(phi, 0, s) = s exactly, phi finite everywhere.
-template <int ORDER, int PADDING, int MC>
+template <int ORDER, int PADDING, int MC, int ROWS>
 __global__ void __launch_bounds__(256) sparse_warp_bands_kernel(const WarpArgs a) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  float *lk = reinterpret_cast<float *>(smem);
-  float *lw = lk + 2 * a.M;
+  static_assert(ROWS % 2 == 0, "rows are carried in pairs");
+  constexpr int RP = ROWS / 2;
   const int64_t n = blockIdx.y;
-  const int H = a.H, W = a.W, M = a.M;
-  for (int i = (int)threadIdx.x; i < 2 * M; i += 256) lk[i] = a.knots[n * 2 * M + i];
-  for (int i = (int)threadIdx.x; i < 2 * (M + 3); i += 256) lw[i] = a.wv[n * 2 * (M + 3) + i];
-  __syncthreads();
-  auto uni = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
-  float kx[MC], ky[MC], wx[MC], wy[MC];
-#pragma unroll
-  for (int m = 0; m < MC; ++m) {
-    const bool in = m < M;
-    kx[m] = uni(in ? lk[2 * m] : 0.0f);
-    ky[m] = uni(in ? lk[2 * m + 1] : 0.0f);
-    wx[m] = uni(in ? lw[2 * m] : 0.0f);
-    wy[m] = uni(in ? lw[2 * m + 1] : 0.0f);
-  }
-  const float ax = uni(lw[2 * M]), ay = uni(lw[2 * M + 1]), bx = uni(lw[2 * (M + 1)]), by = uni(lw[2 * (M + 1) + 1]);
-  const float cx = uni(lw[2 * (M + 2)]), cy = uni(lw[2 * (M + 2) + 1]);
-  const float inv_w = 1.0f / (float)W, inv_h = 1.0f / (float)H;
-  const int HW = H * W, bands = (H + 3) >> 2;
-  // (one column per lane: four columns per lane, amortising the set-up above, measured the same)
+  const int H = a.H, W = a.W;
+  const float *__restrict__ tab = a.wv + n * warp_table_stride(MC);  // (wave-uniform addresses: scalar loads)
+  const int HW = H * W, bands = (H + ROWS - 1) / ROWS;
   const int idx = (int)(blockIdx.x * 256 + threadIdx.x);
-  if (idx >= bands * W) return;  // (no barrier below)
-  int band = (int)(((float)idx + 0.5f) * inv_w), w = idx - band * W;  // (bands * W < 2^23: checked by the launcher)
+  if (idx >= bands * W) return;
+  int band = (int)(((float)idx + 0.5f) * a.inv_w), w = idx - band * W;  // (bands * W < 2^23: checked by the launcher)
   if (w < 0) { --band; w += W; }
   if (w >= W) { ++band; w -= W; }
-  const int h0 = band * 4;
+  const int h0 = band * ROWS;
   const float x = (float)w, yb = (float)h0;
-  const wf2 y01 = {yb, yb + 1.0f}, y23 = {yb + 2.0f, yb + 3.0f};
-  // spline: the affine part, then the centres
-  const float axc = __builtin_fmaf(ax, x, cx), ayc = __builtin_fmaf(ay, x, cy);
-  wf2 sx01 = __builtin_elementwise_fma(y01, wf2{bx, bx}, wf2{axc, axc}), sx23 = __builtin_elementwise_fma(y23, wf2{bx, bx}, wf2{axc, axc});
-  wf2 sy01 = __builtin_elementwise_fma(y01, wf2{by, by}, wf2{ayc, ayc}), sy23 = __builtin_elementwise_fma(y23, wf2{by, by}, wf2{ayc, ayc});
+  wf2 yv[RP], sx[RP], sy[RP];
+  {
+    const float *af = tab + 4 * MC;
+    const float axc = __builtin_fmaf(af[0], x, af[4]), ayc = __builtin_fmaf(af[1], x, af[5]);
+    const wf2 bx = {af[2], af[2]}, by = {af[3], af[3]};
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+      yv[i] = wf2{yb + (float)(2 * i), yb + (float)(2 * i + 1)};
+      sx[i] = __builtin_elementwise_fma(yv[i], bx, wf2{axc, axc});
+      sy[i] = __builtin_elementwise_fma(yv[i], by, wf2{ayc, ayc});
+    }
+  }
 #pragma unroll
   for (int m = 0; m < MC; ++m) {
-    const float dx = x - kx[m], dx2 = dx * dx;
-    const wf2 dy01 = y01 - wf2{ky[m], ky[m]}, dy23 = y23 - wf2{ky[m], ky[m]};
-    const wf2 p01 = phi2_from_d2<ORDER>(__builtin_elementwise_fma(dy01, dy01, wf2{dx2, dx2}), a.order);
-    const wf2 p23 = phi2_from_d2<ORDER>(__builtin_elementwise_fma(dy23, dy23, wf2{dx2, dx2}), a.order);
-    sx01 = __builtin_elementwise_fma(p01, wf2{wx[m], wx[m]}, sx01);
-    sx23 = __builtin_elementwise_fma(p23, wf2{wx[m], wx[m]}, sx23);
-    sy01 = __builtin_elementwise_fma(p01, wf2{wy[m], wy[m]}, sy01);
-    sy23 = __builtin_elementwise_fma(p23, wf2{wy[m], wy[m]}, sy23);
-  }
-  const float sxs[4] = {sx01.x, sx01.y, sx23.x, sx23.y}, sys[4] = {sy01.x, sy01.y, sy23.x, sy23.y};
-  float ix[4], iy[4], x0f[4], y0f[4];
+    const float kx = tab[4 * m], ky = tab[4 * m + 1], wx = tab[4 * m + 2], wy = tab[4 * m + 3];
+    const float dx = x - kx, dx2 = dx * dx;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const float y = yb + (float)j;
-    float gx, gy;
-    if (a.as_grid) {
-      gx = sxs[j];
-      gy = sys[j];
-    } else {
-      gx = (2.0f * x - 2.0f * sxs[j] + 1.0f) * inv_w - 1.0f;  // _img.py:432
-      gy = (2.0f * y - 2.0f * sys[j] + 1.0f) * inv_h - 1.0f;
+    for (int i = 0; i < RP; ++i) {
+      const wf2 dy = yv[i] - wf2{ky, ky};
+      const wf2 p = phi2_unscaled<ORDER>(__builtin_elementwise_fma(dy, dy, wf2{dx2, dx2}), a.order);
+      sx[i] = __builtin_elementwise_fma(p, wf2{wx, wx}, sx[i]);
+      sy[i] = __builtin_elementwise_fma(p, wf2{wy, wy}, sy[i]);
     }
-    ix[j] = source_index(gx, W, PADDING);
-    iy[j] = source_index(gy, H, PADDING);
-    x0f[j] = floorf(ix[j]);
-    y0f[j] = floorf(iy[j]);
   }
+  float ix[ROWS], iy[ROWS], x0f[ROWS], y0f[ROWS];
+  const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+#pragma unroll
+  for (int j = 0; j < ROWS; ++j) {
+    float px = (j & 1) ? sx[j >> 1].y : sx[j >> 1].x, py = (j & 1) ? sy[j >> 1].y : sy[j >> 1].x;
+    if (PADDING == PAD_REFLECTION) {
+      px = reflect_coord(px, -1, 2 * W - 1);
+      py = reflect_coord(py, -1, 2 * H - 1);
+    }
+    if (PADDING != PAD_ZEROS) {  // clip_coord
+      px = fminf(wm1, fmaxf(px, 0.0f));
+      py = fminf(hm1, fmaxf(py, 0.0f));
+    }
+    ix[j] = px;
+    iy[j] = py;
+    x0f[j] = floorf(px);
+    y0f[j] = floorf(py);
+  }
+  const float wf = (float)W;
   for (int c = 0; c < a.C; ++c) {
     const float *pl = a.image + (n * a.C + c) * (int64_t)HW;
-    // (base in scalar registers, 32-bit byte offsets; reads beyond the plane cannot happen: the
-    // offsets are clamped into it)
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pl), 0, HW * 4, 0x00020000);
-    unsigned t00[4], t01[4], t10[4], t11[4];  // (the pixels' BITS: the loads return integers)
+    unsigned t00[ROWS], t01[ROWS], t10[ROWS], t11[ROWS];  // (the pixels' BITS: the loads return integers)
+    if (PADDING == PAD_ZEROS) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {  // all the taps in flight (taps outside the image: any valid address)
-      const int x0 = (int)x0f[j], y0 = (int)y0f[j];
-      const int xc0 = PADDING == PAD_ZEROS ? min(max(x0, 0), W - 1) : x0, xc1 = min(max(x0 + 1, 0), W - 1);
-      const int yc0 = (PADDING == PAD_ZEROS ? min(max(y0, 0), H - 1) : y0) * W, yc1 = min(max(y0 + 1, 0), H - 1) * W;
-      t00[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc0 + xc0) << 2, 0, 0);
-      t01[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc0 + xc1) << 2, 0, 0);
-      t10[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc1 + xc0) << 2, 0, 0);
-      t11[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc1 + xc1) << 2, 0, 0);
+      for (int j = 0; j < ROWS; ++j) {  // taps outside the image: any valid address, left out below
+        const int x0 = (int)x0f[j], y0 = (int)y0f[j];
+        const int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x0 + 1, 0), W - 1);
+        const int yc0 = min(max(y0, 0), H - 1) * W, yc1 = min(max(y0 + 1, 0), H - 1) * W;
+        t00[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc0 + xc0) << 2, 0, 0);
+        t01[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc0 + xc1) << 2, 0, 0);
+        t10[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc1 + xc0) << 2, 0, 0);
+        t11[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (yc1 + xc1) << 2, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < ROWS; ++j) {  // all the taps in flight
+        const int o00 = (int)__builtin_fmaf(y0f[j], wf, x0f[j]) << 2;
+        const int right = x0f[j] < wm1 ? 4 : 0x40000000, down = y0f[j] < hm1 ? 4 * W : 0x40000000;
+        const int o10 = o00 + down;
+        t00[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o00, 0, 0);
+        t01[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o00 + right, 0, 0);
+        t10[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o10, 0, 0);
+        t11[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o10 + right, 0, 0);
+      }
     }
     float *po = a.out + (n * a.C + c) * (int64_t)HW;
     const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(po, 0, HW * 4, 0x00020000);
+    const int obase = (h0 * W + w) << 2;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int x0 = (int)x0f[j], y0 = (int)y0f[j], x1 = x0 + 1, y1 = y0 + 1;
+    for (int j = 0; j < ROWS; ++j) {
       const float wx1 = ix[j] - x0f[j], wy1 = iy[j] - y0f[j], wx0 = (x0f[j] + 1.0f) - ix[j], wy0 = (y0f[j] + 1.0f) - iy[j];
-      const bool vx0 = PADDING != PAD_ZEROS || (x0 >= 0 && x0 < W), vx1 = x1 >= 0 && x1 < W;
-      const bool vy0 = PADDING != PAD_ZEROS || (y0 >= 0 && y0 < H), vy1 = y1 >= 0 && y1 < H;
-      // (a tap outside the image is left out, as image_warp_kernel does -- a select, not a product
-      // with 0: that would turn an inf / NaN pixel into NaN)
-      float acc = (vx0 && vy0) ? __uint_as_float(t00[j]) * (wx0 * wy0) : 0.0f;
-      acc += (vx1 && vy0) ? __uint_as_float(t01[j]) * (wx1 * wy0) : 0.0f;
-      acc += (vx0 && vy1) ? __uint_as_float(t10[j]) * (wx0 * wy1) : 0.0f;
-      acc += (vx1 && vy1) ? __uint_as_float(t11[j]) * (wx1 * wy1) : 0.0f;
-      if (h0 + j < H) __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(acc), ro, ((h0 + j) * W + w) << 2, 0, 0);
+      float acc;
+      if (PADDING == PAD_ZEROS) {
+        const int x0 = (int)x0f[j], y0 = (int)y0f[j], x1 = x0 + 1, y1 = y0 + 1;
+        const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W, vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
+        // (a select, not a product with 0: that would turn an inf / NaN pixel into NaN)
+        acc = (vx0 && vy0) ? __uint_as_float(t00[j]) * (wx0 * wy0) : 0.0f;
+        acc += (vx1 && vy0) ? __uint_as_float(t01[j]) * (wx1 * wy0) : 0.0f;
+        acc += (vx0 && vy1) ? __uint_as_float(t10[j]) * (wx0 * wy1) : 0.0f;
+        acc += (vx1 && vy1) ? __uint_as_float(t11[j]) * (wx1 * wy1) : 0.0f;
+      } else {
+        acc = __uint_as_float(t00[j]) * (wx0 * wy0);
+        acc += __uint_as_float(t01[j]) * (wx1 * wy0);
+        acc += __uint_as_float(t10[j]) * (wx0 * wy1);
+        acc += __uint_as_float(t11[j]) * (wx1 * wy1);
+      }
+      if (h0 + j < H) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc), ro, obase + j * (4 * W), 0, 0);
     }
   }
 }
@@ -991,6 +1045,7 @@ int64_t pdt_spline_workspace_bytes(int64_t N, int64_t T, int64_t I, int64_t O) {
   if (N < 0 || T < 0 || I < 0 || O < 0) return 0;
   const int64_t S = T + I + 1;
   int64_t bytes = N * S * O * (int64_t)(sizeof(double) + sizeof(float)) + 64;
+  bytes += N * pdt::kWarpTableFloats * (int64_t)sizeof(float);  // sparse_warp_bands_kernel's per-image table
   // systems beyond the LDS are eliminated in global memory, after the solutions
   if ((size_t)S * (S + O) * sizeof(double) + 16 > pdt::kSplineLdsCap) bytes += N * S * (S + O) * (int64_t)sizeof(double);
   return bytes;
@@ -1226,8 +1281,11 @@ static int sparse_warp_launch(const float *image, const float *train_points,
   if (rc != PDT_OK) return rc;
   const int64_t total = N * (M + 3) * 2;
   float *wvf = reinterpret_cast<float *>(wv + total);
-  hipLaunchKernelGGL(cast_wv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
-                     (hipStream_t)stream, wv, wvf, total);
+  // (the bands kernel reads its own table, written from the double solution by warp_table_kernel)
+  const bool fast_shape = !grad_image && mode == INTERP_BILINEAR && !flow_out && M <= kWarpFastM && H * W < (1 << 23);
+  if (!(fast_shape && switches().warp_bands != 0))
+    hipLaunchKernelGGL(cast_wv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, wv, wvf, total);
   WarpArgs a{};
   a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
   a.mode = mode; a.padding = padding;
@@ -1241,21 +1299,27 @@ static int sparse_warp_launch(const float *image, const float *train_points,
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
-  } else if (mode == INTERP_BILINEAR && !flow_out && M <= kWarpFastM && H * W < (1 << 23)) {
-    // a lane = a column of four rows, centres in scalar registers (sparse_warp_bands_kernel);
+  } else if (fast_shape) {
+    // a lane = a column of kBandRows rows, the image's constants from a table (sparse_warp_bands_kernel);
     // PDT_WARP_BANDS=0: four pixels 256 apart per lane (sparse_warp_fast_kernel, for comparisons)
     const bool rows4 = switches().warp_bands != 0;
     const int per_wg = 256 * kWarpPix;
-    const int64_t lanes = ((H + 3) / 4) * W;
+    const int64_t lanes = ((H + kBandRows - 1) / kBandRows) * W;
     const dim3 gf(rows4 ? (unsigned)((lanes + 255) / 256) : (unsigned)((H * W + per_wg - 1) / per_wg), (unsigned)N);
     auto go = [&](auto ord) {
       constexpr int O = decltype(ord)::value;
       if (rows4) {
         auto bands = [&](auto mc) {
           constexpr int MC = decltype(mc)::value;
-          if (padding == PAD_BORDER) hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_BORDER, MC>), gf, dim3(256), smem, (hipStream_t)stream, a);
-          else if (padding == PAD_ZEROS) hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_ZEROS, MC>), gf, dim3(256), smem, (hipStream_t)stream, a);
-          else hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_REFLECTION, MC>), gf, dim3(256), smem, (hipStream_t)stream, a);
+          float *tab = wvf + total;
+          const int64_t entries = N * warp_table_stride(MC);
+          hipLaunchKernelGGL(warp_table_kernel, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                             wv, train_points, tab, N, (int)M, MC, values_are_grid, (int)H, (int)W, order);
+          a.wv = tab;
+          a.inv_w = 1.0f / (float)W;
+          if (padding == PAD_BORDER) hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_BORDER, MC, kBandRows>), gf, dim3(256), 0, (hipStream_t)stream, a);
+          else if (padding == PAD_ZEROS) hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_ZEROS, MC, kBandRows>), gf, dim3(256), 0, (hipStream_t)stream, a);
+          else hipLaunchKernelGGL((sparse_warp_bands_kernel<O, PAD_REFLECTION, MC, kBandRows>), gf, dim3(256), 0, (hipStream_t)stream, a);
         };
         // (seven centres = three control points + four pinned corners, the SpecAugment-style call)
         if (M == 7) bands(std::integral_constant<int, 7>{}); else bands(std::integral_constant<int, kWarpFastM>{});
