@@ -469,6 +469,25 @@ int pdt_sparse_image_warp(const float *image, const float *train_points,
                           int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
                           void *workspace, void *stream);
 
+/* float64 images: the reference samples a double image on a double grid (_img.py:423-436) while
+ * flows and spline points stay float32 (:420, :537-538).  Same arguments as the float32 entries. */
+int pdt_dense_image_warp_f64(const double *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                             int64_t W, int flow_is_hw, int mode, int padding, double *out,
+                             void *stream);
+int pdt_dense_image_warp_backward_f64(const double *grad_out, const float *flow, int64_t N, int64_t C,
+                                      int64_t H, int64_t W, int flow_is_hw, int mode, int padding,
+                                      double *grad_image, void *stream);
+int pdt_sparse_image_warp_f64(const double *image, const float *train_points,
+                              const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
+                              int64_t M, int order, float regularization_weight, int values_are_grid,
+                              int mode, int padding, double *out, float *flow_out, int flow_out_is_hw,
+                              void *workspace, void *stream);
+int pdt_sparse_image_warp_backward_f64(const double *grad_out, const float *train_points,
+                                       const float *train_values, int64_t N, int64_t C, int64_t H,
+                                       int64_t W, int64_t M, int order, float regularization_weight,
+                                       int values_are_grid, int mode, int padding, double *grad_image,
+                                       void *workspace, void *stream);
+
 int pdt_spec_augment_apply_backward(const float *grad_out, int64_t N, int64_t T, int64_t F,
                                     const float *time_grid, const float *freq_grid,
                                     const int64_t *t_0, const int64_t *t_len, int64_t MT,

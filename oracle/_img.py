@@ -105,7 +105,9 @@ def _reflect(x, lo2, hi2):
 def grid_sample(image, grid, mode="bilinear", padding_mode="zeros"):
     """torch.nn.functional.grid_sample(image (N,C,H,W), grid (N,Ho,Wo,2), align_corners=False)."""
     img = _np(image).astype(np.float64)
-    g = _np(grid).astype(np.float32).astype(np.float64)
+    # (a float32 image's grid is a float32 tensor; a float64 image's grid is float64: the reference
+    # builds it from arange(..., dtype=image.dtype), _img.py:423-436)
+    g = _np(grid).astype(np.float64) if _np(image).dtype == np.float64 else _np(grid).astype(np.float32).astype(np.float64)
     N, C, H, W = img.shape
     ix = ((g[..., 0] + 1) * W - 1) / 2
     iy = ((g[..., 1] + 1) * H - 1) / 2

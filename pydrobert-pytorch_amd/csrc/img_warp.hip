@@ -244,11 +244,27 @@ warp_1d_grid_kernel(const float *__restrict__ src, const float *__restrict__ flo
 enum { PAD_ZEROS = 0, PAD_BORDER = 1, PAD_REFLECTION = 2 };
 enum { INTERP_BILINEAR = 0, INTERP_NEAREST = 1 };
 
-__device__ __forceinline__ float unnormalize(float g, int size) {
-  return ((g + 1.0f) * (float)size - 1.0f) * 0.5f;
+// (CT: the coordinate type -- float, or double for float64 images, whose grid the reference forms
+// and samples in float64, _img.py:420-436)
+template <typename CT>
+__device__ __forceinline__ CT unnormalize(CT g, int size) {
+  return ((g + CT(1)) * (CT)size - CT(1)) * CT(0.5);
+}
+template <typename CT>
+__device__ __forceinline__ CT clip_coord(CT x, int size) {
+  return fmin((CT)(size - 1), fmax(x, CT(0)));
 }
 __device__ __forceinline__ float clip_coord(float x, int size) {
   return fminf((float)(size - 1), fmaxf(x, 0.0f));
+}
+template <typename CT>
+__device__ __forceinline__ CT reflect_coord(CT x, int twice_low, int twice_high) {
+  if (twice_low == twice_high) return CT(0);
+  const CT mn = (CT)twice_low * CT(0.5), span = (CT)(twice_high - twice_low) * CT(0.5);
+  x = fabs(x - mn);
+  const CT extra = fmod(x, span);
+  const int flips = (int)floor(x / span);
+  return (flips & 1) ? span - extra + mn : extra + mn;
 }
 __device__ __forceinline__ float reflect_coord(float x, int twice_low, int twice_high) {
   if (twice_low == twice_high) return 0.0f;
@@ -258,8 +274,9 @@ __device__ __forceinline__ float reflect_coord(float x, int twice_low, int twice
   const int flips = (int)floorf(x / span);
   return (flips & 1) ? span - extra + mn : extra + mn;
 }
-__device__ __forceinline__ float source_index(float g, int size, int padding) {
-  float x = unnormalize(g, size);
+template <typename CT>
+__device__ __forceinline__ CT source_index(CT g, int size, int padding) {
+  CT x = unnormalize(g, size);
   if (padding == PAD_BORDER) x = clip_coord(x, size);
   else if (padding == PAD_REFLECTION) x = clip_coord(reflect_coord(x, -1, 2 * size - 1), size);
   return x;
@@ -550,9 +567,11 @@ spec_augment_rows_backward_kernel(const SpecAugArgs a, const float *__restrict__
   }
 }
 
-struct WarpArgs {
-  const float *image;  // (N,C,H,W) contiguous
-  float *out;          // (N,C,H,W)
+// PT: the pixel type (float; double for float64 images -- image_warp_kernel only, see there)
+template <typename PT>
+struct WarpArgsT {
+  const PT *image;     // (N,C,H,W) contiguous
+  PT *out;             // (N,C,H,W)
   int N, C, H, W;
   int mode, padding;
   // source of the sampling position, one of:
@@ -564,14 +583,20 @@ struct WarpArgs {
   float inv_w;         // 1 / W (sparse_warp_bands_kernel)
   float *flow_out;     // sparse, optional (N,H,W,2)
   int flow_out_flip;
-  float *grad_image;   // BACKWARD: (N,C,H,W), zeroed by the caller; `out` then holds grad_out
+  PT *grad_image;      // BACKWARD: (N,C,H,W), zeroed by the caller; `out` then holds grad_out
 };
+using WarpArgs = WarpArgsT<float>;
 
 // BACKWARD = adjoint with respect to the image: the same sampling positions, each pixel scatters
 // its gradient to its taps with the hardware float atomic.
+// PT = double: a float64 image.  The reference keeps flows and spline points in float32 whatever
+// the image's type (_img.py:420, :537-538) but forms the sampling grid and samples it in the
+// image's type (:423-436), so here the flow / spline value stays float and everything from the grid
+// on (un-normalisation, padding, weights, blend, the adjoint's atomics) is double.
 constexpr int kPixPerWG = 2048;
-template <bool BACKWARD>
-__global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
+template <bool BACKWARD, typename PT = float>
+__global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgsT<PT> a) {
+  using CT = PT;  // coordinate type
   extern __shared__ __align__(16) unsigned char smem[];
   float *lk = reinterpret_cast<float *>(smem);  // knots (M,2) then weights (M+3,2)
   float *lw = lk + 2 * a.M;
@@ -599,7 +624,9 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
       h = pix / W;
       w = pix - h * W;
     }
-    float gx, gy;
+    CT gx, gy;
+    const CT inv_wc = std::is_same<CT, float>::value ? (CT)inv_w : CT(1) / (CT)W;
+    const CT inv_hc = std::is_same<CT, float>::value ? (CT)inv_h : CT(1) / (CT)H;
     if (a.knots) {
       const float x = (float)w, y = (float)h;
       float sx = lw[2 * a.M + 0] * x + lw[2 * (a.M + 1) + 0] * y + lw[2 * (a.M + 2) + 0];
@@ -628,40 +655,40 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
           fo[0] = a.flow_out_flip ? sy : sx;
           fo[1] = a.flow_out_flip ? sx : sy;
         }
-        gx = (2.0f * x - 2.0f * sx + 1.0f) * inv_w - 1.0f;  // _img.py:432
-        gy = (2.0f * y - 2.0f * sy + 1.0f) * inv_h - 1.0f;
+        gx = (CT(2) * (CT)x - CT(2) * (CT)sx + CT(1)) * inv_wc - CT(1);  // _img.py:432
+        gy = (CT(2) * (CT)y - CT(2) * (CT)sy + CT(1)) * inv_hc - CT(1);
       }
     } else {
       const float *fl = a.flow + ((n * H + h) * (int64_t)W + w) * 2;
       const float fx = a.flip ? fl[1] : fl[0], fy = a.flip ? fl[0] : fl[1];
-      gx = (2.0f * (float)w - 2.0f * fx + 1.0f) * inv_w - 1.0f;
-      gy = (2.0f * (float)h - 2.0f * fy + 1.0f) * inv_h - 1.0f;
+      gx = (CT(2) * (CT)w - CT(2) * (CT)fx + CT(1)) * inv_wc - CT(1);
+      gy = (CT(2) * (CT)h - CT(2) * (CT)fy + CT(1)) * inv_hc - CT(1);
     }
-    const float ix = source_index(gx, W, a.padding), iy = source_index(gy, H, a.padding);
+    const CT ix = source_index<CT>(gx, W, a.padding), iy = source_index<CT>(gy, H, a.padding);
     const int64_t plane = (int64_t)H * W;
-    const float *img = a.image + n * a.C * plane;
-    float *o = a.out + n * a.C * plane + pix;
-    float *gi = a.grad_image + n * a.C * plane;
+    const PT *img = a.image + n * a.C * plane;
+    PT *o = a.out + n * a.C * plane + pix;
+    PT *gi = a.grad_image + n * a.C * plane;
     if (a.mode == INTERP_NEAREST) {
-      const int xn = (int)nearbyintf(ix), yn = (int)nearbyintf(iy);
+      const int xn = (int)nearbyint(ix), yn = (int)nearbyint(iy);
       const bool ok = xn >= 0 && xn < W && yn >= 0 && yn < H;
       if (BACKWARD) {
         if (ok)
           for (int c = 0; c < a.C; ++c) unsafeAtomicAdd(gi + c * plane + (int64_t)yn * W + xn, o[c * plane]);
         continue;
       }
-      for (int c = 0; c < a.C; ++c) o[c * plane] = ok ? img[c * plane + (int64_t)yn * W + xn] : 0.0f;
+      for (int c = 0; c < a.C; ++c) o[c * plane] = ok ? img[c * plane + (int64_t)yn * W + xn] : PT(0);
       continue;
     }
-    const float x0f = floorf(ix), y0f = floorf(iy);
+    const CT x0f = floor(ix), y0f = floor(iy);
     const int x0 = (int)x0f, y0 = (int)y0f, x1 = x0 + 1, y1 = y0 + 1;
-    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.0f) - ix, wy0 = (y0f + 1.0f) - iy;
+    const CT wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + CT(1)) - ix, wy0 = (y0f + CT(1)) - iy;
     const bool vx0 = x0 >= 0 && x0 < W, vx1 = x1 >= 0 && x1 < W;
     const bool vy0 = y0 >= 0 && y0 < H, vy1 = y1 >= 0 && y1 < H;
     if (BACKWARD) {
       for (int c = 0; c < a.C; ++c) {
-        float *pl = gi + c * plane;
-        const float g = o[c * plane];
+        PT *pl = gi + c * plane;
+        const PT g = o[c * plane];
         if (vx0 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x0, g * (wx0 * wy0));
         if (vx1 && vy0) unsafeAtomicAdd(pl + (int64_t)y0 * W + x1, g * (wx1 * wy0));
         if (vx0 && vy1) unsafeAtomicAdd(pl + (int64_t)y1 * W + x0, g * (wx0 * wy1));
@@ -670,8 +697,8 @@ __global__ void __launch_bounds__(256) image_warp_kernel(const WarpArgs a) {
       continue;
     }
     for (int c = 0; c < a.C; ++c) {
-      const float *pl = img + c * plane;
-      float v = 0.0f;
+      const PT *pl = img + c * plane;
+      PT v = PT(0);
       if (vx0 && vy0) v += pl[(int64_t)y0 * W + x0] * (wx0 * wy0);
       if (vx1 && vy0) v += pl[(int64_t)y0 * W + x1] * (wx1 * wy0);
       if (vx0 && vy1) v += pl[(int64_t)y1 * W + x0] * (wx0 * wy1);
@@ -1223,50 +1250,55 @@ int pdt_spec_augment_apply_backward(const float *grad_out, int64_t N, int64_t T,
   return (int)hipGetLastError();
 }
 
-static int dense_warp_launch(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
-                             int64_t W, int flow_is_hw, int mode, int padding, float *out,
-                             float *grad_image, void *stream) {
+extern "C++" {
+template <typename PT>
+static int dense_warp_launch(const PT *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                             int64_t W, int flow_is_hw, int mode, int padding, PT *out,
+                             PT *grad_image, void *stream) {
   using namespace pdt;
   if (N < 0 || C < 0 || H < 0 || W < 0 || mode < 0 || mode > 1 || padding < 0 || padding > 2)
     return PDT_E_ARG;
   if (N == 0 || C == 0 || H == 0 || W == 0) return PDT_OK;
   if ((!image && !grad_image) || !flow || !out) return PDT_E_ARG;
   if (H * W >= (1ll << 31) || N > 65535) return PDT_E_TOO_LONG;
-  WarpArgs a{};
+  WarpArgsT<PT> a{};
   a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
   a.mode = mode; a.padding = padding; a.flow = flow; a.flip = flow_is_hw;
   a.grad_image = grad_image;
   const dim3 grid((unsigned)((H * W + kPixPerWG - 1) / kPixPerWG), (unsigned)N);
   if (grad_image) {
-    hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(float),
+    hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(PT),
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((image_warp_kernel<true, PT>), grid, dim3(256), 0, (hipStream_t)stream, a);
   } else {
-    hipLaunchKernelGGL(image_warp_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((image_warp_kernel<false, PT>), grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   return (int)hipGetLastError();
 }
+}  // extern "C++"
 
 int pdt_dense_image_warp(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
                          int64_t W, int flow_is_hw, int mode, int padding, float *out,
                          void *stream) {
-  return dense_warp_launch(image, flow, N, C, H, W, flow_is_hw, mode, padding, out, nullptr, stream);
+  return dense_warp_launch<float>(image, flow, N, C, H, W, flow_is_hw, mode, padding, out, nullptr, stream);
 }
 
 int pdt_dense_image_warp_backward(const float *grad_out, const float *flow, int64_t N, int64_t C,
                                   int64_t H, int64_t W, int flow_is_hw, int mode, int padding,
                                   float *grad_image, void *stream) {
   if (!grad_image && N && C && H && W) return PDT_E_ARG;
-  return dense_warp_launch(nullptr, flow, N, C, H, W, flow_is_hw, mode, padding,
-                           const_cast<float *>(grad_out), grad_image, stream);
+  return dense_warp_launch<float>(nullptr, flow, N, C, H, W, flow_is_hw, mode, padding,
+                                  const_cast<float *>(grad_out), grad_image, stream);
 }
 
-static int sparse_warp_launch(const float *image, const float *train_points,
+extern "C++" {
+template <typename PT>
+static int sparse_warp_launch(const PT *image, const float *train_points,
                               const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
                               int64_t M, int order, float regularization_weight, int values_are_grid,
-                              int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
-                              float *grad_image, void *workspace, void *stream) {
+                              int mode, int padding, PT *out, float *flow_out, int flow_out_is_hw,
+                              PT *grad_image, void *workspace, void *stream) {
   using namespace pdt;
   if (N < 0 || C < 0 || H < 0 || W < 0 || M < 1 || order < 1 || mode < 0 || mode > 1 ||
       padding < 0 || padding > 2)
@@ -1282,11 +1314,12 @@ static int sparse_warp_launch(const float *image, const float *train_points,
   const int64_t total = N * (M + 3) * 2;
   float *wvf = reinterpret_cast<float *>(wv + total);
   // (the bands kernel reads its own table, written from the double solution by warp_table_kernel)
-  const bool fast_shape = !grad_image && mode == INTERP_BILINEAR && !flow_out && M <= kWarpFastM && H * W < (1 << 23);
+  constexpr bool kFloat = std::is_same<PT, float>::value;  // (the fast forms are float32 kernels)
+  const bool fast_shape = kFloat && !grad_image && mode == INTERP_BILINEAR && !flow_out && M <= kWarpFastM && H * W < (1 << 23);
   if (!(fast_shape && switches().warp_bands != 0))
     hipLaunchKernelGGL(cast_wv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, wv, wvf, total);
-  WarpArgs a{};
+  WarpArgsT<PT> a{};
   a.image = image; a.out = out; a.N = (int)N; a.C = (int)C; a.H = (int)H; a.W = (int)W;
   a.mode = mode; a.padding = padding;
   a.knots = train_points; a.wv = wvf; a.M = (int)M; a.order = order; a.as_grid = values_are_grid;
@@ -1295,11 +1328,14 @@ static int sparse_warp_launch(const float *image, const float *train_points,
   const size_t smem = (size_t)(2 * M + 2 * (M + 3)) * sizeof(float);
   const dim3 grid((unsigned)((H * W + kPixPerWG - 1) / kPixPerWG), (unsigned)N);
   if (grad_image) {
-    hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(float),
+    hipError_t e = hipMemsetAsync(grad_image, 0, (size_t)(N * C * H * W) * sizeof(PT),
                                   (hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(image_warp_kernel<true>, grid, dim3(256), smem, (hipStream_t)stream, a);
-  } else if (fast_shape) {
+    hipLaunchKernelGGL((image_warp_kernel<true, PT>), grid, dim3(256), smem, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
+  if constexpr (kFloat) {
+   if (fast_shape) {
     // a lane = a column of kBandRows rows, the image's constants from a table (sparse_warp_bands_kernel);
     // PDT_WARP_BANDS=0: four pixels 256 apart per lane (sparse_warp_fast_kernel, for comparisons)
     const bool rows4 = switches().warp_bands != 0;
@@ -1333,20 +1369,22 @@ static int sparse_warp_launch(const float *image, const float *train_points,
     else if (order == 1) go(std::integral_constant<int, 1>{});
     else if (order == 3) go(std::integral_constant<int, 3>{});
     else go(std::integral_constant<int, 0>{});
-  } else {
-    hipLaunchKernelGGL(image_warp_kernel<false>, grid, dim3(256), smem, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+   }
   }
+  hipLaunchKernelGGL((image_warp_kernel<false, PT>), grid, dim3(256), smem, (hipStream_t)stream, a);
   return (int)hipGetLastError();
 }
+}  // extern "C++"
 
 int pdt_sparse_image_warp(const float *image, const float *train_points,
                           const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
                           int64_t M, int order, float regularization_weight, int values_are_grid,
                           int mode, int padding, float *out, float *flow_out, int flow_out_is_hw,
                           void *workspace, void *stream) {
-  return sparse_warp_launch(image, train_points, train_values, N, C, H, W, M, order,
-                            regularization_weight, values_are_grid, mode, padding, out, flow_out,
-                            flow_out_is_hw, nullptr, workspace, stream);
+  return sparse_warp_launch<float>(image, train_points, train_values, N, C, H, W, M, order,
+                                   regularization_weight, values_are_grid, mode, padding, out, flow_out,
+                                   flow_out_is_hw, nullptr, workspace, stream);
 }
 
 int pdt_sparse_image_warp_backward(const float *grad_out, const float *train_points,
@@ -1355,9 +1393,47 @@ int pdt_sparse_image_warp_backward(const float *grad_out, const float *train_poi
                                    int values_are_grid, int mode, int padding, float *grad_image,
                                    void *workspace, void *stream) {
   if (!grad_image && N && C && H && W) return PDT_E_ARG;
-  return sparse_warp_launch(nullptr, train_points, train_values, N, C, H, W, M, order,
-                            regularization_weight, values_are_grid, mode, padding,
-                            const_cast<float *>(grad_out), nullptr, 0, grad_image, workspace, stream);
+  return sparse_warp_launch<float>(nullptr, train_points, train_values, N, C, H, W, M, order,
+                                   regularization_weight, values_are_grid, mode, padding,
+                                   const_cast<float *>(grad_out), nullptr, 0, grad_image, workspace, stream);
+}
+
+// float64 images (the reference samples a double image on a double grid, _img.py:423-436; flows and
+// spline points are float32 there whatever the image's type, :420, :537-538): image_warp_kernel in
+// double from the grid on.  Same arguments as the float32 entries.
+int pdt_dense_image_warp_f64(const double *image, const float *flow, int64_t N, int64_t C, int64_t H,
+                             int64_t W, int flow_is_hw, int mode, int padding, double *out,
+                             void *stream) {
+  return dense_warp_launch<double>(image, flow, N, C, H, W, flow_is_hw, mode, padding, out, nullptr, stream);
+}
+
+int pdt_dense_image_warp_backward_f64(const double *grad_out, const float *flow, int64_t N, int64_t C,
+                                      int64_t H, int64_t W, int flow_is_hw, int mode, int padding,
+                                      double *grad_image, void *stream) {
+  if (!grad_image && N && C && H && W) return PDT_E_ARG;
+  return dense_warp_launch<double>(nullptr, flow, N, C, H, W, flow_is_hw, mode, padding,
+                                   const_cast<double *>(grad_out), grad_image, stream);
+}
+
+int pdt_sparse_image_warp_f64(const double *image, const float *train_points,
+                              const float *train_values, int64_t N, int64_t C, int64_t H, int64_t W,
+                              int64_t M, int order, float regularization_weight, int values_are_grid,
+                              int mode, int padding, double *out, float *flow_out, int flow_out_is_hw,
+                              void *workspace, void *stream) {
+  return sparse_warp_launch<double>(image, train_points, train_values, N, C, H, W, M, order,
+                                    regularization_weight, values_are_grid, mode, padding, out, flow_out,
+                                    flow_out_is_hw, nullptr, workspace, stream);
+}
+
+int pdt_sparse_image_warp_backward_f64(const double *grad_out, const float *train_points,
+                                       const float *train_values, int64_t N, int64_t C, int64_t H,
+                                       int64_t W, int64_t M, int order, float regularization_weight,
+                                       int values_are_grid, int mode, int padding, double *grad_image,
+                                       void *workspace, void *stream) {
+  if (!grad_image && N && C && H && W) return PDT_E_ARG;
+  return sparse_warp_launch<double>(nullptr, train_points, train_values, N, C, H, W, M, order,
+                                    regularization_weight, values_are_grid, mode, padding,
+                                    const_cast<double *>(grad_out), nullptr, 0, grad_image, workspace, stream);
 }
 
 }  // extern "C"

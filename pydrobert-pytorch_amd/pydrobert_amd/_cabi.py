@@ -134,6 +134,17 @@ SIGNATURES = {
         _INT,
         [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _P],
     ),
+    # float64 images: the same argument lists, double pixels
+    "pdt_dense_image_warp_f64": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P, _P]),
+    "pdt_dense_image_warp_backward_f64": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P, _P]),
+    "pdt_sparse_image_warp_f64": (
+        _INT,
+        [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _INT, _P, _P],
+    ),
+    "pdt_sparse_image_warp_backward_f64": (
+        _INT,
+        [_P, _P, _P, _I64, _I64, _I64, _I64, _I64, _INT, _F, _INT, _INT, _INT, _P, _P, _P],
+    ),
     "pdt_lookup_lm_log_probs": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I64, _I64, _P, _P, _P],

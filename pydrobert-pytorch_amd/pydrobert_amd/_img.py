@@ -48,9 +48,13 @@ _NARROWING_WARNED = False
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
-    """float32 contiguous view / copy of ``t`` for the kernels.  The image kernels compute in float32
-    (the spline systems are solved in float64 inside); a float64 argument is narrowed, results are
-    cast back -- said out loud once per process, since the reference would have computed in float64."""
+    """float32 contiguous view / copy of ``t`` for the kernels.  Splines, 1-D grids and SpecAugment's
+    resampling compute in float32 (the spline systems are solved in float64 inside); a float64
+    argument there is narrowed and the result cast back, said out loud once per process.  (The
+    reference itself keeps spline points, flows and 1-D grids in float32, _img.py:142-143, :283, :420,
+    and RAISES for float64 spline values / SpecAugment warps -- a dtype mismatch inside
+    ``linalg.solve`` / ``grid_sample``; its one float64 computation, sampling a float64 image, is
+    float64 here too: ``_pixels``.)"""
     global _NARROWING_WARNED
     t = t.detach()
     if t.dtype != torch.float:
@@ -62,6 +66,15 @@ def _f32c(t: torch.Tensor) -> torch.Tensor:
             )
         t = t.float()
     return t.contiguous()
+
+
+def _pixels(t: torch.Tensor) -> Tuple[torch.Tensor, str]:
+    """(contiguous pixels, entry-point suffix) for the gathers: a float64 image is sampled in float64
+    (``pdt_*_f64``: the reference forms the grid and samples it in the image's type, _img.py:423-436;
+    flows and spline points are float32 there whatever the image's type); anything else in float32."""
+    if t.dtype == torch.double:
+        return t.detach().contiguous(), "_f64"
+    return _f32c(t), ""
 
 
 @custom_op("pydrobert_amd::polyharmonic_spline", mutates_args=())
@@ -309,10 +322,10 @@ def _dense_image_warp_op(
     if flow.shape != (N, H, W, 2):
         raise RuntimeError("expected flow to have shape {}, got {}".format((N, H, W, 2), tuple(flow.shape)))
     device = _cabi.require_hip(image, flow)
-    img, fl = _f32c(image), _f32c(flow)
+    (img, sfx), fl = _pixels(image), _f32c(flow)
     with torch.cuda.device(device):
         out = torch.empty_like(img)
-        rc = _cabi.lib().pdt_dense_image_warp(
+        rc = getattr(_cabi.lib(), "pdt_dense_image_warp" + sfx)(
             _cabi.ptr(img), _cabi.ptr(fl), N, C, H, W, int(indexing == "hw"), _MODES[mode],
             _PADDINGS[padding_mode], _cabi.ptr(out), _cabi.stream_ptr(device),
         )  # fmt: skip
@@ -331,11 +344,11 @@ def _dense_image_warp_backward_op(
 ) -> torch.Tensor:
     """Adjoint of the gather with respect to the image (csrc/img_warp.hip, BACKWARD)."""
     device = _cabi.require_hip(grad_out, flow)
-    g, fl = _f32c(grad_out), _f32c(flow)
+    (g, sfx), fl = _pixels(grad_out), _f32c(flow)
     N, C, H, W = g.shape
     with torch.cuda.device(device):
         grad = torch.empty_like(g)
-        rc = _cabi.lib().pdt_dense_image_warp_backward(
+        rc = getattr(_cabi.lib(), "pdt_dense_image_warp_backward" + sfx)(
             _cabi.ptr(g), _cabi.ptr(fl), N, C, H, W, int(indexing == "hw"), _MODES[mode],
             _PADDINGS[padding_mode], _cabi.ptr(grad), _cabi.stream_ptr(device),
         )  # fmt: skip
@@ -489,13 +502,13 @@ def _sparse_image_warp_op(
         return image.clone(), torch.zeros(
             (N, H, W, 2) if include_flow else (0,), dtype=torch.float, device=device
         )
-    img = _f32c(image)
+    img, sfx = _pixels(image)
     L = _cabi.lib()
     with torch.cuda.device(device):
         out = torch.empty_like(img)
         flow = torch.empty((N, H, W, 2) if include_flow else (0,), device=device, dtype=torch.float)
         ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, Mp, 2, 2)),), device=device, dtype=torch.uint8)
-        rc = L.pdt_sparse_image_warp(
+        rc = getattr(L, "pdt_sparse_image_warp" + sfx)(
             _cabi.ptr(img), _cabi.ptr(pts), _cabi.ptr(vals), N, C, H, W, Mp,
             int(field_interpolation_order), float(field_regularization_weight),
             int(not include_flow), _MODES[dense_interpolation_mode], _PADDINGS[dense_padding_mode],
@@ -525,13 +538,13 @@ def _sparse_image_warp_backward_op(
     )
     if Mp == 0:
         return grad_out.clone()
-    g = _f32c(grad_out)
+    g, sfx = _pixels(grad_out)
     N, C, H, W = g.shape
     L = _cabi.lib()
     with torch.cuda.device(device):
         grad = torch.empty_like(g)
         ws = torch.empty((int(L.pdt_spline_workspace_bytes(N, Mp, 2, 2)),), device=device, dtype=torch.uint8)
-        rc = L.pdt_sparse_image_warp_backward(
+        rc = getattr(L, "pdt_sparse_image_warp_backward" + sfx)(
             _cabi.ptr(g), _cabi.ptr(pts), _cabi.ptr(vals), N, C, H, W, Mp,
             int(field_interpolation_order), float(field_regularization_weight),
             int(not include_flow), _MODES[dense_interpolation_mode], _PADDINGS[dense_padding_mode],

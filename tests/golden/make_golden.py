@@ -741,3 +741,48 @@ def spec_draw_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "spec_draw"):
     spec_draw_goldens()
+
+
+def image_f64_goldens():
+    """The reference's float64 image path: dense_image_warp / sparse_image_warp(include_flow=True) on a
+    float64 image (the grid is formed and sampled in float64, _img.py:423-436; the flow and the
+    spline stay float32, :420, :537-538).  Its other image operators RAISE on float64 values (a dtype
+    mismatch in linalg.solve / grid_sample), which the last entries record."""
+    rng = np.random.default_rng(0x5EED000C)
+    d = {}
+    N, C, H, W = 2, 2, 11, 7
+    img = torch.from_numpy(rng.normal(size=(N, C, H, W)))
+    flow = torch.from_numpy((rng.normal(size=(N, H, W, 2)) * 2.5).astype(np.float32))
+    d.update(img=img, flow=flow)
+    for mode in ("bilinear", "nearest"):
+        for pad in ("border", "zeros", "reflection"):
+            for ind in ("hw", "wh"):
+                d["dense_{}_{}_{}".format(mode, pad, ind)] = F.dense_image_warp(img, flow, ind, mode, pad)
+    Mp = 4
+    sp = torch.from_numpy((rng.uniform(size=(N, Mp, 2)) * [H - 1, W - 1]).astype(np.float32))
+    dp = sp + torch.from_numpy(rng.normal(size=(N, Mp, 2)).astype(np.float32))
+    d.update(src=sp, dst=dp)
+    for order in (1, 2, 3):
+        w, fl = F.sparse_image_warp(img, sp, dp, field_interpolation_order=order, include_flow=True)
+        assert w.dtype == torch.double
+        d["sparse_w{}".format(order)], d["sparse_f{}".format(order)] = w, fl
+    raises = []
+    for name, fn in (
+        ("sparse_image_warp(include_flow=True, pinned_boundary_points=1)",
+         lambda: F.sparse_image_warp(img, sp, dp, pinned_boundary_points=1, include_flow=True)),
+        ("sparse_image_warp(include_flow=False)", lambda: F.sparse_image_warp(img, sp, dp, include_flow=False)),
+        ("polyharmonic_spline(float64 values)", lambda: F.polyharmonic_spline(sp, dp.double(), sp, 2)),
+        ("spec_augment_apply_parameters(float64 feats, warp)", lambda: F.spec_augment_apply_parameters(
+            img[:, 0], F.spec_augment_draw_parameters(img[:, 0], 2.0, 1.0, 2, 2, 0.5, 1, 0.5, 1), 1)),
+    ):
+        try:
+            fn()
+            raises.append(name + ": ok")
+        except RuntimeError:
+            raises.append(name + ": RuntimeError")
+    d["reference_behaviour"] = np.array(raises)
+    save("image_f64", **d)
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "image_f64"):
+    image_f64_goldens()

@@ -205,6 +205,52 @@ def test_sparse_image_warp(device, pinned, include_flow):
     assert torch.equal(out.cpu(), torch.from_numpy(img))
 
 
+def test_float64_images_are_sampled_in_float64(device):
+    """A float64 image goes through the float64 instantiation of the gather (pdt_*_f64): the live
+    reference's outputs (tests/golden/image_f64.npz) to 1e-12 for dense_image_warp in every mode /
+    padding / indexing, to the float32 spline's accuracy for sparse_image_warp with its flow; a larger
+    random case against the oracle; the adjoint in float64; no narrowing warning."""
+    import warnings
+    from test_oracle_golden import load as _load
+
+    g = _load("image_f64")
+    img, flow = _t(g["img"], device), _t(g["flow"], device)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        for mode in ("bilinear", "nearest"):
+            for pad in ("border", "zeros", "reflection"):
+                for ind in ("hw", "wh"):
+                    a = F.dense_image_warp(img, flow, ind, mode, pad)
+                    e = g["dense_{}_{}_{}".format(mode, pad, ind)]
+                    assert a.dtype == torch.double
+                    assert np.allclose(a.cpu().numpy(), e, atol=1e-12, rtol=0), (mode, pad, ind, np.abs(a.cpu().numpy() - e).max())
+        for order in (1, 2, 3):
+            w, f = F.sparse_image_warp(img, _t(g["src"], device), _t(g["dst"], device), field_interpolation_order=order)
+            assert w.dtype == torch.double and f.dtype == torch.float
+            assert np.allclose(w.cpu().numpy(), g["sparse_w{}".format(order)], atol=2e-3), order
+            assert np.allclose(f.cpu().numpy(), g["sparse_f{}".format(order)], atol=1e-3), order
+        rng = np.random.default_rng(31)
+        N, C, H, W = 3, 2, 37, 29
+        big = rng.normal(size=(N, C, H, W))
+        fl = (rng.normal(size=(N, H, W, 2)) * 6).astype(np.float32)
+        for pad in ("border", "zeros", "reflection"):
+            a = F.dense_image_warp(_t(big, device), _t(fl, device), "hw", "bilinear", pad).cpu().numpy()
+            e = oracle.dense_image_warp(big, fl, "hw", "bilinear", pad)
+            assert np.allclose(a, e, atol=1e-12, rtol=0), (pad, np.abs(a - e).max())
+        # the same flow applied to the float32 copy differs from the float64 result by float32 rounding
+        a32 = F.dense_image_warp(_t(big.astype(np.float32), device), _t(fl, device)).cpu().numpy()
+        a64 = F.dense_image_warp(_t(big, device), _t(fl, device)).cpu().numpy()
+        assert 1e-9 < np.abs(a32 - a64).max() < 1e-4
+        # adjoint (the op is linear in the image), float64 atomics
+        x = _t(big, device)
+        lhs, rhs, _ = _adjoint_gap(lambda t: F.dense_image_warp(t, _t(fl, device)), x)
+        assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs)), (lhs, rhs)
+        src = _t((rng.uniform(size=(N, 4, 2)) * [H - 1, W - 1]).astype(np.float32), device)
+        dst = src + _t(rng.normal(size=(N, 4, 2)).astype(np.float32), device)
+        lhs, rhs, _ = _adjoint_gap(lambda t: F.sparse_image_warp(t, src, dst, pinned_boundary_points=1, include_flow=False), x)
+        assert abs(lhs - rhs) <= 1e-9 * max(1.0, abs(lhs)), (lhs, rhs)
+
+
 def _adjoint_gap(op, x):
     """<op(x + d) - op(x), g> vs <d, op^T g> for an operator that is linear in x."""
     x = x.clone().requires_grad_(True)
