@@ -331,7 +331,9 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
                                     "roofline": roof(2 * 4 * feats.numel(), ms,
                                                      "pdt::spline_solve_kernel + pdt::warp_1d_grid + pdt::spec_augment_rows_kernel")}
     ms = event_ms(lambda: sa(feats, lens))
-    out["C4_SpecAugment_forward"] = {"workload": "draw + apply", "ms": ms, "utt_per_s": N / ms * 1e3}
+    out["C4_SpecAugment_forward"] = {"workload": "draw + apply", "ms": ms, "utt_per_s": N / ms * 1e3,
+                                     "roofline": roof(2 * 4 * feats.numel(), ms,
+                                                      "pdt::spec_augment_draw_kernel + the apply's kernels")}
     img = feats.view(N, 1, T, Fq)
     src = torch.rand((N, 3, 2), device=device, generator=g) * torch.tensor([T - 1.0, Fq - 1.0], device=device)
     dst = src + torch.randn((N, 3, 2), device=device, generator=g)
@@ -340,7 +342,7 @@ def other_configs(F, M, device, world, rank, dist, gather_check):
     out["C4_sparse_image_warp"] = {"workload": "(2048,1,1000,80), 3 control + 4 pinned points, order 2", "ms": ms,
                                    "img_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6,
                                    "roofline": roof(2 * 4 * feats.numel(), ms,
-                                                    "pdt::spline_solve_kernel + pdt::sparse_warp_fast_kernel<2, border>")}
+                                                    "pdt::spline_solve_kernel + pdt::warp_table_kernel + pdt::sparse_warp_bands_kernel<2, border, 7, 4>")}
     return out
 
 
@@ -484,7 +486,7 @@ def lm_configs(F, M, device, args, ref, hyp):
     lg_speech = speechlike_logits(T3, N3, V3, device, 0x5EED0009, dicts)
     lg = peaky_logits(T3, N3, V3, device, 0x5EED0003)
     search = M.CTCPrefixSearch(K, 0.2, lm)
-    lm_kernel = "pdt::ctc_lm_search_kernel"
+    lm_kernel = "pdt::ctc_lm_table_kernel<16> (factor table of the bigram model; csrc/ctc_lm_table.hip)"
     with torch.no_grad():
         search(lg[:8])
         ms_speech = event_ms(lambda: search(lg_speech), reps=3, warm=1)

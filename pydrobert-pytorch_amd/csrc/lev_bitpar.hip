@@ -78,7 +78,9 @@ BitparPlan plan_bitpar(int64_t X, int64_t Y, int64_t N) {
   const size_t Xs = (size_t)(X > 0 ? X : 1), Ys = (size_t)(Y > 0 ? Y : 1);
   // classify: [(presence, offset) per class X * 8] [tokens (X + 1) * 8 (later: the mask words)]
   //           [classes of Y, 2 bytes each]
-  p.lds_classify = align_up(Xs * 8 + (Xs + 1) * 8 + Ys * 2, 16);
+  // (the token table's region also holds the presence map of small tokens, lev_classes.hpp: at
+  // least kDirectWords * 8 bytes)
+  p.lds_classify = align_up(Xs * 8 + std::max((Xs + 1) * 8, (size_t)kDirectWords * 8) + Ys * 2, 16);
   // DP: per utterance [yh Y * 8] [mask words (X + 1) * 4]; per workgroup the ring of match words
   // (two chunks of kRingWords per lane), which the distances (X + 1) * 4 per utterance take over
   p.lds_sub = align_up(Ys * 8 + (Xs + 1) * 4, 16);
@@ -111,7 +113,10 @@ __global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, c
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6);
-  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  // (time-major tokens: one 128-byte line of a row holds 16 neighbouring utterances' tokens = four
+  // workgroups; with the XCD-aware order those four run on ONE XCD and its L2 fetches the line once
+  // -- under the dispatcher's round-robin they sat on four XCDs and HBM delivered it four times)
+  const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
   if (n >= a.N) return;  // waves never synchronise with each other
   unsigned char *base = smem + (size_t)wave * lds_per_wave;
   const int X = a.X > 0 ? a.X : 1, Y = a.Y > 0 ? a.Y : 1;
@@ -120,7 +125,8 @@ __global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, c
   uint2 *po = reinterpret_cast<uint2 *>(base);
   int64_t *ctok = reinterpret_cast<int64_t *>(base + (size_t)X * 8);
   unsigned *msk = reinterpret_cast<unsigned *>(ctok);
-  short *yc = reinterpret_cast<short *>(ctok + X + 1);
+  uint2 *pmap = reinterpret_cast<uint2 *>(ctok);  // (instead of the token table: one or the other)
+  short *yc = reinterpret_cast<short *>(ctok + max(X + 1, kDirectWords));
 
   // ---- lengths (_string.py:195-228) -----------------------------------------------------
   int ref_len = a.R, hyp_len = a.H;
@@ -145,15 +151,28 @@ __global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, c
   const int x_len = oc ? ref_len : Heff, y_len = oc ? Heff : ref_len;
 
   // ---- distinct tokens of X in ascending order (lev_classes.hpp) ---------------------------
+  // (vocabulary indices below kDirectBits: ranks from a presence map, no sort -- lev_classes.hpp;
+  // anything else: the sorted table and binary searches.  The classes are the same numbers.)
   int64_t xt[NR];
-  const int U = distinct_sorted<NR>(x, x_len, x_st, xoff, xt, ctok);
-  wave_sync();
-  for (int k = lane; k < U; k += PDT_WAVE) po[k] = make_uint2(0u, 0u);
-  if (oc)
-    for (int k = lane; k < U; k += PDT_WAVE) a.class_tokens[n * (int64_t)a.R + k] = ctok[k];
-  const int lgP = search_depth(U);
+  load_sequence<NR>(x, x_len, x_st, xoff, xt);
+  const bool direct = tokens_are_small<NR>(x_len, xt);
+  int U, lgP = 0;
   int xc[NR];  // classes of X[lane + 64 q]
-  classes_of<NR>(ctok, U, lgP, xt, xc);
+  if (direct) {
+    U = presence_map<NR>(x_len, xt, pmap);
+    if (oc) tokens_from_map(pmap, a.class_tokens + n * (int64_t)a.R);
+    classes_from_map<NR>(pmap, xt, xc);
+#pragma unroll
+    for (int q = 0; q < NR; ++q) xc[q] = lane + q * PDT_WAVE < x_len ? xc[q] : -1;
+  } else {
+    U = distinct_sorted_regs<NR>(x_len, xt, ctok);
+    wave_sync();
+    if (oc)
+      for (int k = lane; k < U; k += PDT_WAVE) a.class_tokens[n * (int64_t)a.R + k] = ctok[k];
+    lgP = search_depth(U);
+    classes_of<NR>(ctok, U, lgP, xt, xc);
+  }
+  for (int k = lane; k < U; k += PDT_WAVE) po[k] = make_uint2(0u, 0u);
   if (oc) {
 #pragma unroll
     for (int q = 0; q < NR; ++q)
@@ -163,7 +182,8 @@ __global__ void __launch_bounds__(256) lev_classify_kernel(const BitparArgs a, c
     int64_t yt[8];
     int c[8];
     load_tokens(y, y_len, y_st, yoff, j0, 0, yt);
-    classes_of<8>(ctok, U, lgP, yt, c);
+    if (direct) classes_from_map<8>(pmap, yt, c);
+    else classes_of<8>(ctok, U, lgP, yt, c);
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (j0 + lane + q * PDT_WAVE < y_len) yc[j0 + lane + q * PDT_WAVE] = (short)c[q];

@@ -100,18 +100,20 @@ __device__ __forceinline__ int first_eos(const int64_t *tok, const int T, const 
 // key = ~(token with its sign bit flipped): a descending sort of the keys is an ascending sort of
 // the tokens with the padding last; the first element of every run of equal keys is kept.
 template <int NR>
-__device__ __forceinline__ int distinct_sorted(const int64_t *tok, const int len, const int64_t st,
-                                               const int64_t off, int64_t (&xt)[NR], int64_t *tab) {
-  const int lane = lane_id();
-  {
-    int64_t part[8];
+__device__ __forceinline__ void load_sequence(const int64_t *tok, const int len, const int64_t st,
+                                              const int64_t off, int64_t (&xt)[NR]) {
+  int64_t part[8];
 #pragma unroll
-    for (int c = 0; c < NR / 8; ++c) {
-      load_tokens(tok, len, st, off, c * 8 * PDT_WAVE, INT64_MAX, part);
+  for (int c = 0; c < NR / 8; ++c) {
+    load_tokens(tok, len, st, off, c * 8 * PDT_WAVE, INT64_MAX, part);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) xt[c * 8 + q] = part[q];
-    }
+    for (int q = 0; q < 8; ++q) xt[c * 8 + q] = part[q];
   }
+}
+
+template <int NR>
+__device__ __forceinline__ int distinct_sorted_regs(const int len, const int64_t (&xt)[NR], int64_t *tab) {
+  const int lane = lane_id();
   constexpr u64 kSign = 0x8000000000000000ull;
   int U = 0;
   u64 key[NR];
@@ -138,6 +140,84 @@ __device__ __forceinline__ int distinct_sorted(const int64_t *tok, const int len
     U += (int)__popcll(firsts);
   }
   return U;
+}
+
+template <int NR>
+__device__ __forceinline__ int distinct_sorted(const int64_t *tok, const int len, const int64_t st,
+                                               const int64_t off, int64_t (&xt)[NR], int64_t *tab) {
+  load_sequence<NR>(tok, len, st, off, xt);
+  return distinct_sorted_regs<NR>(len, xt, tab);
+}
+
+// ---- small non-negative tokens: classes without a sort ----------------------------------------
+// When every token of the sequence lies in [0, kDirectBits) -- vocabulary indices, the usual case --
+// its distinct tokens are the set bits of a kDirectBits-bit presence map in LDS, and the class of a
+// token (its rank among them, the same number the sorted table gives) is the count of set bits
+// below it: the map's words carry their exclusive prefix count, so a look-up is ONE 8-byte LDS read
+// and a popcount instead of a log2(U)-step binary search, and the 64 x NR-key sort disappears.
+constexpr int kDirectBits = 8192, kDirectWords = kDirectBits / 32;
+static_assert(kDirectWords % PDT_WAVE == 0, "word w belongs to lane w % 64");
+
+template <int NR>
+__device__ __forceinline__ bool tokens_are_small(const int len, const int64_t (&xt)[NR]) {
+  const int lane = lane_id();
+  bool big = false;
+#pragma unroll
+  for (int q = 0; q < NR; ++q) big = big || (lane + q * PDT_WAVE < len && (u64)xt[q] >= (u64)kDirectBits);
+  return __ballot(big) == 0ull;
+}
+
+// map[w] = (presence word w, number of distinct tokens below 32 w); returns U
+template <int NR>
+__device__ __forceinline__ int presence_map(const int len, const int64_t (&xt)[NR], uint2 *map) {
+  const int lane = lane_id();
+  constexpr int kRounds = kDirectWords / PDT_WAVE;
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) map[lane + j * PDT_WAVE] = make_uint2(0u, 0u);
+  wave_sync();
+#pragma unroll
+  for (int q = 0; q < NR; ++q)
+    if (lane + q * PDT_WAVE < len) atomicOr(&map[(int)xt[q] >> 5].x, 1u << ((int)xt[q] & 31));
+  wave_sync();
+  int U = 0;
+#pragma unroll
+  for (int j = 0; j < kRounds; ++j) {  // word lane + 64 j: prefix within the round + the rounds before
+    const int cnt = __popc(map[lane + j * PDT_WAVE].x);
+    const int incl = wave_incl_scan_add(cnt);
+    map[lane + j * PDT_WAVE].y = (unsigned)(U + incl - cnt);
+    U += __builtin_amdgcn_readlane(incl, PDT_WAVE - 1);
+  }
+  wave_sync();
+  return U;
+}
+
+template <int NQ>
+__device__ __forceinline__ void classes_from_map(const uint2 *map, const int64_t (&v)[NQ], int (&cls)[NQ]) {
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const bool in = (u64)v[q] < (u64)kDirectBits;
+    const int t = in ? (int)v[q] : 0;
+    const uint2 e = map[t >> 5];
+    const unsigned bit = 1u << (t & 31);
+    cls[q] = (in && (e.x & bit)) ? (int)(e.y + (unsigned)__popc(e.x & (bit - 1u))) : -1;
+  }
+}
+
+// the distinct tokens themselves, ascending: out[k * stride] = k-th token (callers that list them)
+template <typename T>
+__device__ __forceinline__ void tokens_from_map(const uint2 *map, T *out) {
+  const int lane = lane_id();
+#pragma unroll 1
+  for (int j = 0; j < kDirectWords / PDT_WAVE; ++j) {
+    const uint2 e = map[lane + j * PDT_WAVE];
+    unsigned w = e.x;
+    int at = (int)e.y;
+    while (w) {
+      const int b = __builtin_ctz(w);
+      w &= w - 1u;
+      out[at++] = (T)((lane + j * PDT_WAVE) * 32 + b);
+    }
+  }
 }
 
 // search depth for classes_of: steps 2^(lg-1) .. 1 reach every index below U

@@ -490,6 +490,40 @@ def test_bitpar_extreme_token_values(device):
         _assert_same(exp, act, name)
 
 
+def test_classification_by_presence_map_and_by_sort_agree(device):
+    """lev_classify ranks vocabulary indices below 8192 through a presence map and anything else
+    through a sorted table (lev_classes.hpp), decided per utterance: utterances on both sides of the
+    boundary in one batch, look-up tokens outside the map's range (negative, >= 8192, beyond int32)
+    against in-range class tokens, every word of the map in use -- against the oracle; and the same
+    sequences shifted by 2^40 (all through the sort) give the same distances and the same
+    completions."""
+    rng = np.random.default_rng(77)
+    N, R, H = 24, 300, 280
+    ref = rng.integers(0, 8192, (R, N))
+    hyp = rng.integers(0, 8192, (H, N))
+    hyp[:, 0:4] = rng.integers(8100, 8292, (H, 4))      # some hypothesis tokens beyond the map
+    ref[:, 4:8] = rng.integers(-50, 60, (R, 4))          # negative reference tokens, small hypothesis
+    hyp[:, 4:8] = rng.integers(0, 60, (H, 4))
+    ref[:, 8:12] = rng.integers(8000, 8400, (R, 4))      # reference across the boundary, hypothesis inside
+    hyp[:, 8:12] = rng.integers(8000, 8192, (H, 4))
+    ref[::7, 12] = 2**33 + 5                              # a look-up whose low 32 bits are a present token
+    hyp[:, 12] = rng.integers(0, 9, H)
+    ref[:, 12] = np.where(ref[:, 12] > 2**33, ref[:, 12], rng.integers(0, 9, R))
+    hyp[:, 13] = np.arange(H) * 29 % 8192                 # spread over every word of the map
+    ref[:, 13] = np.arange(R) * 31 % 8192
+    for name in NAMES:
+        for kw in ({}, {"eos": 8191, "include_eos": True}):
+            exp, act = _call_both(name, ref, hyp, device, **kw)
+            _assert_same(exp, act, (name, kw))
+    small_r, small_h = rng.integers(0, 40, (R, N)), rng.integers(0, 40, (H, N))
+    for name in NAMES:
+        a = getattr(F, name)(torch.from_numpy(small_r).to(device), torch.from_numpy(small_h).to(device), warn=False)
+        b = getattr(F, name)(torch.from_numpy(small_r + 2**40).to(device), torch.from_numpy(small_h + 2**40).to(device), warn=False)
+        if name == "optimal_completion":
+            b = torch.where(b >= 0, b - 2**40, b)  # (the padding value stays)
+        assert torch.equal(a, b), name
+
+
 def test_lev_workspace_is_optional(device):
     """pdt_lev gives the same bits with and without its workspace (bit-parallel kernels against the
     cell-by-cell ones), and reports no workspace for hypotheses beyond 1024 tokens."""
