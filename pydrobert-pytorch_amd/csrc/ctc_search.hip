@@ -53,10 +53,17 @@ namespace pdt {
 // (No amdgpu_num_sgpr: eight waves per SIMD cap the register-resident form at 80 scalar registers
 // by themselves -- 96 admit seven waves, measured 2.65 against 2.14 ms -- and the long-row forms,
 // four waves per SIMD, may take the 102 there are: an explicit 80 cost them 92-118 scalar spills.)
-template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
+// WC > 0: the beam width as a compile-time constant (a.W must equal it): the tier choices, list
+// lengths and table strides that depend on it fold away -- scalar work and scalar registers the
+// register-resident form has none to spare of (instantiated for the default width 16).
+template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false, int WC = -1, int VC = -1>
 __global__ void __launch_bounds__(256, INREG ? 8 : 4)
-ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
+ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
+  static_assert((WC > 0 && VC > 0) ? (P == 1 && INREG && !GROW) : true, "compile-time shapes: the register-resident form");
+  // (both known: the LDS layout is a set of constants too -- the launcher checks that it is the
+  // layout the plan chose)
+  const RingLayout rl = (WC > 0 && VC > 0) ? ring_layout(VC, WC, PDT_RING_STAGES, PDT_UTT_PER_WG, 1) : rl_arg;
   static_assert(!GROW || !INREG, "rows in the workspace are a form of the generic row pass");
   static_assert(NT < 0 || INREG, "compile-time chunk counts belong to the register-resident row pass");
   extern __shared__ __align__(16) unsigned char smem[];
@@ -72,7 +79,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
   const int64_t n_raw = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
   const bool idle = u >= rl.utt_per_wg || n_raw >= a.N;
   const int64_t n = idle ? 0 : n_raw;
-  const int V = a.V, W = a.W;
+  const int V = VC > 0 ? VC : a.V, W = WC > 0 ? WC : a.W;  // (VC: the vocabulary size likewise)
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
   unsigned char *cs = ub + (size_t)rl.slot_bytes * rl.nstage;      // consumer scratch
@@ -554,16 +561,16 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl) {
 #endif
 }
 
-template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false>
+template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false, int WC = -1, int VC = -1>
 static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG, GROW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG, GROW, WC, VC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG, GROW>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
+  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG, GROW, WC, VC>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
                      stream, a, rl);
   return (int)hipGetLastError();
 }
@@ -625,6 +632,17 @@ int launch_ctc_rowreg(CtcArgs a, hipStream_t stream);
 int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &rl, hipStream_t stream) {
   if (plan.inreg == 2) return launch_ctc_search_p<3, -1, false, true>(a, rl, stream);
   if (plan.producers == 3) return launch_ctc_search_p<3>(a, rl, stream);
+#ifndef PDT_NO_V256  // (diagnostic builds compare against the run-time shapes)
+  {
+    const RingLayout c = ring_layout(256, 16, PDT_RING_STAGES, PDT_UTT_PER_WG, 1);
+    if (a.V == 256 && a.W == 16 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
+        c.slot_bytes == rl.slot_bytes)
+      return launch_ctc_search_p<1, 4, true, false, 16, 256>(a, rl, stream);
+  }
+#endif
+#ifndef PDT_NO_WIDTH16
+  if (a.V / PDT_WAVE == 4 && a.W == 16) return launch_ctc_search_p<1, 4, true, false, 16>(a, rl, stream);
+#endif
   if (a.V / PDT_WAVE == 4) return launch_ctc_search_p<1, 4>(a, rl, stream);
   return launch_ctc_search_p<1>(a, rl, stream);
 }
