@@ -59,7 +59,9 @@ constexpr int rowreg_waves(int NR) {
 // NF need no guard -- a guard per chunk is a scalar branch and, worse, a merge of the two versions
 // of everything the chunk touches).  P producers per utterance take the frames t = p, p + P, ... in
 // turn; a workgroup is one utterance: three producers and the consumer.
-template <int NR, int NF, int P>
+// WC > 0: the beam width as a compile-time constant (the default, 16, has instantiations of its own:
+// the consumer's tier choices and table strides fold away, as in ctc_search.hip).
+template <int NR, int NF, int P, int WC = -1>
 __global__ void __launch_bounds__(256, rowreg_waves(NR))
 ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -71,7 +73,7 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   const int64_t n_raw = (int64_t)xcd_remap(blockIdx.x, gridDim.x) * rl.utt_per_wg + u;
   const bool idle = u >= rl.utt_per_wg || n_raw >= a.N;
   const int64_t n = idle ? 0 : n_raw;
-  const int V = a.V, W = a.W, NS = rl.nstage;
+  const int V = a.V, W = WC > 0 ? WC : a.W, NS = rl.nstage;
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
   unsigned char *pos = ub + (size_t)rl.slot_bytes * NS;
@@ -384,46 +386,46 @@ void ctc_rowreg_plan(int V, int W, int32_t *plan5) {
   plan5[4] = rowreg_chunks(V);
 }
 
-template <int NR, int NF, int P>
+template <int NR, int NF, int P, int WC = -1>
 static int launch_rowreg(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_rowreg_kernel<NR, NF, P>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_rowreg_kernel<NR, NF, P, WC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL((ctc_rowreg_kernel<NR, NF, P>), dim3(grid), dim3(256), smem, stream, a, rl);
+  hipLaunchKernelGGL((ctc_rowreg_kernel<NR, NF, P, WC>), dim3(grid), dim3(256), smem, stream, a, rl);
   return (int)hipGetLastError();
 }
 
 // full token chunks (the chunk with the blank has a register of its own): instantiations in steps of
 // eight chunks up to 80 (four waves per SIMD and more), of 16 up to 128 (three), of 32 up to 256 (two,
 // then one: the whole register file of a SIMD holds one row)
-template <int P>
+template <int P, int WC = -1>
 static int launch_rowreg_nr(const CtcArgs &a, const RowregLayout &rl, hipStream_t stream) {
   const int c = a.V / PDT_WAVE;
   if (c <= 80) {
     switch ((c + 7) / 8) {
-      case 1: return launch_rowreg<8, 0, P>(a, rl, stream);
-      case 2: return launch_rowreg<16, 8, P>(a, rl, stream);
-      case 3: return launch_rowreg<24, 16, P>(a, rl, stream);
-      case 4: return launch_rowreg<32, 24, P>(a, rl, stream);
-      case 5: return launch_rowreg<40, 32, P>(a, rl, stream);
-      case 6: return launch_rowreg<48, 40, P>(a, rl, stream);
-      case 7: return launch_rowreg<56, 48, P>(a, rl, stream);
-      case 8: return launch_rowreg<64, 56, P>(a, rl, stream);
-      case 9: return launch_rowreg<72, 64, P>(a, rl, stream);
-      default: return launch_rowreg<80, 72, P>(a, rl, stream);
+      case 1: return launch_rowreg<8, 0, P, WC>(a, rl, stream);
+      case 2: return launch_rowreg<16, 8, P, WC>(a, rl, stream);
+      case 3: return launch_rowreg<24, 16, P, WC>(a, rl, stream);
+      case 4: return launch_rowreg<32, 24, P, WC>(a, rl, stream);
+      case 5: return launch_rowreg<40, 32, P, WC>(a, rl, stream);
+      case 6: return launch_rowreg<48, 40, P, WC>(a, rl, stream);
+      case 7: return launch_rowreg<56, 48, P, WC>(a, rl, stream);
+      case 8: return launch_rowreg<64, 56, P, WC>(a, rl, stream);
+      case 9: return launch_rowreg<72, 64, P, WC>(a, rl, stream);
+      default: return launch_rowreg<80, 72, P, WC>(a, rl, stream);
     }
   }
-  if (c <= 96) return launch_rowreg<96, 80, P>(a, rl, stream);
-  if (c <= 112) return launch_rowreg<112, 96, P>(a, rl, stream);
-  if (c <= 128) return launch_rowreg<128, 112, P>(a, rl, stream);
-  if (c <= 160) return launch_rowreg<160, 128, P>(a, rl, stream);
-  if (c <= 192) return launch_rowreg<192, 160, P>(a, rl, stream);
-  if (c <= 224) return launch_rowreg<224, 192, P>(a, rl, stream);
-  return launch_rowreg<256, 224, P>(a, rl, stream);
+  if (c <= 96) return launch_rowreg<96, 80, P, WC>(a, rl, stream);
+  if (c <= 112) return launch_rowreg<112, 96, P, WC>(a, rl, stream);
+  if (c <= 128) return launch_rowreg<128, 112, P, WC>(a, rl, stream);
+  if (c <= 160) return launch_rowreg<160, 128, P, WC>(a, rl, stream);
+  if (c <= 192) return launch_rowreg<192, 160, P, WC>(a, rl, stream);
+  if (c <= 224) return launch_rowreg<224, 192, P, WC>(a, rl, stream);
+  return launch_rowreg<256, 224, P, WC>(a, rl, stream);
 }
 
 int launch_ctc_rowreg(CtcArgs a, hipStream_t stream) {
@@ -434,6 +436,7 @@ int launch_ctc_rowreg(CtcArgs a, hipStream_t stream) {
   while (((size_t)(a.T >> sh) + 1) * a.W * sizeof(int2) > room) ++sh;
   a.ckpt_shift = sh;
   a.ckpt_count = (a.T >> sh) + 1;
+  if (a.W == 16) return launch_rowreg_nr<3, 16>(a, rl, stream);
   return launch_rowreg_nr<3>(a, rl, stream);
 }
 

@@ -80,6 +80,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   const bool idle = u >= rl.utt_per_wg || n_raw >= a.N;
   const int64_t n = idle ? 0 : n_raw;
   const int V = VC > 0 ? VC : a.V, W = WC > 0 ? WC : a.W;  // (VC: the vocabulary size likewise)
+  // (... and with it contiguous rows: the launcher checks the strides)
+  const int64_t lg_sv = VC > 0 ? 1 : a.lg_sv, lg_sn = VC > 0 ? VC + 1 : a.lg_sn;
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
   unsigned char *cs = ub + (size_t)rl.slot_bytes * rl.nstage;      // consumer scratch
@@ -148,11 +150,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     const int nt_ = NT >= 0 ? NT : V / PDT_WAVE, rem_ = V - nt_ * PDT_WAVE;  // full token chunks; lane of the blank
     const float inv_ntok = 1.0f / (float)(nt_ > 0 ? nt_ * PDT_WAVE : 1);
     if (pr < Tn) {
-      const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
+      const float *row0 = a.logits + (int64_t)pr * a.lg_st + n * lg_sn + (int64_t)lane * lg_sv;
 #pragma unroll
       for (int i = 0; i < kPrefetch; ++i) {
         const int v = lane + i * PDT_WAVE;
-        pre[i] = v <= V ? row0[(int64_t)(i * PDT_WAVE) * a.lg_sv] : 0.0f;
+        pre[i] = v <= V ? row0[(int64_t)(i * PDT_WAVE) * lg_sv] : 0.0f;
       }
     }
     int sl = pr % NS;  // t % NS, kept by add / compare: no division in the loop
@@ -264,14 +266,14 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
         if (t + P < Tn) {
           // (lane term first: the per-element offsets are then wave-uniform scalars, not eight
           // hoisted 64-bit vector products)
-          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lp * a.lg_sv;
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * lg_sn + (int64_t)lp * lg_sv;
 #pragma unroll
           for (int i = 0; i < kPrefetch; ++i) {
             if (i > nt) break;
             if (i < nt) {
-              pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
+              pre[i] = nrow[(int64_t)(i * PDT_WAVE) * lg_sv];
             } else if (i == nt) {
-              if (in_row) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
+              if (in_row) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * lg_sv];
             }
           }
         }
@@ -286,7 +288,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
           }
         }
         {
-          const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
+          const float *row = a.logits + (int64_t)t * a.lg_st + n * lg_sn;
           int v = lane + kPrefetch * PDT_WAVE;
           if constexpr (!INREG) {
             // long rows: kBatch loads in flight, then the rest in guarded groups of 8 (a load that
@@ -295,7 +297,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
             for (; v + (kBatch - 1) * PDT_WAVE <= V; v += kBatch * PDT_WAVE) {
               float x[kBatch];
 #pragma unroll
-              for (int i = 0; i < kBatch; ++i) x[i] = row[(int64_t)(v + i * PDT_WAVE) * a.lg_sv];
+              for (int i = 0; i < kBatch; ++i) x[i] = row[(int64_t)(v + i * PDT_WAVE) * lg_sv];
 #pragma unroll
               for (int i = 0; i < kBatch; ++i) {
                 p[v + i * PDT_WAVE] = x[i];
@@ -306,7 +308,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
               float x[8];
 #pragma unroll
               for (int i = 0; i < 8; ++i)
-                x[i] = v + i * PDT_WAVE <= V ? row[(int64_t)(v + i * PDT_WAVE) * a.lg_sv] : -PDT_INF;
+                x[i] = v + i * PDT_WAVE <= V ? row[(int64_t)(v + i * PDT_WAVE) * lg_sv] : -PDT_INF;
 #pragma unroll
               for (int i = 0; i < 8; ++i) {
                 if (v + i * PDT_WAVE <= V) p[v + i * PDT_WAVE] = x[i];
@@ -315,7 +317,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
             }
           }
           for (; v <= V; v += PDT_WAVE) {
-            const float x = row[(int64_t)v * a.lg_sv];
+            const float x = row[(int64_t)v * lg_sv];
             p[v] = x;
             mx = fmaxf(mx, x);
           }
@@ -323,11 +325,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
         if (t + P < Tn) {
           // (lane term first: the per-element offsets are then wave-uniform scalars, not eight
           // hoisted 64-bit vector products)
-          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * a.lg_sn + (int64_t)lane * a.lg_sv;
+          const float *nrow = a.logits + (int64_t)(t + P) * a.lg_st + n * lg_sn + (int64_t)lane * lg_sv;
 #pragma unroll
           for (int i = 0; i < kPrefetch; ++i) {
             const int v = lane + i * PDT_WAVE;
-            if (v <= V) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * a.lg_sv];
+            if (v <= V) pre[i] = nrow[(int64_t)(i * PDT_WAVE) * lg_sv];
           }
         }
         mx = wave_max_f(mx);
@@ -635,7 +637,7 @@ int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &r
 #ifndef PDT_NO_V256  // (diagnostic builds compare against the run-time shapes)
   {
     const RingLayout c = ring_layout(256, 16, PDT_RING_STAGES, PDT_UTT_PER_WG, 1);
-    if (a.V == 256 && a.W == 16 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
+    if (a.V == 256 && a.W == 16 && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
         c.slot_bytes == rl.slot_bytes)
       return launch_ctc_search_p<1, 4, true, false, 16, 256>(a, rl, stream);
   }

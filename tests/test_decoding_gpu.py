@@ -260,6 +260,32 @@ def test_ctc_prefix_search_wider_than_the_kernel_holds(device, V, K):
             _check_search(M.CTCPrefixSearch(K)(torch.from_numpy(lg).to(device), tl), exp, (V, K, T, N, "module"))
 
 
+def test_ctc_default_shape_instances_match_the_general_kernels(device):
+    """ctc_search.hip has instantiations with the beam width 16 and the vocabulary size 256 (and with
+    them the LDS layout and contiguous rows) as compile-time constants.  The same values through the
+    general kernels -- a vocabulary axis with a stride (run-time strides: the width-16 instance), and
+    widths 15 / 17 around the default against the oracle -- give the same bits / the oracle's
+    answers; ragged lengths, several hundred frames (checkpoints, underflow guard), V = 256 .. 258."""
+    rng = np.random.default_rng(123)
+    T, N = 300, 37
+    for V in (256, 257, 258):
+        lg = _peaky_logits(rng, T, N, V, scale=6.0)
+        lens = rng.integers(0, T + 1, N)
+        tl = torch.from_numpy(lens).to(device)
+        dense = torch.from_numpy(lg).to(device)
+        wide = torch.zeros((T, N, 2 * (V + 1)), device=device)
+        wide[:, :, ::2] = dense
+        a = F.ctc_prefix_search(dense, 16, tl)
+        b = F.ctc_prefix_search(wide[:, :, ::2], 16, tl)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), V
+        exp = oracle.ctc_prefix_search(lg[:60, :8], 16, np.minimum(lens[:8], 60))
+        _check_search(F.ctc_prefix_search(dense[:60, :8].contiguous(), 16, tl[:8].clamp(max=60)), exp, (V, 16))
+        for K in (15, 17):
+            exp = oracle.ctc_prefix_search(lg[:60, :8], K, np.minimum(lens[:8], 60))
+            _check_search(F.ctc_prefix_search(dense[:60, :8].contiguous(), K, tl[:8].clamp(max=60)), exp, (V, K))
+
+
 def test_ctc_strided_logits_and_errors(device):
     rng = np.random.default_rng(6)
     lg = _peaky_logits(rng, 12, 4, 9)
