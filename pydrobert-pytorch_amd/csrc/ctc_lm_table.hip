@@ -92,7 +92,8 @@ __host__ __device__ inline LmTabLayout lmtab_layout(int V, int W, int contexts) 
 }
 
 // NR: 64-element chunks a row takes in registers (V + 1 <= 64 * NR)
-template <int NR>
+// (WC > 0: the beam width as a compile-time constant, as in ctc_search.hip -- the default 16)
+template <int NR, int WC = -1>
 __global__ void __launch_bounds__(256, NR <= 16 ? 4 : 2)
 ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -100,7 +101,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   const int lane = lane_id();
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int64_t n = (int64_t)xcd_remap(blockIdx.x, gridDim.x);
-  const int V = a.V, W = a.W;
+  const int V = a.V, W = WC > 0 ? WC : a.W;
   float *rows = reinterpret_cast<float *>(smem);
   int *tl_tok = reinterpret_cast<int *>(smem + ly.rows_bytes);       // [W lists x 64]
   float *tl_p = reinterpret_cast<float *>(tl_tok + W * PDT_WAVE);     // [W lists x 64]
@@ -467,15 +468,15 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   }
 }
 
-template <int NR>
+template <int NR, int WC = -1>
 static int launch_lm_table(const LmTabArgs &A, const LmTabLayout &ly, hipStream_t stream) {
   const size_t smem = (size_t)ly.utt_bytes;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_lm_table_kernel<NR>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_lm_table_kernel<NR, WC>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL((ctc_lm_table_kernel<NR>), dim3((unsigned)A.c.N), dim3(256), smem, stream, A, ly);
+  hipLaunchKernelGGL((ctc_lm_table_kernel<NR, WC>), dim3((unsigned)A.c.N), dim3(256), smem, stream, A, ly);
   return (int)hipGetLastError();
 }
 
@@ -521,6 +522,13 @@ int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V
   a.ckpt_shift = sh;
   a.ckpt_count = (int)(T >> sh) + 1;
   const int chunks = (int)((V + 1 + PDT_WAVE - 1) / PDT_WAVE);
+  if (a.W == 16) {
+    if (chunks <= 8) return launch_lm_table<8, 16>(A, ly, (hipStream_t)stream);
+    if (chunks <= 16) return launch_lm_table<16, 16>(A, ly, (hipStream_t)stream);
+    if (chunks <= 32) return launch_lm_table<32, 16>(A, ly, (hipStream_t)stream);
+    if (chunks <= 48) return launch_lm_table<48, 16>(A, ly, (hipStream_t)stream);
+    return launch_lm_table<80, 16>(A, ly, (hipStream_t)stream);
+  }
   if (chunks <= 8) return launch_lm_table<8>(A, ly, (hipStream_t)stream);
   if (chunks <= 16) return launch_lm_table<16>(A, ly, (hipStream_t)stream);
   if (chunks <= 32) return launch_lm_table<32>(A, ly, (hipStream_t)stream);
