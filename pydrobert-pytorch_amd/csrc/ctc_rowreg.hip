@@ -121,7 +121,7 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       int lp = lane, nt = nt_, rem = rem_;
       asm volatile("" : "+v"(lp), "+s"(nt), "+s"(rem));
       const bool in_row = lp <= rem, is_tok = lp < rem;
-      const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
+      const int M = ctc_list_len(V, W, (t == 0 && WC <= 0) ? 1 : W);  // (WC: W entries from frame 0, see the consumer)
       // ---- pass A: per-lane maximum over the tokens; with the blank, the row maximum ---------
       float lmx = is_tok ? rt : -PDT_INF, lmn = in_row ? rt : PDT_INF;
 #pragma unroll
@@ -255,7 +255,9 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   bm.node = -1;
   bm.isp = lane == 0 ? 1u : 0u;
   bm.origin = lane;
-  int Kp = 1;
+  // (with the width a constant the first frame runs with W entries too, all but the first invalid --
+  // ctc_search.hip, kFullFromStart; rows here have at least 128 tokens)
+  int Kp = WC > 0 ? WC : 1;
   const float *lg_n = a.logits + n * a.lg_sn;
   // the logit of every prefix's last token in the coming frame (lanes beyond the beam read token 0)
   float xg = Tn > 0 ? lg_n[0] : 0.0f;
@@ -293,7 +295,7 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       int *tmp = L.nxt_old;
       L.nxt_old = L.nxt_new;
       L.nxt_new = tmp;
-      Kp = W;
+      if (WC <= 0) Kp = W;
     }
     if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (t + 1 < Tn)

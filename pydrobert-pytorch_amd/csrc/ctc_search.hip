@@ -357,7 +357,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
       }
       s = wave_sum_f(s);
       wave_sync();
-      const int M = ctc_list_len(V, W, t == 0 ? 1 : W);
+      const int M = ctc_list_len(V, W, (t == 0 && !(WC > 0 && VC > 0 && VC + 1 >= WC)) ? 1 : W);
       // reciprocal of the normaliser: v_rcp_f32 + one Newton step (within 1 ulp of the quotient;
       // the IEEE division sequence is 12 VALU instructions)
       const float inv0 = __builtin_amdgcn_rcpf(s);
@@ -431,7 +431,13 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   bm.node = -1;
   bm.isp = lane == 0 ? 1u : 0u;
   bm.origin = lane;
-  int Kp = 1;
+  // Live beam entries: 1 at t = 0, then W.  With both shapes known (and V + 1 >= W) the first frame
+  // runs with W entries too, all but the first invalid (mass -inf: no candidates, no merges) -- the
+  // state a frame leaves behind when it finds fewer than W candidates -- so K, M and every tier
+  // choice derived from them are constants of the loop.  The producer sends the longer list (M for
+  // W entries) in frame 0 as well.
+  constexpr bool kFullFromStart = WC > 0 && VC > 0 && VC + 1 >= WC;
+  int Kp = kFullFromStart ? WC : 1;
   int fail_score = 0, full_mode = 0;
 #ifdef PDT_STAMPS
   unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
@@ -474,7 +480,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
       int *tmp = L.nxt_old;  // (a skipped frame leaves the next-token tables where they are)
       L.nxt_old = L.nxt_new;
       L.nxt_new = tmp;
-      Kp = W;
+      if (!kFullFromStart) Kp = W;
     }
     // feedback to the producers: a complete selection costs the producer about what two list
     // completions cost this wave, so the balance is at one completed list in two frames: +1
@@ -491,7 +497,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     }
 #else
     ns = nt = nk = 0; (void)s;
-    Kp = W;
+    if (!kFullFromStart) Kp = W;
 #endif
     if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
