@@ -189,7 +189,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
         // (laundered: chunk predicates and the two masks of chunk nt are recomputed by a scalar
         // compare where used, not hoisted out of the frame loop into scalar registers that spill)
         int lp = lane, nt = nt_, rem = rem_;
-        if constexpr (NT >= 0) {
+        if constexpr (VC > 0) {  // (the lane of the blank is a constant too)
+          asm volatile("" : "+v"(lp));
+          nt = NT;
+          rem = VC - NT * PDT_WAVE;
+        } else if constexpr (NT >= 0) {
           asm volatile("" : "+v"(lp), "+s"(rem));
           nt = NT;
         } else {
@@ -362,7 +366,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
       // the IEEE division sequence is 12 VALU instructions)
       const float inv0 = __builtin_amdgcn_rcpf(s);
       float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
-      if (a.exact_div) {  // the quotient itself, element by element (CtcArgs::exact_div)
+      if (VC <= 0 && a.exact_div) {  // the quotient itself, element by element (CtcArgs::exact_div; general instances)
         for (int v = lane; v <= V; v += PDT_WAVE) p[v] = p[v] / s;
         wave_sync();
         inv = 1.0f;
@@ -643,7 +647,7 @@ int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &r
 #ifndef PDT_NO_V256  // (diagnostic builds compare against the run-time shapes)
   {
     const RingLayout c = ring_layout(256, 16, PDT_RING_STAGES, PDT_UTT_PER_WG, 1);
-    if (a.V == 256 && a.W == 16 && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
+    if (a.V == 256 && a.W == 16 && !a.exact_div && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
         c.slot_bytes == rl.slot_bytes)
       return launch_ctc_search_p<1, 4, true, false, 16, 256>(a, rl, stream);
   }
