@@ -154,8 +154,11 @@ __global__ void __launch_bounds__(512) beam_advance_kernel(const BeamAdvArgs a) 
   // out lowest token first although their log_probs_t differ: with "lowest lane first" in the
   // merge below an exact tie goes to the lowest flat index k * V + v, the oracle's order
   for (int k = wave; k < Kp; k += NW) {
-    const u64 tk = wave_top_sorted_strided<true, false, true>(  // (rows in HBM: eight loads in flight)
-        a.lpt + n * a.lt_sn + k * a.lt_sk, a.lt_sv, V, M, surv, nullptr, nullptr, 1, a.lpp[n * a.lp_sn + k * a.lp_sk]);
+    // (rows in HBM: read once, into registers, where they are short enough -- ctc_advance_kernel's choice)
+    const float *row = a.lpt + n * a.lt_sn + k * a.lt_sk;
+    const float bias = a.lpp[n * a.lp_sn + k * a.lp_sk];
+    const u64 tk = V > 8 * PDT_WAVE ? wave_top_sorted_regs<16, true>(row, a.lt_sv, V, M, surv, bias)
+                                    : wave_top_sorted_strided<true, false, true>(row, a.lt_sv, V, M, surv, nullptr, nullptr, 1, bias);
     if (lane < M) {
       tl[k * PDT_WAVE + lane] = (int)idx_of(tk);
       tlm[k * PDT_WAVE + lane] = fkey_inv(key_of(tk));  // the sum that was ranked
