@@ -15,7 +15,7 @@ L.pdt_debug_read_stamps(buf, 1)
 F.ctc_prefix_search(logits, K); torch.cuda.synchronize()
 L.pdt_debug_read_stamps(buf, 1)
 tot = sum(buf[i] for i in range(14))
-names = ["wait ready", "top-M list", "masses+merge", "rounds(rest)", "state+trie", "isp/nxt", "output walk", "lean prep", "lean sort", "lean shfl", "chm/info", "-", "-", "-"]
+names = ["wait ready", "top-M list", "masses+merge", "rounds(rest)", "state+trie", "isp/nxt", "output walk", "lean prep", "lean sort", "lean shfl", "chm/info", "walk: checkpoints", "walk: segments", "-"]
 for i, nm in enumerate(names):
     print("%-14s %8.1f cycles/frame  %5.1f%%" % (nm, buf[i] / (N * T), 100.0 * buf[i] / tot))
 print("total %.1f cycles/frame/wave" % (tot / (N * T)))

@@ -799,4 +799,56 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   return list_sufficed;
 }
 
+// Output walk of the one-kernel searches, second step: the (C + 1) x W segments between consecutive
+// checkpoints (tab[c * W + k] = (node, length) of prefix k's ancestor at checkpoint c; the last row
+// is the final beam) are read off the trie by all 64 lanes.  A segment is a chain of DEPENDENT loads,
+// one per token, and every utterance of a launch gets here at about the same time with nothing else
+// left to overlap: a lane therefore walks JW segments AT ONCE -- JW loads in flight per lane instead
+// of one (the walk was 9 % of the headline launch: 160 load latencies per lane; now ~40).
+template <int JW = 4>
+__device__ __forceinline__ void walk_trie_segments(const int2 *tab, const int nseg, const int W, const int2 *trie_u,
+                                                   int64_t *y_n, const int64_t row_stride) {
+  const int lane = lane_id();
+  for (int base = 0; base < nseg; base += JW * PDT_WAVE) {
+    int node[JW], ps[JW], stop[JW], col[JW];
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+      const int sg = base + j * PDT_WAVE + lane;
+      node[j] = -1, ps[j] = -1, stop[j] = 0, col[j] = 0;
+      if (sg < nseg) {
+        const int c = sg / W;
+        col[j] = sg - c * W;
+        const int2 top = tab[sg];
+        stop[j] = c > 0 ? tab[sg - W].y : 0;
+        node[j] = top.x;
+        ps[j] = top.y - 1;
+      }
+    }
+    bool any = true;
+    while (any) {
+      any = false;
+      u64 rec[JW];
+      bool act[JW];
+#pragma unroll
+      for (int j = 0; j < JW; ++j) {
+        act[j] = ps[j] >= stop[j] && node[j] >= 0;
+        rec[j] = 0ull;
+        // (a record = (parent, token), written by this wave earlier in the launch and made visible by
+        // the caller's fences: one ordinary 8-byte load -- the prefixes of a beam share most of their
+        // ancestors, so the L1 serves most of them)
+        if (act[j]) rec[j] = *reinterpret_cast<const u64 *>(trie_u + node[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < JW; ++j) {
+        if (act[j]) {
+          y_n[(int64_t)ps[j] * row_stride + col[j]] = (int64_t)(int)(unsigned)(rec[j] >> 32);
+          node[j] = (int)(unsigned)rec[j];
+          --ps[j];
+          any = true;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace pdt

@@ -427,7 +427,10 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
     a.y_probs[n * W + lane] = bm.nb + bm.b;
     a.y_lens[n * W + lane] = bm.len;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // (records stored by THIS wave, read back below with ordinary loads: its stores complete -- release,
+  // workgroup scope: no L2 write-back -- and its CU's L1 holds nothing stale -- acquire; ctc_search.hip)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   {
     // the walk of ctc_search.hip: checkpoint table in the freed row ring (the workers have left)
     const int C = Tn >> a.ckpt_shift;
@@ -439,26 +442,13 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
       int cur = bm.origin;
       for (int c = C - 1; c >= 0; --c) {
         const int2 *rec = a.ckpt + (((int64_t)n * a.ckpt_count + c) * W + cur);
-        const int nd = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int lo = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int nd = rec->x, lo = rec->y;
         tab[c * W + lane] = ok ? make_int2(nd, lo & 0xFFFFFF) : make_int2(-1, 0);
         cur = lo >> 24;
       }
     }
     wave_sync();
-    for (int sg = lane; sg < (C + 1) * W; sg += PDT_WAVE) {
-      const int c = sg / W, k = sg - c * W;
-      const int2 top = tab[sg];
-      const int stop = c > 0 ? tab[sg - W].y : 0;
-      int node = top.x;
-      for (int ps = top.y - 1; ps >= stop && node >= 0; --ps) {
-        const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
-        const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.y[((int64_t)ps * a.N + n) * W + k] = tok;
-        node = par;
-      }
-    }
+    walk_trie_segments(tab, (C + 1) * W, W, a.trie + (int64_t)n * a.T * W, a.y + n * W, (int64_t)a.N * W);
     int lmin = lane < W ? bm.len : 0x7fffffff;
     for (int off = 32; off > 0; off >>= 1) lmin = min(lmin, shfl_i(lmin, lane ^ off));
     for (int f = lmin * W + lane; f < a.S * W; f += PDT_WAVE) {

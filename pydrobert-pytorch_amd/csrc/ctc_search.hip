@@ -522,7 +522,11 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     a.y_probs[n * W + lane] = bm.nb + bm.b;
     a.y_lens[n * W + lane] = bm.len;
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  // (the trie and checkpoint records below were stored by THIS wave: once its stores have completed
+  // -- the release, workgroup scope: no write-back of the L2 as an agent-scope release costs every
+  // wave of the launch -- and this CU's L1 holds nothing stale -- the acquire -- ordinary loads see them)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #ifndef PDT_SKIP_WALK  // diagnostic build: cost of the output walk
   {
     // One chain of bm.len dependent loads per prefix would be ~T global-memory latencies with
@@ -537,27 +541,22 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
       tab[C * W + lane] = make_int2(bm.node, bm.len);
       int cur = bm.origin;
       for (int c = C - 1; c >= 0; --c) {
-        const int2 *rec = a.ckpt + (((int64_t)n * a.ckpt_count + c) * W + cur);
-        const int nd = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int lo = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int2 rec = a.ckpt[((int64_t)n * a.ckpt_count + c) * W + cur];
+        const int nd = rec.x, lo = rec.y;
         tab[c * W + lane] = ok ? make_int2(nd, lo & 0xFFFFFF) : make_int2(-1, 0);
         cur = lo >> 24;
       }
     }
     wave_sync();
-    for (int sg = lane; sg < (C + 1) * W; sg += PDT_WAVE) {
-      const int c = sg / W, k = sg - c * W;
-      const int2 top = tab[sg];
-      const int stop = c > 0 ? tab[sg - W].y : 0;
-      int node = top.x;
-      for (int pos = top.y - 1; pos >= stop && node >= 0; --pos) {
-        const int2 *rec = a.trie + ((int64_t)n * a.T * W + node);
-        const int par = __hip_atomic_load(&rec->x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int tok = __hip_atomic_load(&rec->y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.y[((int64_t)pos * a.N + n) * W + k] = tok;
-        node = par;
-      }
-    }
+#ifdef PDT_STAMPS
+    unsigned long long st1_ = __builtin_readcyclecounter();
+    if (lane == 0) atomicAdd(&g_stamps[11], st1_ - stamp_last_);
+#endif
+    walk_trie_segments(tab, (C + 1) * W, W, a.trie + (int64_t)n * a.T * W, a.y + n * W, (int64_t)a.N * W);
+#ifdef PDT_STAMPS
+    unsigned long long st2_ = __builtin_readcyclecounter();
+    if (lane == 0) atomicAdd(&g_stamps[12], st2_ - st1_);
+#endif
     // rows beyond a prefix's length are 0: the kernel writes every element of y (a separate
     // fill of the whole tensor costs 2 % of the launch; here it is a few stores per prefix)
     int lmin = lane < W ? bm.len : 0x7fffffff;
