@@ -565,10 +565,14 @@ def ctc_kernel_name(V, W):
         return "pdt::ctc_search_kernel"
     if plan[3] == 3:  # long rows held in the producers' registers (ctc_rowreg.hip)
         nr = plan[4]
-        return "pdt::ctc_rowreg_kernel<{}, {}, {}>".format(nr, nr - (8 if nr <= 80 else 16 if nr <= 128 else 32), plan[0])
+        return "pdt::ctc_rowreg_kernel<{}, {}, {}, {}>".format(nr, nr - (8 if nr <= 80 else 16 if nr <= 128 else 32), plan[0],
+                                                                16 if W == 16 else -1)
     nt = V // 64 if (plan[3] == 1 and V // 64 == 4) else -1
-    return "pdt::ctc_search_kernel<{}, {}, {}, {}>".format(
-        plan[0], nt, "true" if plan[3] == 1 else "false", "true" if plan[3] == 2 else "false")
+    # (the default shape -- width 16, 256 tokens, contiguous rows -- has its constants compiled in)
+    wc = 16 if (nt == 4 and W == 16) else -1
+    vc = 256 if (wc == 16 and V == 256) else -1
+    return "pdt::ctc_search_kernel<{}, {}, {}, {}, {}, {}>".format(
+        plan[0], nt, "true" if plan[3] == 1 else "false", "true" if plan[3] == 2 else "false", wc, vc)
 
 
 def rendezvous_only(args, world, rank):
@@ -760,15 +764,14 @@ def run_rank(args):
         if rec.get("config") == {"N": N, "T": T, "V": args.V, "beam": args.beam}:
             traffic = rec.get("hbm_bytes_per_launch")
             if "sq" in rec:
-                insts = rec["sq"]["SQ_INSTS_VALU_per_launch"]
-                ns = rec["sq"].get("valu_issue_ns_per_inst_static_mix")
                 valu = {
-                    "wave_insts_per_launch": insts,
-                    "issue_ns_per_wave_inst": ns,
-                    "pipe_busy_frac": None if ns is None else insts * ns * 1e-9 / (1024 * op_ms[dom] * 1e-3),
-                    "source": "profiles/" + tname + " (SQ_INSTS_VALU PMC pass; the kernel's static instruction mix priced "
-                              "by profiles/tools/valu_mix.py with the issue costs measured by "
-                              "profiles/tools/micro/valu_cost.hip)",
+                    "wave_insts_per_launch": rec["sq"]["SQ_INSTS_VALU_per_launch"],
+                    "pipe_busy_frac": rec["sq"].get("valu_pipe_busy_frac_measured"),
+                    "cycles_per_wave_inst": rec["sq"].get("valu_cycles_per_inst_measured"),
+                    "profiled_ms": rec.get("avg_ms_profiled"),
+                    "source": "profiles/" + tname + " (SQ_INSTS_VALU and SQ_ACTIVE_INST_VALU PMC passes over this "
+                              "configuration: busy = 4 x SQ_ACTIVE_INST_VALU / 1024 SIMDs against GRBM_GUI_ACTIVE / 8 "
+                              "cycles of the launch; a committed record, not collected in this run)",
                 }
 
     def say(msg):

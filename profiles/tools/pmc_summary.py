@@ -48,6 +48,11 @@ if "SQ_WAVE_CYCLES" in c and "SQ_ACTIVE_INST_ANY" in c:
                               "scalar": c["SQ_ACTIVE_INST_SCA"] / w, "lds": c["SQ_ACTIVE_INST_LDS"] / w}
 if "GRBM_GUI_ACTIVE" in c and "avg_ms" in rec:
     rec["effective_clock_GHz"] = c["GRBM_GUI_ACTIVE"] / 8.0 / (rec["avg_ms"] * 1e-3) / 1e9
+if "GRBM_GUI_ACTIVE" in c and "SQ_ACTIVE_INST_VALU" in c:
+    # SQ_ACTIVE_INST_VALU counts, chip-wide, quad-cycles in which a SIMD's vector pipe is executing:
+    # x 4 / 1024 SIMDs = busy cycles per SIMD, against the launch's cycles (GRBM_GUI_ACTIVE is summed over 8 XCDs)
+    rec["valu_pipe_busy_frac"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0)
+    rec["valu_cycles_per_inst"] = c["SQ_ACTIVE_INST_VALU"] * 4.0 / c["SQ_INSTS_VALU"] if c.get("SQ_INSTS_VALU") else None
 print(json.dumps(rec, indent=1))
 if len(sys.argv) > 3:
     json.dump(rec, open(sys.argv[3], "w"), indent=1)
