@@ -443,6 +443,8 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   constexpr bool kFullFromStart = WC > 0 && VC > 0 && VC + 1 >= WC;
   int Kp = kFullFromStart ? WC : 1;
   int fail_score = 0, full_mode = 0;
+  // (32-frame checkpoints in the constant-shape instance: the launcher checks)
+  const int ckpt_shift = (WC > 0 && VC > 0) ? 5 : a.ckpt_shift;
 #ifdef PDT_STAMPS
   unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
@@ -470,6 +472,9 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     L.list_len = __float_as_int(slot_hdr(sl)[2]);
     const float s = slot_hdr(sl)[0];  // reciprocal of the frame's softmax normaliser
     int ns, nt, nk;
+    // (a fresh copy of the lane index for the end of the frame: the masks of `lane == 0` / `lane < W`
+    // are then a compare where used, not scalar pairs kept across the frame and spilled to lanes)
+    int lane_t = lane;
 #ifndef PDT_SKIP_CONSUMER  // diagnostic build: producer-side cost alone
     // Every mass has underflowed to 0 (the beam is ordered, so entry 0 holds the largest): every
     // candidate of this and all later frames has mass 0 too, the reference's top-k over them is
@@ -497,18 +502,20 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     const int wf = fail_score > 16 ? 1 : (fail_score < 4 ? 0 : full_mode);
     if (wf != full_mode) {
       full_mode = wf;
-      if (lane == 0) __hip_atomic_store(want_full, wf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" : "+v"(lane_t));
+      if (lane_t == 0) __hip_atomic_store(want_full, wf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
 #else
     ns = nt = nk = 0; (void)s;
     if (!kFullFromStart) Kp = W;
 #endif
-    if (lane == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
-      const int c = ((t + 1) >> a.ckpt_shift) - 1;
-      if (lane < W)
-        a.ckpt[((int64_t)n * a.ckpt_count + c) * W + lane] = make_int2(bm.node, bm.len | (bm.origin << 24));
-      bm.origin = lane;
+    asm volatile("" : "+v"(lane_t));
+    if (lane_t == 0) __hip_atomic_store(consumed, t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (((t + 1) & ((1 << ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
+      const int c = ((t + 1) >> ckpt_shift) - 1;
+      if (lane_t < W)
+        a.ckpt[((int64_t)n * a.ckpt_count + c) * W + lane_t] = make_int2(bm.node, bm.len | (bm.origin << 24));
+      bm.origin = lane_t;
     }
   }
 
@@ -534,7 +541,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     // (1) each prefix follows its `origin` links back through the C checkpoints -- C hops --
     // leaving (node, length) of its ancestor at every checkpoint in LDS (the ring is free now);
     // (2) the (C + 1) x W segments between consecutive checkpoints are walked by all 64 lanes.
-    const int C = Tn >> a.ckpt_shift;
+    const int C = Tn >> ckpt_shift;
     int2 *tab = reinterpret_cast<int2 *>(ring);  // [(C + 1) x W]: fits, see launch_ctc_search
     if (lane < W) {
       const bool ok = bm.node >= 0;
@@ -646,7 +653,7 @@ int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &r
 #ifndef PDT_NO_V256  // (diagnostic builds compare against the run-time shapes)
   {
     const RingLayout c = ring_layout(256, 16, PDT_RING_STAGES, PDT_UTT_PER_WG, 1);
-    if (a.V == 256 && a.W == 16 && !a.exact_div && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
+    if (a.V == 256 && a.W == 16 && a.ckpt_shift == 5 && !a.exact_div && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
         c.slot_bytes == rl.slot_bytes)
       return launch_ctc_search_p<1, 4, true, false, 16, 256>(a, rl, stream);
   }
