@@ -286,6 +286,26 @@ def test_ctc_default_shape_instances_match_the_general_kernels(device):
             _check_search(F.ctc_prefix_search(dense[:60, :8].contiguous(), K, tl[:8].clamp(max=60)), exp, (V, K))
 
 
+def test_ctc_default_shape_with_many_frames(device):
+    """V = 256, width 16 with so many frames that the checkpoints of the output walk are spaced wider
+    than 32 frames (the constant-shape instance holds 32 as a constant, so the launcher must pick the
+    width-16 instance instead): against the oracle and, through a strided vocabulary axis, against the
+    general kernel."""
+    rng = np.random.default_rng(321)
+    T, N, V = 2100, 3, 256
+    lg = _peaky_logits(rng, T, N, V, scale=12.0)  # (peaky enough for float32 masses to last 2100 frames)
+    lens = np.array([2100, 1500, 1793])
+    tl = torch.from_numpy(lens).to(device)
+    dense = torch.from_numpy(lg).to(device)
+    a = F.ctc_prefix_search(dense, 16, tl)
+    _check_search(a, oracle.ctc_prefix_search(lg, 16, lens), "many frames")
+    wide = torch.zeros((T, N, 2 * (V + 1)), device=device)
+    wide[:, :, ::2] = dense
+    b = F.ctc_prefix_search(wide[:, :, ::2], 16, tl)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+
+
 def test_ctc_strided_logits_and_errors(device):
     rng = np.random.default_rng(6)
     lg = _peaky_logits(rng, 12, 4, 9)
