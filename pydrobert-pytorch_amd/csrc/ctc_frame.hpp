@@ -30,6 +30,17 @@ __device__ unsigned long long g_stats[16];
 #define PDT_STAT(i) do {} while (0)
 #endif
 
+// Diagnostic build only (-DPDT_UTT_STATS): per utterance (first 8192 of a launch), accumulated in the
+// consumer wave's registers and stored once at the end -- [0] when its loop ended (16-cycle units
+// since the wave started), [1] frames that left the lean tier, [2] short lists it completed,
+// [3] time it waited for its producer
+#ifdef PDT_UTT_STATS
+__device__ unsigned g_utt_stats[8192 * 4];
+#define PDT_UTT(k, v) do { pdt_utt_acc[k] += (unsigned)(v); } while (0)
+#else
+#define PDT_UTT(k, v) do {} while (0)
+#endif
+
 constexpr int kMaxWidth = 32;  // K + K' <= 64 tokens fit one per lane
 
 struct CtcArgs {
@@ -52,6 +63,9 @@ struct CtcArgs {
   // the row) instead of e * (1 / sum) -- slower; lets a caller see which disagreements with a
   // reference are the reciprocal's ("Near ties")
   int exact_div;
+  // PDT_CTC_LEAN_EXTRA=0: frames the lean tier's mid / exact paths would decide go to the full tiers
+  // (same results; the tests compare the two)
+  int no_lean_extra;
 };
 
 struct Beam {
@@ -182,9 +196,12 @@ __device__ __forceinline__ void build_shared_list(const float *p, float inv, int
 // Kp = number of live lanes (1 at t = 0, then W).
 // On return new_src / new_tok / new_kind describe where lane i's new prefix came from
 // (kind: 0/1 extension, 2 non-extension, -1 invalid).
-#ifdef PDT_STAMPS
+#if defined(PDT_STAMPS)
 #define PDT_STAMP_PARAM , unsigned *pdt_stamp_acc
 #define PDT_STAMP_ARG , pdt_stamp_acc
+#elif defined(PDT_UTT_STATS)
+#define PDT_STAMP_PARAM , unsigned *pdt_utt_acc
+#define PDT_STAMP_ARG , pdt_utt_acc
 #else
 #define PDT_STAMP_PARAM
 #define PDT_STAMP_ARG
@@ -388,22 +405,45 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     const unsigned kt = has ? (((keyL + 63u) & ~63u) | (63u - (unsigned)lane)) : (63u - (unsigned)lane);
     const unsigned st = wave_sort_desc<unsigned>(kt);
     PDT_STAMP(8);
-    const int wl = 63 - (int)(st & 63u);
-    const unsigned wkey = (unsigned)shfl_i((int)keyL, wl);
-    const int wth = shfl_i(tokL | (hidden ? (int)0x80000000u : 0), wl);
+    int wl = 63 - (int)(st & 63u);
+    unsigned wkey = (unsigned)shfl_i((int)keyL, wl);
     const unsigned st_next = (unsigned)shfl_i((int)st, lane + 1);
+    bool tie = lane < K && (st >> 6) != 0u && (st >> 6) == (st_next >> 6);
+#ifndef PDT_NO_EXACT_LEAN
+    // Two of the first K + 1 agree in the upper 26 bits.  Between prefixes that came by equal masses
+    // once (two tokens with the same logit in one frame is all it takes) this repeats in every later
+    // frame, and a launch ends with its slowest utterance: rank the same 64 candidates again by their
+    // EXACT keys with the full tiers' tie order in the low word (lowest flat candidate index of the
+    // reference's layout first: extension (k, list position) -- the last-token stream just before
+    // the entry at its own position --, every non-extension after every extension) instead of
+    // handing the frame over.  Ties among masses that have underflowed to 0 stay with the full tiers.
+    if (__ballot(tie) != 0ull && __ballot(tie && (st >> 6) <= 1u) == 0ull && !a.no_lean_extra) {
+      const int jl_k = shfl_i(jl, ksrc);
+      const unsigned trank = rr < 2 ? (unsigned)kb * 128u + 2u * (unsigned)j + 1u
+                                    : (rr == 2 ? (unsigned)kb * 128u + 2u * (unsigned)(jl_k >= 0 ? jl_k : 63) : (unsigned)(32 + kb) * 128u);
+      const u64 s64 = wave_sort_desc<u64>(pack_key(keyL, (trank << 6) | (unsigned)lane));
+      wl = (int)(idx_of(s64) & 63u);
+      wkey = key_of(s64);
+      tie = false;
+    }
+#endif
+    const int wth = shfl_i(tokL | (hidden ? (int)0x80000000u : 0), wl);
     const int wtok = wth & 0x7fffffff;
     const bool isw = lane < K && wkey != 0u;
     const int rw = wl >> 4;
-    const bool tie = lane < K && (st >> 6) != 0u && (st >> 6) == (st_next >> 6);
     const int wid = wth < 0 ? 64 : 0;
     PDT_STAMP(9);
     bool lean_ok = __ballot((isw && wid >= 64) || tie) == 0ull;
+#ifdef PDT_UTT_REASONS
+    if (__ballot(tie) != 0ull) PDT_UTT(2, 1);
+    if (__ballot(tie && (st >> 6) == 1u) != 0ull) PDT_UTT(3, 1);
+#endif
     if (__ballot(isw && wid >= 64) == 0ull) {
       // (not when an upper bound ranks among the first K: that is no real candidate.)  The keys
       // of a bucket of the rounded sort lie in (r - 64, r].
-      const unsigned rk = (unsigned)__builtin_amdgcn_readlane((int)st, K - 1) >> 6;
-      tau_hint = rk ? (rk << 6) - 63u : 1u;
+      // (from the K-th winner's exact key: a lower bound of the same kind, a little lower)
+      const unsigned kk = (unsigned)__builtin_amdgcn_readlane((int)wkey, K - 1);
+      tau_hint = kk > 64u ? ((kk + 63u) & ~63u) - 63u : 1u;
     }
     if (lean_ok && __ballot(isw && rw == 1) != 0ull) {
       // A prefix's entry 1 is among the winners: its entry 2 (not resident here) matters only
@@ -422,10 +462,66 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       if (a2 != 0u) key2 = fkey_nonneg(tot2 * p2);
       else if (!full_list) key2 = fkey_nonneg(tot2 * p2) + 1u;  // upper bound of a hidden entry
       const bool third_wins = isw && rw == 1 && key2 != 0u && key2 >= kth;
-      lean_ok = __ballot(third_wins) == 0ull;
+      const u64 tw = __ballot(third_wins);
+      lean_ok = tw == 0ull;
 #ifdef PDT_STATS
       if (!lean_ok) {
-        if (__popcll(__ballot(third_wins)) == 1) PDT_STAT(6); else PDT_STAT(7);
+        if (__popcll(tw) == 1) PDT_STAT(6); else PDT_STAT(7);
+      }
+#endif
+#ifndef PDT_NO_MID_TIER
+      // Mid tier: ONE prefix's deeper entries reach the winners (97 % of the frames that leave the lean
+      // tier; a beam that has collapsed onto one prefix does it frame after frame, and the launch ends
+      // with its slowest utterance).  Every other prefix is settled by the lean sort -- its third
+      // entry loses against the lean K-th winner, and the final K-th can only be larger -- so the
+      // frame's winners are the top K of (lean winners, in rank order in lanes 0..15) and (that
+      // prefix's next 16 available list entries, in list order in lanes 16..31): two sorted runs, one
+      // 5-stage merge of rounded keys.  Anything unusual -- a rounded tie among the first K + 1, the
+      // prefix's last entry here still winning while the list has more (or is short) -- goes to the
+      // full tiers as before.
+      if (tw != 0ull && (tw & (tw - 1ull)) == 0ull && !a.no_lean_extra) {
+        const int kw1 = __builtin_amdgcn_readlane(wl, (int)__builtin_ctzll(tw)) & 15;
+        unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)avail, kw1);
+        a2 &= a2 - 1u;
+        a2 &= a2 - 1u;  // entries 0 and 1 are among the lean candidates
+        const float tot1 = readlane_f(tot, kw1);
+        const int list1 = list_of(kw1);
+        const int n_more = __popc(a2);
+        // lane j < 32 with bit j of a2 set owns the list entry j; its rank among the set bits is the
+        // lane (16 + rank) that takes it: one forward permute (lanes without an entry send to lane 63)
+        const unsigned below = a2 & ((1u << (lane & 31)) - 1u);
+        const int rank = __popc(below);
+        const bool owner = lane < 32 && ((a2 >> (lane & 31)) & 1u) && rank < 16;
+        const int jj = __builtin_amdgcn_ds_permute((owner ? 16 + rank : 63) << 2, owner ? lane + 1 : 0) - 1;
+        const bool extra = lane >= 16 && lane < 32 && jj >= 0;
+        const int jx = extra ? jj : 0;
+        const unsigned key_e = extra ? fkey_nonneg(tot1 * L.tl_p[list1 * PDT_WAVE + jx]) : 0u;
+        const int tok_e = L.tl_tok[list1 * PDT_WAVE + jx];
+        // payload of lane l < 32: the exact key, the token, (source prefix | kind << 8)
+        const unsigned pk = lane < 16 ? (isw ? wkey : 0u) : key_e;
+        const int ptok = lane < 16 ? wtok : tok_e;
+        const int pinfo = lane < 16 ? ((wl & 15) | ((rw == 2 ? 1 : (rw == 3 ? 2 : 0)) << 8)) : kw1;
+        const unsigned km = (lane < 32 && pk != 0u) ? (((pk + 63u) & ~63u) | (63u - (unsigned)lane)) : (63u - (unsigned)lane);
+        const unsigned sm = sort_groups<32>(lane < 32 ? km : 0u);
+        const unsigned sm_next = (unsigned)shfl_i((int)sm, lane + 1);
+        const int from = 63 - (int)(sm & 63u);
+        const bool win = lane < K && (sm >> 6) != 0u;
+        const bool tie_m = lane < K && (sm >> 6) != 0u && (sm >> 6) == (sm_next >> 6);
+        // the last entry taken here (16 + min(n_more, 16) - 1) must lose unless the list holds no more
+        const int last_lane = 15 + min(n_more, 16);
+        const bool open_end = n_more > 16 || !full_list;
+        const bool runs_out = win && open_end && from == last_lane;
+        if (n_more > 0 && __ballot(tie_m || runs_out) == 0ull) {
+          const unsigned k_w = (unsigned)shfl_i((int)pk, from);
+          const int t_w = shfl_i(ptok, from), i_w = shfl_i(pinfo, from);
+          if (win) {
+            new_src = i_w & 255;
+            new_tok = t_w;
+            new_kind = i_w >> 8;
+            new_mass = fkey_nonneg_inv(k_w);
+          }
+          selected = true;
+        }
       }
 #endif
     }
@@ -444,6 +540,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   bool list_sufficed = true;
   if (!selected) {  // the full tiers own their layout values: nothing of them is live above
   PDT_STAT(5);
+  PDT_UTT(1, 1);
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
   // candidates (slots s = 0..2, "entry" e = r + R * s): entries 0 .. 3R-3 are the first
   // available list entries of stream 0 in order, entry 3R-2 is stream 1, entry 3R-1 stream 2.
@@ -685,6 +782,9 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     // already indexed stay valid), redo the bookkeeping that depends on list positions, and
     // run the tiers again from a clean slate
     PDT_STAT(4);
+#ifndef PDT_UTT_REASONS
+    PDT_UTT(2, 1);
+#endif
     build_shared_list<false>(p, inv, V, M, reinterpret_cast<u64 *>(L.nxt_new), L.tl_tok, L.tl_p, L.pos);
     if (lane == 0) L.hdr[2] = __int_as_float(M);
     wave_sync();

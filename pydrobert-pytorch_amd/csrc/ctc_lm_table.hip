@@ -504,6 +504,7 @@ int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V
   a.trie = reinterpret_cast<int2 *>(workspace);
   a.ckpt = a.trie + T * N * width;
   a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
+  a.no_lean_extra = switches().ctc_lean_extra == 0 ? 1 : 0;
   A.factors = factors; A.fmax = factor_max; A.f_stride = f_stride; A.contexts = (int)contexts; A.sos_row = (int)sos_row; A.beta = beta; A.valid_mixture = valid_mixture;
   const LmTabLayout ly = lmtab_layout((int)V, (int)width, (int)contexts);
   if ((size_t)ly.utt_bytes > 160 * 1024) return PDT_E_TOO_LONG;

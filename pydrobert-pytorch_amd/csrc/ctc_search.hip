@@ -449,8 +449,15 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   unsigned pdt_stamp_acc[14] = {0};  // wave-uniform: scalar registers
 #endif
   int sl = 0;  // t % NS
+#ifdef PDT_UTT_STATS
+  const unsigned long long utt_t0_ = __builtin_readcyclecounter();
+  unsigned pdt_utt_acc[4] = {0, 0, 0, 0};
+#endif
   for (int t = 0; t < Tn; ++t, sl = sl + 1 == NS ? 0 : sl + 1) {
     PDT_STAMP_BEGIN;
+#ifdef PDT_UTT_STATS
+    const unsigned long long w0_ = __builtin_readcyclecounter();
+#endif
     if (__hip_atomic_load(&ready[P == 1 ? 0 : sl], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= t) {
       // the producer is behind: wait at low priority (the polling loop itself issues VALU
       // instructions that would otherwise outrank the producer this wave is waiting for)
@@ -465,6 +472,9 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
 #endif
     }
     PDT_STAMP(0);
+#if defined(PDT_UTT_STATS) && !defined(PDT_UTT_REASONS)
+    PDT_UTT(3, (__builtin_readcyclecounter() - w0_) >> 4);
+#endif
     L.tl_tok = slot_tok(sl);
     L.tl_p = slot_p(sl);
     L.pos = slot_pos(sl);
@@ -519,6 +529,12 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
     }
   }
 
+#ifdef PDT_UTT_STATS
+  if (lane == 0 && n < 8192) {
+    g_utt_stats[n * 4 + 0] = (unsigned)((__builtin_readcyclecounter() - utt_t0_) >> 4);
+    for (int k = 1; k < 4; ++k) g_utt_stats[n * 4 + k] = pdt_utt_acc[k];
+  }
+#endif
 #ifdef PDT_STAMPS
   if (lane == 0)
     for (int i = 0; i < 14; ++i) atomicAdd(&g_stamps[i], (unsigned long long)pdt_stamp_acc[i]);
@@ -653,7 +669,7 @@ int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &r
 #ifndef PDT_NO_V256  // (diagnostic builds compare against the run-time shapes)
   {
     const RingLayout c = ring_layout(256, 16, PDT_RING_STAGES, PDT_UTT_PER_WG, 1);
-    if (a.V == 256 && a.W == 16 && a.ckpt_shift == 5 && !a.exact_div && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
+    if (a.V == 256 && a.W == 16 && a.ckpt_shift == 5 && !a.exact_div && !a.no_lean_extra && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
         c.slot_bytes == rl.slot_bytes)
       return launch_ctc_search_p<1, 4, true, false, 16, 256>(a, rl, stream);
   }
@@ -718,6 +734,7 @@ int pdt_ctc_prefix_search(const float *logits, int64_t T, int64_t N, int64_t V, 
   a.ckpt = a.trie + T * N * width;
   a.grow = reinterpret_cast<unsigned char *>(workspace) + ctc_trie_bytes(T, N, width);
   a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
+  a.no_lean_extra = switches().ctc_lean_extra == 0 ? 1 : 0;
   // (contiguous rows: the register form addresses a row as base + immediates)
   if (ctc_rowreg_applies(a.V, a.W) && lg_sv == 1) return launch_ctc_rowreg(a, (hipStream_t)stream);
   CtcPlan plan;
@@ -737,6 +754,17 @@ extern "C" int pdt_debug_read_stats(unsigned long long *host16, int reset) {
   if (e == hipSuccess && reset) {
     unsigned long long z[16] = {0};
     e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_stats), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
+
+#ifdef PDT_UTT_STATS
+extern "C" int pdt_debug_read_utt_stats(unsigned *host, int count, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(pdt::g_utt_stats), sizeof(unsigned) * 4 * (size_t)count);
+  if (e == hipSuccess && reset) {
+    static unsigned z[8192 * 4];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_utt_stats), z, sizeof(z));
   }
   return (int)e;
 }

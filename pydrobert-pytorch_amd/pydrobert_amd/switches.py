@@ -30,7 +30,7 @@ _HOST_DEFAULTS = {
 # switches of the native library (csrc/switches.hpp); the library reads the environment itself
 _NATIVE = (
     "PDT_LEV_BITPAR", "PDT_OC_BITPAR", "PDT_OC_WAVES", "PDT_CTC_EXACT_DIV", "PDT_CTC_ROWREG",
-    "PDT_STEP_WIDE", "PDT_LM_CACHE", "PDT_LM_PERSISTENT", "PDT_LM_STEP_WAVES", "PDT_WARP_BANDS",
+    "PDT_STEP_WIDE", "PDT_LM_CACHE", "PDT_LM_PERSISTENT", "PDT_LM_STEP_WAVES", "PDT_WARP_BANDS", "PDT_CTC_LEAN_EXTRA",
 )  # fmt: skip
 
 

@@ -286,6 +286,39 @@ def test_ctc_default_shape_instances_match_the_general_kernels(device):
             _check_search(F.ctc_prefix_search(dense[:60, :8].contiguous(), K, tl[:8].clamp(max=60)), exp, (V, K))
 
 
+def test_lean_tier_extras_match_the_full_tiers(device, switch):
+    """A frame whose winners include one prefix's third-and-deeper list entries, or two candidates
+    that agree in the upper 26 bits of their masses, is decided beside the lean tier (ctc_frame.hpp:
+    mid tier / exact re-ranking) -- with PDT_CTC_LEAN_EXTRA=0 by the full tiers.  Same bits on inputs
+    built to hit both all the time: few distinct logit values (exact ties everywhere), duplicated
+    logits (two tokens equal in a quarter of the rows -- the prefixes they start carry equal masses
+    from then on), values on a coarse grid (near ties); short rows (both instances) and register rows."""
+    rng = np.random.default_rng(99)
+    for it in range(24):
+        V = int(rng.choice([256, 256, 300, 1000, 40])); W = int(rng.choice([16, 16, 8, 32, 5]))
+        T = int(rng.choice([40, 120, 300])); N = int(rng.integers(2, 24))
+        kind = it % 3
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        np.put_along_axis(lg, rng.integers(0, V + 1, (T, N, 1)), float(rng.choice([6.0, 9.0, 12.0])), 2)
+        if kind == 0:
+            lg = np.round(lg * 2) / 2
+        elif kind == 1:
+            for _ in range(T * N // 4):
+                t, n = rng.integers(0, T), rng.integers(0, N)
+                a, b = rng.integers(0, V, 2)
+                lg[t, n, b] = lg[t, n, a]
+        else:
+            lg = np.round(lg * 4096) / 4096
+        lens = torch.from_numpy(rng.integers(T // 2, T + 1, N)).to(device)
+        x = torch.from_numpy(lg).to(device)
+        outs = []
+        for extra in (1, 0):
+            switch("PDT_CTC_LEAN_EXTRA", extra)
+            outs.append(F.ctc_prefix_search(x, W, lens))
+        for p, q in zip(*outs):
+            assert torch.equal(p, q), (it, V, W, T, N, kind)
+
+
 def test_ctc_default_shape_with_many_frames(device):
     """V = 256, width 16 with so many frames that the checkpoints of the output walk are spaced wider
     than 32 frames (the constant-shape instance holds 32 as a constant, so the launcher must pick the
