@@ -392,9 +392,16 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
 #ifdef PDT_LMTAB_STAMPS
   unsigned long long acc_[4] = {0, 0, 0, 0}, last_ = __builtin_amdgcn_s_memtime();
 #endif
+#ifdef PDT_UTT_STATS
+  const unsigned long long utt_t0_ = __builtin_readcyclecounter();
+  unsigned pdt_utt_acc[4] = {0, 0, 0, 0};
+#endif
   for (int t = 0; t < Tn; ++t) {
     build_lists(t);
     LMTAB_STAMP(0);
+#ifdef PDT_UTT_STATS
+    if (lane == 0) pdt_utt_acc[3] += (unsigned)*ctx_count;  // lists asked for in this frame
+#endif
     for (int w = 1; w < kLmTabWaves; ++w) wait_above(&done[w], t);
     LMTAB_STAMP(1);
     const float *p = rows + (t % kLmTabRows) * ly.row_floats;
@@ -420,6 +427,12 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
 #ifdef PDT_LMTAB_STAMPS
   if (lane == 0)
     for (int i = 0; i < 4; ++i) atomicAdd(&g_lmtab_stamps[i], acc_[i]);
+#endif
+#ifdef PDT_UTT_STATS
+  if (lane == 0 && n < 8192) {
+    g_utt_stats[n * 4 + 0] = (unsigned)((__builtin_readcyclecounter() - utt_t0_) >> 4);
+    for (int k = 1; k < 4; ++k) g_utt_stats[n * 4 + k] = pdt_utt_acc[k];
+  }
 #endif
 
   // ---- outputs (:1188-1200): probabilities, lengths, and the prefixes read off the trie ------
@@ -535,6 +548,17 @@ extern "C" int pdt_debug_read_lmtab_stamps(unsigned long long *host8, int reset)
   if (e == hipSuccess && reset) {
     unsigned long long z[8] = {0};
     e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_lmtab_stamps), z, sizeof(z));
+  }
+  return (int)e;
+}
+#endif
+
+#ifdef PDT_UTT_STATS
+extern "C" int pdt_debug_read_utt_stats_lm(unsigned *host, int count, int reset) {
+  hipError_t e = hipMemcpyFromSymbol(host, HIP_SYMBOL(pdt::g_utt_stats), sizeof(unsigned) * 4 * (size_t)count);
+  if (e == hipSuccess && reset) {
+    static unsigned z[8192 * 4];
+    e = hipMemcpyToSymbol(HIP_SYMBOL(pdt::g_utt_stats), z, sizeof(z));
   }
   return (int)e;
 }
