@@ -33,7 +33,8 @@ __device__ unsigned long long g_stats[16];
 // Diagnostic build only (-DPDT_UTT_STATS): per utterance (first 8192 of a launch), accumulated in the
 // consumer wave's registers and stored once at the end -- [0] when its loop ended (16-cycle units
 // since the wave started), [1] frames that left the lean tier, [2] short lists it completed,
-// [3] time it waited for its producer
+// [3] time it waited for its producer  (with -DPDT_UTT_REASONS as well: [2] frames with a rounded tie
+// among the best K + 1, [3] those whose tie is among masses that underflowed to 0)
 #ifdef PDT_UTT_STATS
 __device__ unsigned g_utt_stats[8192 * 4];
 #define PDT_UTT(k, v) do { pdt_utt_acc[k] += (unsigned)(v); } while (0)
