@@ -18,6 +18,6 @@ for vm in (False, True):
         for _ in range(2):
             search(lg); torch.cuda.synchronize()
             L.pdt_debug_read_utt_stats_lm(buf.ctypes.data, N, 1)
-    end = buf[:, 0].astype(np.float64); exits = buf[:, 1]; lists = buf[:, 3].astype(np.float64) / T
-    print("valid mixture" if vm else "fusion", "end: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | lean exits mean %.1f max %d | lists per frame mean %.2f max %.2f | corr(end, lists) %.2f corr(end, exits) %.2f"
-          % (*np.percentile(end, [10, 50, 90, 99]), end.max(), exits.mean(), exits.max(), lists.mean(), lists.max(), np.corrcoef(end, lists)[0, 1], np.corrcoef(end, exits)[0, 1]))
+    end = buf[:, 0].astype(np.float64); exits = buf[:, 1]; lists = buf[:, 2].astype(np.float64) / T; ctxs = buf[:, 3].astype(np.float64) / T
+    print("valid mixture" if vm else "fusion", "end: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f | lean exits mean %.1f max %d | contexts per frame mean %.2f | LISTS per frame mean %.2f max %.2f | corr(end, lists) %.2f corr(end, exits) %.2f"
+          % (*np.percentile(end, [10, 50, 90, 99]), end.max(), exits.mean(), exits.max(), ctxs.mean(), lists.mean(), lists.max(), np.corrcoef(end, lists)[0, 1], np.corrcoef(end, exits)[0, 1]))
