@@ -345,6 +345,9 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   // the same float operations on larger operands.  ub_k < tau closes prefix k's extension streams
   // (DenseCtx::closed).  In blank-dominated frames that leaves a list or two instead of one per context.
   unsigned closed = 0u;
+#ifdef PDT_UTT_STATS
+  int open_lists_dbg_v = 0, *open_lists_dbg = &open_lists_dbg_v;
+#endif
   auto publish = [&](const int t) {
     int lp = lane;
     asm volatile("" : "+v"(lp));
@@ -386,6 +389,9 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
       *ctx_count = dead ? 0 : __popcll(leaders);
       *kp_pub = Kp;
     }
+#ifdef PDT_UTT_STATS
+    *open_lists_dbg = dead ? 0 : __popcll(__ballot(valid && leader == lp && group_open));
+#endif
     st_flag(ctx_pub, t + 1);
   };
   if (Tn > 0) publish(0);
@@ -400,7 +406,8 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
     build_lists(t);
     LMTAB_STAMP(0);
 #ifdef PDT_UTT_STATS
-    if (lane == 0) pdt_utt_acc[3] += (unsigned)*ctx_count;  // lists asked for in this frame
+    if (lane == 0) pdt_utt_acc[3] += (unsigned)*ctx_count;  // contexts of this frame (an etab row each)
+    pdt_utt_acc[2] += (unsigned)open_lists_dbg_v;           // ... of which need a list
 #endif
     for (int w = 1; w < kLmTabWaves; ++w) wait_above(&done[w], t);
     LMTAB_STAMP(1);
