@@ -422,9 +422,24 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       const int jl_k = shfl_i(jl, ksrc);
       const unsigned trank = rr < 2 ? (unsigned)kb * 128u + 2u * (unsigned)j + 1u
                                     : (rr == 2 ? (unsigned)kb * 128u + 2u * (unsigned)(jl_k >= 0 ? jl_k : 63) : (unsigned)(32 + kb) * 128u);
-      const u64 s64 = wave_sort_desc<u64>(pack_key(keyL, (trank << 6) | (unsigned)lane));
-      wl = (int)(idx_of(s64) & 63u);
-      wkey = key_of(s64);
+      const bool tie_prev = shfl_i((int)tie, lane - 1) != 0;  // this rank ties with the one before it
+      if (__ballot(tie && tie_prev) == 0ull) {
+        // runs of two (the usual case: a pair of prefixes with equal masses): the rounded sort has
+        // everything else in order, so each pair is put in exact order by itself -- three crossbar
+        // fetches and a compare instead of a 64-bit sort
+        const unsigned wtr = (unsigned)shfl_i((int)trank, wl);
+        const int partner = tie ? lane + 1 : (tie_prev ? lane - 1 : lane);
+        const unsigned pkey = (unsigned)shfl_i((int)wkey, partner), ptr = (unsigned)shfl_i((int)wtr, partner);
+        const int pwl = shfl_i(wl, partner);
+        const bool mine_first = wkey > pkey || (wkey == pkey && wtr < ptr);
+        const bool take = tie ? !mine_first : (tie_prev && mine_first);
+        wl = take ? pwl : wl;
+        wkey = take ? pkey : wkey;
+      } else {
+        const u64 s64 = wave_sort_desc<u64>(pack_key(keyL, (trank << 6) | (unsigned)lane));
+        wl = (int)(idx_of(s64) & 63u);
+        wkey = key_of(s64);
+      }
       tie = false;
     }
 #endif
