@@ -8,6 +8,9 @@ g = torch.Generator(device=dev).manual_seed(3)
 logits = torch.randn((T, N, V + 1), device=dev, generator=g)
 peak = torch.randint(0, V + 1, (T, N, 1), device=dev, generator=g)
 logits.scatter_add_(2, peak, torch.full((T, N, 1), 12.0, device=dev))
+if os.environ.get("SPEECH"):  # blank-dominated rows (bench.speechlike_logits)
+    import bench
+    logits = bench.speechlike_logits(T, N, V, dev, 5, bench.synthetic_bigram_dicts(V))
 L = _cabi.lib()
 buf = (ctypes.c_ulonglong * 16)()
 F.ctc_prefix_search(logits, K); torch.cuda.synchronize()
