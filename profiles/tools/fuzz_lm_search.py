@@ -7,6 +7,9 @@ from pydrobert_amd import modules as M
 from pydrobert_amd import switches
 from _lm_fixtures import random_dicts
 dev = torch.device("cuda:0")
+# (bigram models would otherwise take the factor-table search, whose fused softmax differs from torch's in
+# the last bits: that route is fuzzed against the oracle with a tolerance by fuzz_r04.py)
+switches.set("PDT_CTC_LM_TABLE", 0)
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 cases = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 for it in range(cases):

@@ -418,7 +418,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
     // reference's layout first: extension (k, list position) -- the last-token stream just before
     // the entry at its own position --, every non-extension after every extension) instead of
     // handing the frame over.  Ties among masses that have underflowed to 0 stay with the full tiers.
-    if (__ballot(tie) != 0ull && __ballot(tie && (st >> 6) <= 1u) == 0ull && !a.no_lean_extra) {
+    if (__builtin_expect(__ballot(tie) != 0ull && __ballot(tie && (st >> 6) <= 1u) == 0ull && !a.no_lean_extra, 0)) {
       const int jl_k = shfl_i(jl, ksrc);
       const unsigned trank = rr < 2 ? (unsigned)kb * 128u + 2u * (unsigned)j + 1u
                                     : (rr == 2 ? (unsigned)kb * 128u + 2u * (unsigned)(jl_k >= 0 ? jl_k : 63) : (unsigned)(32 + kb) * 128u);
@@ -495,7 +495,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       // 5-stage merge of rounded keys.  Anything unusual -- a rounded tie among the first K + 1, the
       // prefix's last entry here still winning while the list has more (or is short) -- goes to the
       // full tiers as before.
-      if (tw != 0ull && (tw & (tw - 1ull)) == 0ull && !a.no_lean_extra) {
+      if (__builtin_expect(tw != 0ull && (tw & (tw - 1ull)) == 0ull && !a.no_lean_extra, 0)) {
         const int kw1 = __builtin_amdgcn_readlane(wl, (int)__builtin_ctzll(tw)) & 15;
         unsigned a2 = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)avail, kw1);
         a2 &= a2 - 1u;
@@ -554,7 +554,7 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
 
   }
   bool list_sufficed = true;
-  if (!selected) {  // the full tiers own their layout values: nothing of them is live above
+  if (__builtin_expect(!selected, 0)) {  // the full tiers own their layout values: nothing of them is live above
   PDT_STAT(5);
   PDT_UTT(1, 1);
   // All 64 lanes hold candidates: lane = G * r + k carries, for prefix k, three of its
@@ -849,7 +849,64 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
   PDT_STAMP(10);
   unsigned isp_new = 0u;
   bool need_walk = false;
-  if (is_valid) {
+  bool pairs_done = false;
+#ifndef PDT_NO_PAIR_PREFIX
+#ifndef PDT_PAIR_DENSE
+#define PDT_PAIR_DENSE 8  // old entries a source is a prefix of, beyond which all pairs are evaluated
+#endif
+  // Dense relations (blank-dominated rows: short prefixes are prefixes of most of the beam) make the
+  // per-descendant loops below run 10-15 times a frame.  Then ALL pairs (a, b) are evaluated instead,
+  // four per lane -- lane = a + 16 q takes b = 4 r + q in round r -- with the same tests, the masks
+  // assembled from four ballots: ~140 instructions whatever the density (the loops: ~20 per
+  // descendant of the busiest lane).  Widths up to 16, trie histories.
+  if (__builtin_expect(TRIE && W <= 16 && !a.no_lean_extra && __ballot(is_valid && __popc(isp_s) > PDT_PAIR_DENSE) != 0ull, 0)) {
+    const int pa = lane & 15, pq = lane >> 4;
+    const u64 vmask = __ballot(is_valid);
+    const int a_tok = shfl_i(new_tok, pa);
+    const int a_w = shfl_i(len_s | (new_src << 20) | ((is_ext ? 1 : 0) << 28) | ((is_valid ? 1 : 0) << 29), pa);
+    const unsigned a_isp = (unsigned)shfl_i((int)isp_s, pa);
+    const int a_len_s = a_w & 0xFFFFF, a_src = (a_w >> 20) & 0xFF;
+    const bool a_ext = (a_w >> 28) & 1, a_valid = (a_w >> 29) & 1;
+    const int a_len = a_len_s + (a_ext ? 1 : 0);
+    unsigned bits = 0u, walks = 0u;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int b = 4 * r + pq;
+      const int tok_b = L.info[2 * b], w1 = L.info[2 * b + 1];  // (entries of invalid b are stale: vmask)
+      const int lenB = w1 & 0xFFFFF, src_b = (w1 >> 20) & 0xFF;
+      const bool ext_b = (w1 >> 28) & 1;
+      const int len_b = lenB + (ext_b ? 1 : 0);
+      bool pref = a_valid && ((vmask >> b) & 1ull) && b != pa && ((a_isp >> src_b) & 1u) && !(a_len > len_b);
+      int tok_at = -1;
+      if (pref) tok_at = lenB > a_len_s ? L.nxt_old[a_src * W + src_b] : (ext_b ? tok_b : -1);
+      pref = pref && !(a_ext && tok_at != a_tok);
+      bool walk = false;
+      if (pref && a_len < len_b) {  // strict prefix: the token that follows a inside b
+        int nx;
+        if (!a_ext) {
+          nx = tok_at;
+        } else if (lenB == a_len_s + 1) {
+          nx = tok_b;
+        } else {
+          nx = -(2 + b);
+          walk = true;
+        }
+        L.nxt_new[pa * W + b] = nx;
+      }
+      const u64 m = __ballot(pref), wm = __ballot(walk);
+      const unsigned lo = (unsigned)m >> pa, hi = (unsigned)(m >> 32) >> pa;
+      bits |= ((lo & 1u) | ((lo >> 15) & 2u) | ((hi & 1u) << 2) | ((hi >> 13) & 8u)) << (4 * r);
+      walks |= (unsigned)(wm | (wm >> 16) | (wm >> 32) | (wm >> 48));
+    }
+    if (is_valid) {  // (lanes 0 .. W - 1: pa is the lane itself)
+      isp_new = bits | (1u << lane);
+      need_walk = (walks >> lane) & 1u;
+    }
+    pairs_done = true;
+    wave_sync();
+  }
+#endif
+  if (is_valid && !pairs_done) {
     unsigned cand = 0u;
     for (unsigned m = isp_s; m; m &= m - 1u) cand |= L.chm[__builtin_ctz(m)];
     // (an entry is a prefix of itself and never its own strict prefix: one iteration less for every

@@ -292,14 +292,18 @@ def test_lean_tier_extras_match_the_full_tiers(device, switch):
     mid tier / exact re-ranking) -- with PDT_CTC_LEAN_EXTRA=0 by the full tiers.  Same bits on inputs
     built to hit both all the time: few distinct logit values (exact ties everywhere), duplicated
     logits (two tokens equal in a quarter of the rows -- the prefixes they start carry equal masses
-    from then on), values on a coarse grid (near ties); short rows (both instances) and register rows."""
+    from then on), values on a coarse grid (near ties), blank-dominated rows (dense is-prefix relations:
+    the pair-parallel update against the per-descendant loops); short rows (both instances) and register rows."""
     rng = np.random.default_rng(99)
-    for it in range(24):
+    for it in range(32):
         V = int(rng.choice([256, 256, 300, 1000, 40])); W = int(rng.choice([16, 16, 8, 32, 5]))
         T = int(rng.choice([40, 120, 300])); N = int(rng.integers(2, 24))
-        kind = it % 3
+        kind = it % 4
         lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
-        np.put_along_axis(lg, rng.integers(0, V + 1, (T, N, 1)), float(rng.choice([6.0, 9.0, 12.0])), 2)
+        peak = rng.integers(0, V + 1, (T, N, 1))
+        if kind == 3:  # blank-dominated rows: short prefixes, dense is-prefix relations (the pair-parallel update)
+            peak = np.where(rng.random((T, N, 1)) < 0.9, V, peak)
+        np.put_along_axis(lg, peak, float(rng.choice([6.0, 9.0, 12.0])), 2)
         if kind == 0:
             lg = np.round(lg * 2) / 2
         elif kind == 1:
