@@ -1,0 +1,42 @@
+"""Fuzz of the lean tier's side paths (mid tier, exact re-ranking, all-pairs prefix update) against the full
+tiers / per-descendant loops: the same search with PDT_CTC_LEAN_EXTRA = 1 and 0, torch.equal on all outputs.
+python profiles/tools/fuzz_tiers.py [seed] [cases]"""
+import sys, numpy as np, torch
+sys.path.insert(0, "."); sys.path.insert(0, "pydrobert-pytorch_amd")
+from pydrobert_amd import functional as F, switches
+dev = torch.device("cuda:0")
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+cases = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+rng = np.random.default_rng(seed)
+bad = 0
+for it in range(cases):
+    V = int(rng.choice([256, 256, 257, 300, 128, 64, 1000, 5000, 40])); W = int(rng.choice([16, 16, 16, 8, 12, 5, 2, 32]))
+    T = int(rng.choice([20, 64, 130, 300, 600])); N = int(rng.integers(1, 40))
+    if V >= 1000: N = min(N, 6); T = min(T, 130)
+    kind = it % 5
+    lg = rng.normal(size=(T, N, V + 1)).astype(np.float32) * float(rng.choice([0.3, 1.0, 2.0]))
+    peak = rng.integers(0, V + 1, (T, N, 1))
+    if kind == 3:
+        peak = np.where(rng.random((T, N, 1)) < float(rng.choice([0.8, 0.95])), V, peak)
+    np.put_along_axis(lg, peak, float(rng.choice([4.0, 8.0, 12.0])), 2)
+    if kind == 0:
+        lg = np.round(lg * 2) / 2
+    elif kind == 1:
+        for _ in range(T * N // 3):
+            t, n = rng.integers(0, T), rng.integers(0, N); a, b = rng.integers(0, V, 2)
+            lg[t, n, b] = lg[t, n, a]
+    elif kind == 2:
+        lg = np.round(lg * 1024) / 1024
+    elif kind == 4:
+        lg[:, :, rng.integers(0, V, max(1, V // 4))] = -np.inf
+    lens = torch.from_numpy(rng.integers(0, T + 1, N)).to(dev) if rng.random() < 0.5 else None
+    x = torch.from_numpy(lg).to(dev)
+    outs = []
+    for extra in (1, 0):
+        switches.set("PDT_CTC_LEAN_EXTRA", extra)
+        outs.append(F.ctc_prefix_search(x, W, lens))
+    if not all(torch.equal(p, q) for p, q in zip(*outs)):
+        bad += 1
+        print("MISMATCH case", it, "V", V, "W", W, "T", T, "N", N, "kind", kind, flush=True)
+switches.set("PDT_CTC_LEAN_EXTRA", 1)
+print("tier fuzz: %d cases, %d mismatches" % (cases, bad), flush=True)
