@@ -37,6 +37,11 @@ for it in range(cases):
         outs.append(F.ctc_prefix_search(x, W, lens))
     if not all(torch.equal(p, q) for p, q in zip(*outs)):
         bad += 1
-        print("MISMATCH case", it, "V", V, "W", W, "T", T, "N", N, "kind", kind, flush=True)
+        (y1, l1, p1), (y0, l0, p0) = outs
+        dn = ((l1 != l0) | (p1 != p0)).any(1).nonzero().flatten().tolist()
+        dy = (y1 != y0).any(0).any(1).nonzero().flatten().tolist()
+        n = (dn + dy)[0]
+        print("MISMATCH case", it, "V", V, "W", W, "T", T, "N", N, "kind", kind, "utterances", sorted(set(dn + dy))[:6],
+              "probs", p1[n].tolist(), p0[n].tolist(), "lens", l1[n].tolist(), l0[n].tolist(), flush=True)
 switches.set("PDT_CTC_LEAN_EXTRA", 1)
 print("tier fuzz: %d cases, %d mismatches" % (cases, bad), flush=True)

@@ -423,7 +423,10 @@ __device__ __forceinline__ bool ctc_frame(Beam &bm, const float *p, const float 
       const unsigned trank = rr < 2 ? (unsigned)kb * 128u + 2u * (unsigned)j + 1u
                                     : (rr == 2 ? (unsigned)kb * 128u + 2u * (unsigned)(jl_k >= 0 ? jl_k : 63) : (unsigned)(32 + kb) * 128u);
       const bool tie_prev = shfl_i((int)tie, lane - 1) != 0;  // this rank ties with the one before it
-      if (__ballot(tie && tie_prev) == 0ull) {
+      // (a pair at ranks K - 1 and K whose bucket goes on at rank K + 1 is a longer run: the K-th winner
+      // may be any of them)
+      const bool tie_on = lane <= K && (st >> 6) != 0u && (st >> 6) == (st_next >> 6);
+      if (__ballot(tie_on && tie_prev) == 0ull) {
         // runs of two (the usual case: a pair of prefixes with equal masses): the rounded sort has
         // everything else in order, so each pair is put in exact order by itself -- three crossbar
         // fetches and a compare instead of a 64-bit sort
