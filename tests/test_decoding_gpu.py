@@ -321,6 +321,23 @@ def test_lean_tier_extras_match_the_full_tiers(device, switch):
             outs.append(F.ctc_prefix_search(x, W, lens))
         for p, q in zip(*outs):
             assert torch.equal(p, q), (it, V, W, T, N, kind)
+    # narrow beams on few distinct values / masked rows: a tied pair at ranks (K - 1, K) whose bucket goes
+    # on at rank K + 1 (a fuzz of 1 500 cases found the pairwise fix wrong there; profiles/tools/fuzz_tiers.py)
+    for it in range(30):
+        V = int(rng.choice([40, 64, 256])); W = int(rng.choice([2, 3, 5])); T = int(rng.choice([64, 300])); N = 40
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        np.put_along_axis(lg, rng.integers(0, V + 1, (T, N, 1)), float(rng.choice([4.0, 8.0])), 2)
+        if it % 2 == 0:
+            lg = np.round(lg * 2) / 2
+        else:
+            lg[:, :, rng.integers(0, V, V // 4)] = -np.inf
+        x = torch.from_numpy(lg).to(device)
+        outs = []
+        for extra in (1, 0):
+            switch("PDT_CTC_LEAN_EXTRA", extra)
+            outs.append(F.ctc_prefix_search(x, W))
+        for p, q in zip(*outs):
+            assert torch.equal(p, q), ("narrow", it, V, W, T)
 
 
 def test_ctc_default_shape_with_many_frames(device):
