@@ -45,3 +45,38 @@ for it in range(cases):
               "probs", p1[n].tolist(), p0[n].tolist(), "lens", l1[n].tolist(), l0[n].tolist(), flush=True)
 switches.set("PDT_CTC_LEAN_EXTRA", 1)
 print("tier fuzz: %d cases, %d mismatches" % (cases, bad), flush=True)
+
+# ---- the same two settings through the searches with a bigram model (per-prefix lists: DENSE ctc_frame) ----
+sys.path.insert(0, "tests")
+from pydrobert_amd import modules as M
+from _lm_fixtures import random_dicts
+bad2 = n2 = 0
+for it in range(cases // 5):
+    V = int(rng.choice([9, 40, 150, 600])); W = int(rng.choice([2, 4, 8, 16, 16])); T = int(rng.choice([20, 80, 200])); N = int(rng.integers(1, 12))
+    if W > V + 1:
+        continue
+    sos = int(rng.choice([-1, 0, V - 1])); vm = bool(rng.integers(0, 2)); beta = float(rng.choice([0.1, 0.3, 0.7]))
+    dicts = random_dicts(rng, V, 2, 0.5 if V ** 2 < 3000 else (0.1 if V < 200 else 0.01), sos if sos < 0 else None)
+    for v in range(V):
+        dicts[0].setdefault(v, (float(rng.normal()), float(rng.normal())))
+    lm = M.LookupLanguageModel(V, sos, dicts, destructive=True).to(dev)
+    lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+    peak = rng.integers(0, V + 1, (T, N, 1))
+    if it % 2:
+        peak = np.where(rng.random((T, N, 1)) < 0.9, V, peak)
+    np.put_along_axis(lg, peak, float(rng.choice([4.0, 9.0])), 2)
+    if it % 3 == 0:
+        lg = np.round(lg * 2) / 2
+    x = torch.from_numpy(lg).to(dev)
+    search = M.CTCPrefixSearch(W, beta, lm, valid_mixture=vm)
+    outs = []
+    for extra in (1, 0):
+        switches.set("PDT_CTC_LEAN_EXTRA", extra)
+        with torch.no_grad():
+            outs.append(search(x))
+    n2 += 1
+    if not all(torch.equal(p, q) for p, q in zip(*outs)):
+        bad2 += 1
+        print("LM MISMATCH case", it, V, W, T, N, sos, vm, beta, flush=True)
+switches.set("PDT_CTC_LEAN_EXTRA", 1)
+print("tier fuzz with a bigram model: %d cases, %d mismatches" % (n2, bad2), flush=True)
