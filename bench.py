@@ -238,13 +238,36 @@ def roof(alg_bytes, ms, kernel, note=None):
     return r
 
 
+def summary_of(entry):
+    """The few numbers of one `other_configs` entry a reader needs: its times and roofline fraction(s)."""
+    s = {k: round(v, 4) for k, v in entry.items() if k.endswith("ms") and isinstance(v, float)}
+    for k, v in entry.items():
+        if k.endswith("roofline") and isinstance(v, dict) and "frac" in v:
+            s["frac" if k == "roofline" else k[:-len("roofline")] + "frac"] = round(v["frac"], 4)
+            if v.get("bound") == "mfma":
+                s["bound"] = "mfma"
+    return s
+
+
+class _Reported(dict):
+    """`other_configs`: a configuration is reported on stderr the moment it is recorded."""
+
+    def __init__(self, say):
+        super().__init__()
+        self._say = say
+
+    def __setitem__(self, name, entry):
+        super().__setitem__(name, entry)
+        self._say(name + " " + " ".join("{}={}".format(k, v) for k, v in summary_of(entry).items()))
+
+
 def search_bytes(T, N, V, K):
     """4 T (V + 1) of logits + 8 T K + 12 K of outputs per utterance."""
     return (4 * T * (V + 1) + 8 * T * K + 12 * K) * N
 
 
-def other_configs(F, M, device, world, rank, dist, gather_check):
-    out = {}
+def other_configs(F, M, device, world, rank, dist, gather_check, say=lambda msg: None):
+    out = _Reported(say)
     K = 16
     # C5 shard: N=4096 x T=512, V=5000 per GPU -- error_rate + fused CTC decode + the gathers
     T, N, V = 512, 4096, 5000
@@ -447,11 +470,11 @@ def make_gru_lm(M, V, hidden=256):
     return GruLM(V, hidden)
 
 
-def lm_configs(F, M, device, args, ref, hyp):
+def lm_configs(F, M, device, args, ref, hyp, say=lambda msg: None):
     """The runs SURVEY section 8(d) asks for besides the headline step: C2 with ragged lengths, the
     step with the reference's default warn=True, C3 with a language model in the loop (the shipped
     n-gram model; a GRU-cell model whose logit layer is the path's only GEMM), BeamSearch end to end."""
-    out = {}
+    out = _Reported(say)
     T, N, V = args.T, args.N, args.V
     # C2 ragged: eos = V written at len ~ U{T/2 .. T}
     g = torch.Generator(device=device).manual_seed(11)
@@ -795,10 +818,12 @@ def run_rank(args):
     say("timed region done: {:.3f} ms per step".format(dt / args.steps * 1e3))
     extra = None
     if not args.no_extra and have_decode:
-        extra = other_configs(F, M, device, world, rank, dist, gather_check)
+        # (one stderr line per configuration as it finishes, and `config_summary` as the LAST key of the
+        #  JSON line: whatever tail of either stream a driver keeps carries every BASELINE config)
+        extra = other_configs(F, M, device, world, rank, dist, gather_check, say)
         say("other configs done")
         if rank == 0:
-            extra.update(lm_configs(F, M, device, args, ref, hyp))
+            extra.update(lm_configs(F, M, device, args, ref, hyp, say))
             say("ragged / default-argument / language-model configs done")
 
     if rank == 0:
@@ -843,10 +868,14 @@ def run_rank(args):
             },
         }
         if extra is not None:
-            out["other_configs"] = extra
+            out["other_configs"] = dict(extra)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, have_decode, op_ms)
             say("cpu baseline done")
+        if extra is not None:  # LAST key on purpose (see above)
+            out["config_summary"] = {name: summary_of(entry) for name, entry in extra.items()}
+            out["config_summary"]["headline"] = {"ms_per_step": round(dt / args.steps * 1e3, 4), "frac": round(achieved / HBM_PEAK_GBS, 4),
+                                                 **{k + "_ms": round(v, 4) for k, v in op_ms.items()}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

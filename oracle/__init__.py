@@ -29,31 +29,45 @@ WARN_REF_NO_EOS, WARN_HYP_NO_EOS, WARN_EMPTY_REF = 1, 2, 4
 _lib = None
 
 
-def build(force: bool = False) -> str:
-    """Compile the C restatement with gcc (no reference sources involved)."""
+_SAN_LIB_PATH = os.path.join(_BUILD, "libpdt_oracle_san.so")
+
+
+def build(force: bool = False, sanitize: bool = False) -> str:
+    """Compile the C restatement with gcc (no reference sources involved).
+
+    ``sanitize``: the AddressSanitizer + UndefinedBehaviorSanitizer build (CPU only; a process that
+    loads it must have been started with ``LD_PRELOAD=$(gcc -print-file-name=libasan.so)``:
+    ``tests/test_oracle_sanitizers.py`` does that around ``tests/fuzz/oracle_sweep.py``)."""
+    out = _SAN_LIB_PATH if sanitize else _LIB_PATH
     srcs = [os.path.join(_HERE, s) for s in _SOURCES if os.path.exists(os.path.join(_HERE, s))]
     deps = srcs + [os.path.join(_HERE, "pdt_oracle.h")]
     if (
         not force
-        and os.path.exists(_LIB_PATH)
-        and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(d) for d in deps)
+        and os.path.exists(out)
+        and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps)
     ):
-        return _LIB_PATH
+        return out
     os.makedirs(_BUILD, exist_ok=True)
+    flags = ["-O2"]
+    if sanitize:
+        flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                 "-fno-sanitize-recover=all"]  # fmt: skip
     cmd = (
-        ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
-        + ["-Wall", "-Wextra", "-o", _LIB_PATH]
+        ["gcc"] + flags + ["-std=c11", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math"]
+        + ["-Wall", "-Wextra", "-o", out]
         + srcs
         + ["-lm"]
     )
     subprocess.run(cmd, check=True)
-    return _LIB_PATH
+    return out
 
 
 def lib() -> ctypes.CDLL:
     global _lib
     if _lib is None:
-        _lib = ctypes.CDLL(build())
+        # PDT_ORACLE_SANITIZE=1: the sanitizer build (see build()); a test switch of the CHECKER,
+        # read where the checker is loaded -- the product never comes here
+        _lib = ctypes.CDLL(build(sanitize=os.environ.get("PDT_ORACLE_SANITIZE", "") == "1"))
         _declare(_lib)
     return _lib
 
@@ -151,6 +165,9 @@ def string_matching(
     elif mode == MODE_PREFIX:
         out = np.empty((Hout, N), np.float32)
     else:
+        # the initial row mask is appended BEFORE the loop (_string.py:271-278), so there is one row
+        # even for H == 0 with exclude_last
+        Hout = max(1, Hout)
         mask = np.zeros((Hout, R, N), np.uint8)
     rl, hl = np.empty((N,), np.int64), np.empty((N,), np.int64)
     flags = ctypes.c_int(0)
@@ -162,6 +179,8 @@ def string_matching(
         _ptr(out, _f32p), _ptr(mask, _u8p), _ptr(rl, _i64p), _ptr(hl, _i64p),
         ctypes.byref(flags),
     )  # fmt: skip
+    if rc == -2:  # row 0 of an empty mask / prefix buffer (_string.py:275, :285)
+        raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
     if rc != 0:
         raise RuntimeError("oracle string_matching failed: {}".format(rc))
     if mode == MODE_MASK:

@@ -22,6 +22,9 @@ extern "C" {
 #define PDT_WARN_HYP_NO_EOS 2 /* _string.py:211-217 */
 #define PDT_WARN_EMPTY_REF 4  /* _string.py:361-367, :398-404 */
 
+/* return codes: 0 ok, -1 invalid argument, -2 the reference raises IndexError on this shape */
+#define PDT_ORACLE_E_INDEX (-2)
+
 void pdt_oracle_lens_from_eos(const int64_t *tok, int64_t T, int64_t N, int64_t st,
                               int64_t sn, int64_t eos, int64_t *lens);
 

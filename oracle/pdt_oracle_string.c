@@ -72,6 +72,15 @@ int pdt_oracle_string_matching(const int64_t *ref, int64_t R, int64_t ref_st,
   if (mode != PDT_MODE_FINAL && mode != PDT_MODE_PREFIX && mode != PDT_MODE_MASK)
     return -1;
   if (exclude_last && mode == PDT_MODE_FINAL) return -1; /* :165 */
+  /* The loop bound of :286 and the number of OUTPUT rows are different things in mask mode:
+   * the initial row mask is appended before the loop (:271-278), so a mask has max(1, Hloop)
+   * rows -- one row even for H == 0 with exclude_last.  The reference indexes row 0 of a
+   * (R, N) mask (:275) resp. of a (Hloop, N) prefix buffer (:285): IndexError when that
+   * dimension is empty.  PDT_ORACLE_E_INDEX tells the caller to raise it; nothing is written. */
+  const int64_t Hloop = H + (exclude_last ? 0 : 1); /* :281, :286 */
+  const int64_t Hout = (mode == PDT_MODE_MASK && Hloop < 1) ? 1 : Hloop;
+  if (mode == PDT_MODE_MASK && R == 0) return PDT_ORACLE_E_INDEX;
+  if (mode == PDT_MODE_PREFIX && Hloop == 0) return PDT_ORACLE_E_INDEX;
   int flags = 0;
   float mult = 1.0f;
   /* :168-174 uniform-cost shortcut */
@@ -96,7 +105,6 @@ int pdt_oracle_string_matching(const int64_t *ref, int64_t R, int64_t ref_st,
     flags |= PDT_WARN_HYP_NO_EOS;
 
   const int64_t R1 = R + 1;
-  const int64_t Hout = H + (exclude_last ? 0 : 1); /* :281, :286 */
   float *row0 = (float *)malloc(sizeof(float) * (size_t)R1);
   float *row = (float *)malloc(sizeof(float) * (size_t)R1);
   float *last = (float *)malloc(sizeof(float) * (size_t)R1);
@@ -113,12 +121,12 @@ int pdt_oracle_string_matching(const int64_t *ref, int64_t R, int64_t ref_st,
       mis[r] = (float)r; /* :260 */
     }
     if (mode == PDT_MODE_MASK) { /* :271-278 */
-      for (int64_t r = 0; r < R; ++r) mask_out[(0 * R + r) * N + n] = 0;
-      if (R > 0 && Hout > 0) mask_out[(0 * R + 0) * N + n] = ref_len > 0;
-    } else if (mode == PDT_MODE_PREFIX && Hout > 0) { /* :285 */
+      for (int64_t r = 0; r < R; ++r) mask_out[(0 * R + r) * N + n] = 0; /* Hout >= 1, R >= 1 */
+      mask_out[(0 * R + 0) * N + n] = ref_len > 0;
+    } else if (mode == PDT_MODE_PREFIX) { /* :285 */
       out[0 * N + n] = (float)ref_len * (return_mistakes ? 1.0f : del_cost);
     }
-    for (int64_t h = 1; h < Hout; ++h) { /* :286 */
+    for (int64_t h = 1; h < Hloop; ++h) { /* :286 */
       const int not_done = (h - (exclude_last ? 0 : 1)) < hyp_len; /* :288 */
       const float ins_mask = hyp_len >= h ? 1.0f : 0.0f;            /* :290 */
       const int64_t hy = hyp[(h - 1) * hyp_st + n * hyp_sn];

@@ -128,6 +128,11 @@ struct DenseCtx {
 // before the is-prefix update writes it) can double as the 64 x u64 scratch of the candidate
 // selection
 __host__ __device__ inline int nxt_stride(int W) { return W * W < 128 ? 128 : W * W; }
+// bytes of a consumer wave's LDS scratch (two `nxt` tables, chm, info, ...: 3 ints per prefix), rounded
+// to 8: what follows it is read and written as 64-bit words (odd widths would leave it 4-byte aligned)
+__host__ __device__ inline int consumer_scratch_bytes(int W) {
+  return (2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3 + 7) & ~7;
+}
 
 // Per-wave LDS scratch of one frame.
 struct FrameLds {

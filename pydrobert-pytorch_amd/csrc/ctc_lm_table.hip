@@ -86,7 +86,7 @@ __host__ __device__ inline LmTabLayout lmtab_layout(int V, int W, int contexts) 
   l.row_floats = (V + 1 + 3) & ~3;
   l.rows_bytes = l.row_floats * 4 * kLmTabRows;
   const int lists = W * PDT_WAVE * 8, small = lmtab_small_ints(W) * 4;  // (small: etab, lpos, ctx_tok, list_id, lastc)
-  const int consumer = 2 * nxt_stride(W) * 4 + W * 4 * 3;
+  const int consumer = consumer_scratch_bytes(W);
   l.utt_bytes = (l.rows_bytes + lists + small + consumer + kLmTabWaves * PDT_SURV_CAP * 8 + 64 + l.fmax_floats * 4 + 15) & ~15;  // (64: flags, row_p1)
   return l;
 }
@@ -111,7 +111,7 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   int *list_id = ctx_tok + W;                                         // [W] the list of every prefix
   int *lastc_pub = list_id + W;                                       // [W] clamped last token of every prefix
   unsigned char *cs = reinterpret_cast<unsigned char *>(etab) + lmtab_small_ints(W) * 4;  // consumer scratch (16-byte aligned)
-  u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
+  u64 *surv0 = reinterpret_cast<u64 *>(cs + consumer_scratch_bytes(W));
   int *flags = reinterpret_cast<int *>(surv0 + kLmTabWaves * PDT_SURV_CAP);
   int *row_ready = flags;      // [3] frame + 1 held by a ring slot
   int *ctx_pub = flags + 3;    // frames whose contexts are published

@@ -114,7 +114,7 @@ __host__ __device__ inline RingLayout ring_layout(int V, int W, int nstage, int 
   // output walk)
   r.slot_bytes = row_global ? 8192 : r.row_floats * 4 + PDT_WAVE * 8 + r.pos_bytes + 16;
   r.nstage = nstage;
-  const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
+  const int consumer = consumer_scratch_bytes(W);  // nxt tables + chm + info
   r.utt_bytes = (r.slot_bytes * nstage + consumer + producers * PDT_SURV_CAP * 8 + 32 + 15) & ~15;
   r.utt_per_wg = utt_per_wg;
   r.producers = producers;

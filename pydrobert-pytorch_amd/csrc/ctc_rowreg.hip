@@ -42,7 +42,7 @@ __host__ __device__ inline RowregLayout rowreg_layout(int V, int W, int nstage, 
   r.nstage = nstage;
   r.slot_bytes = PDT_WAVE * 8 + 32;
   r.pos_bytes = (V + 15) & ~15;
-  const int consumer = 2 * nxt_stride(W) * 4 + (W > 0 ? W : 1) * 4 * 3;  // nxt tables + chm + info
+  const int consumer = consumer_scratch_bytes(W);  // nxt tables + chm + info
   r.utt_bytes = (r.slot_bytes * nstage + r.pos_bytes + consumer + producers * PDT_SURV_CAP * 8 + 32 + 15) & ~15;
   r.utt_per_wg = utt_per_wg;
   r.producers = producers;
@@ -78,7 +78,7 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   unsigned char *ring = ub;
   unsigned char *pos = ub + (size_t)rl.slot_bytes * NS;
   unsigned char *cs = pos + rl.pos_bytes;  // consumer scratch
-  u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
+  u64 *surv0 = reinterpret_cast<u64 *>(cs + consumer_scratch_bytes(W));
   int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
   int *ready = consumed + 1;                                          // [nstage <= 4] frame + 1 held by a slot
   auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(ring + (size_t)sl * rl.slot_bytes); };

@@ -85,7 +85,7 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   unsigned char *ub = smem + (size_t)u * rl.utt_bytes;
   unsigned char *ring = ub;
   unsigned char *cs = ub + (size_t)rl.slot_bytes * rl.nstage;      // consumer scratch
-  u64 *surv0 = reinterpret_cast<u64 *>(cs + (2 * nxt_stride(W) * 4 + W * 4 * 3));
+  u64 *surv0 = reinterpret_cast<u64 *>(cs + consumer_scratch_bytes(W));
   const int pr = (P == 1 || !producer) ? 0 : role;                   // producer index
   u64 *surv = surv0 + pr * PDT_SURV_CAP;                             // one scratch per producer
   unsigned *surv32 = reinterpret_cast<unsigned *>(surv);             // (short lists: 32-bit sort keys)

@@ -967,13 +967,15 @@ __global__ void __launch_bounds__(256) sparse_warp_bands_kernel(const WarpArgs a
     } else {
 #pragma unroll
       for (int j = 0; j < ROWS; ++j) {  // all the taps in flight
-        const int o00 = (int)__builtin_fmaf(y0f[j], wf, x0f[j]) << 2;
-        const int right = x0f[j] < wm1 ? 4 : 0x40000000, down = y0f[j] < hm1 ? 4 * W : 0x40000000;
-        const int o10 = o00 + down;
-        t00[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o00, 0, 0);
-        t01[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o00 + right, 0, 0);
-        t10[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o10, 0, 0);
-        t11[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, o10 + right, 0, 0);
+        // (unsigned: with both neighbours outside the two out-of-buffer steps add up to 2^31, which
+        //  wraps by definition and is still beyond num_records -- the load returns 0)
+        const unsigned o00 = (unsigned)(int)__builtin_fmaf(y0f[j], wf, x0f[j]) << 2;
+        const unsigned right = x0f[j] < wm1 ? 4u : 0x40000000u, down = y0f[j] < hm1 ? 4u * (unsigned)W : 0x40000000u;
+        const unsigned o10 = o00 + down;
+        t00[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o00, 0, 0);
+        t01[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o00 + right), 0, 0);
+        t10[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)o10, 0, 0);
+        t11[j] = __builtin_amdgcn_raw_buffer_load_b32(rs, (int)(o10 + right), 0, 0);
       }
     }
     float *po = a.out + (n * a.C + c) * (int64_t)HW;
@@ -1164,7 +1166,7 @@ int pdt_spec_augment_draw(const float *u, int64_t N, int64_t R, const int64_t *l
   a.MT = a.time_mask ? (int)num_time_mask : 0;
   a.MF = a.freq_mask ? (int)num_freq_mask : 0;
   if (R < 2 * a.time_warp + 2 * a.freq_warp + 2 * a.MT + 2 * a.MF) return PDT_E_ARG;
-  if (N == 0) return PDT_OK;
+  if (N == 0 || (!a.time_warp && !a.freq_warp && !a.time_mask && !a.freq_mask)) return PDT_OK;  // nothing to draw
   if (!u || (a.time_warp && (!w_0 || !w)) || (a.freq_warp && (!v_0 || !v)) || (a.time_mask && (!t_0 || !t)) ||
       (a.freq_mask && (!f_0 || !f)))
     return PDT_E_ARG;

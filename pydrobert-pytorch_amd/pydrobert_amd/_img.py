@@ -769,13 +769,22 @@ def spec_augment_draw_parameters(
     tm = max_time_mask != 0 and max_time_mask_proportion != 0.0 and num_time_mask != 0 and num_time_mask_proportion != 0.0
     fm = max_freq_mask != 0 and num_freq_mask != 0
     R = 2 * int(tw) + 2 * int(fw) + (2 * num_time_mask if tm else 0) + (2 * num_freq_mask if fm else 0)
+    none = torch.empty(0)  # a disabled group: the reference's ``torch.empty(0)`` pair (_img.py:1093-1139)
+    if R == 0 or N == 0:  # nothing is drawn: no kernel (and no device) is needed
+        if N == 0 and R > 0:
+            z, zl = feats.new_empty((0,), dtype=torch.float), feats.new_empty((0, 0), dtype=torch.long)
+            return (z if tw else none, z if tw else none, z if fw else none, z if fw else none,
+                    zl.new_empty((0, num_time_mask)) if tm else none, zl.new_empty((0, num_time_mask)) if tm else none,
+                    zl.new_empty((0, num_freq_mask)) if fm else none, zl.new_empty((0, num_freq_mask)) if fm else none)  # fmt: skip
+        return none, none, none, none, none, none, none, none
     uniforms = torch.rand((N, R), device=device)
     lens = None if lengths is None else lengths.to(device)
     out = torch.ops.pydrobert_amd.spec_augment_draw(
         uniforms, lens, T, F, max_time_warp, max_freq_warp, max_time_mask, max_freq_mask, max_time_mask_proportion,
         num_time_mask, num_time_mask_proportion, num_freq_mask, feats.dtype == torch.double,
     )  # fmt: skip
-    return out[0], out[1], out[2], out[3], out[4], out[5], out[6], out[7]
+    return (out[0] if tw else none, out[1] if tw else none, out[2] if fw else none, out[3] if fw else none,
+            out[4] if tm else none, out[5] if tm else none, out[6] if fm else none, out[7] if fm else none)  # fmt: skip
 
 
 def _has(a: Optional[torch.Tensor], b: Optional[torch.Tensor]) -> bool:

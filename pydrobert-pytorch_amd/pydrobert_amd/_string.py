@@ -247,8 +247,8 @@ def _string_matching_op(
         )
     if return_prf_dsts:
         Hout = H + (0 if exclude_last else 1)
-        if Hout == 0:
-            raise RuntimeError("hyp has no steps to compute prefixes of")
+        if Hout == 0:  # the reference writes row 0 of a (0, N) buffer (_string.py:280-285)
+            raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
         out = torch.empty((Hout, N), device=device, dtype=torch.float)
         out_sh, out_sn = out.stride(0), out.stride(1)
         mode = _cabi.MODE_PREFIX
@@ -427,7 +427,7 @@ def _optimal_completion_op(
     maximum set size ``C``; the expansion writes the ``(H', N, C)`` int64 targets."""
     device, bitmask, class_tokens, scal, (R, Hout, N) = _oc_mask(
         ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, exclude_last, warn,
-        "pdt_oc_mask",
+        "pdt_oc_mask", initial_row_always=True,
     )  # fmt: skip
     L = _cabi.lib()
     with torch.cuda.device(device):
@@ -451,7 +451,7 @@ def _optimal_completion_op(
 def _(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, padding,
       exclude_last, warn):  # fmt: skip
     N = ref.shape[0] if batch_first else ref.shape[1]
-    Hout = (hyp.shape[1] if batch_first else hyp.shape[0]) + (0 if exclude_last else 1)
+    Hout = max(1, (hyp.shape[1] if batch_first else hyp.shape[0]) + (0 if exclude_last else 1))
     C = torch.library.get_ctx().new_dynamic_size()  # the data-dependent set size (:511)
     out = ref.new_empty((Hout, N, C), dtype=torch.long)
     return out.transpose(0, 1) if batch_first else out
@@ -478,9 +478,20 @@ def optimal_completion(
 
 
 def _oc_mask(ref, hyp, eos, include_eos, batch_first, ins_cost, del_cost, sub_cost, exclude_last,
-             warn, what):
-    """Phase 1 of optimal completion: (bitmask (H', N, W), class_tokens (N, R), scal, sizes)."""
+             warn, what, initial_row_always=False):
+    """Phase 1 of optimal completion: (bitmask (H', N, W), class_tokens (N, R), scal, sizes).
+
+    The reference appends the initial row mask BEFORE its loop (_string.py:271-278, :286), so the mask
+    of an EMPTY hypothesis has one row whether or not ``exclude_last`` is set: with
+    ``initial_row_always`` (optimal_completion itself) ``H == 0, exclude_last=True`` is computed as
+    ``H == 0, exclude_last=False`` -- the same single row ``{ref[0]}``.  The loss (`ocd_loss_rows`)
+    pairs every row with a row of logits and has none to pair it with (the reference fails in
+    ``view_as``, _string.py:1238), so it keeps the error."""
     device, ref, hyp, (R, rst, rsn), (H, hst, hsn), N = _prep(ref, hyp, batch_first)
+    if R == 0:  # the reference sets row 0 of a (0, N) mask (_string.py:275)
+        raise IndexError("index 0 is out of bounds for dimension 0 with size 0")
+    if H == 0 and exclude_last and initial_row_always:
+        exclude_last = False
     Hout = H + (0 if exclude_last else 1)
     if Hout == 0:
         raise RuntimeError("hyp has no steps to compute prefixes of")

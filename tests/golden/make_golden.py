@@ -87,6 +87,58 @@ def string_goldens():
     save("string_s2", **d)
 
 
+def string_edge_goldens():
+    """Degenerate shapes of the string operators (round 5): an EMPTY hypothesis / reference, a batch of
+    one.  The reference's optimal_completion appends the initial row mask before its loop
+    (_string.py:271-278, :286), so ``H == 0, exclude_last=True`` returns ONE row; shapes on which it
+    raises are recorded as the exception's class name (``err_*``)."""
+    d = {}
+    shapes = [(3, 0, 2), (5, 0, 1), (0, 3, 2), (0, 0, 2), (1, 1, 1), (3, 3, 1), (4, 2, 1), (2, 5, 3), (1, 0, 4)]
+    d["shapes"] = np.array(shapes)
+    ops = dict(
+        oc=lambda r, h, ex, bf: F.optimal_completion(r, h, exclude_last=ex, batch_first=bf, warn=False),
+        per=lambda r, h, ex, bf: F.prefix_error_rates(r, h, exclude_last=ex, batch_first=bf, warn=False),
+        ped=lambda r, h, ex, bf: F.prefix_edit_distances(r, h, exclude_last=ex, batch_first=bf, ins_cost=2.0,
+                                                         del_cost=0.5, sub_cost=1.0, warn=False),
+    )
+    finals = dict(
+        er=lambda r, h, bf: F.error_rate(r, h, batch_first=bf, warn=False),
+        ed=lambda r, h, bf: F.edit_distance(r, h, batch_first=bf, warn=False),
+    )
+    for i, (R, H, N) in enumerate(shapes):
+        ref = (torch.arange(R * N).view(R, N) * 7 + 1) % 4 + 1
+        hyp = (torch.arange(H * N).view(H, N) * 5 + 2) % 3 + 1
+        d["ref_{}".format(i)], d["hyp_{}".format(i)] = ref, hyp
+        for bf in (False, True):
+            a, b = (ref.t().contiguous(), hyp.t().contiguous()) if bf else (ref, hyp)
+            for name, fn in ops.items():
+                for ex in (False, True):
+                    tag = "{}_{}_x{}_b{}".format(name, i, int(ex), int(bf))
+                    try:
+                        d[tag] = fn(a, b, ex, bf)
+                    except Exception as e:  # noqa: BLE001 -- the class is the datum
+                        d["err_" + tag] = np.array(type(e).__name__)
+            for name, fn in finals.items():
+                tag = "{}_{}_b{}".format(name, i, int(bf))
+                try:
+                    d[tag] = fn(a, b, bf)
+                except Exception as e:  # noqa: BLE001
+                    d["err_" + tag] = np.array(type(e).__name__)
+    # one utterance with an eos: lengths 0 and full among the cases
+    rng = np.random.default_rng(0x5EED0051)
+    for j, (R, H) in enumerate([(6, 4), (1, 7), (7, 1)]):
+        ref = torch.from_numpy(rng.integers(0, 3, (R, 1)))
+        hyp = torch.from_numpy(rng.integers(0, 3, (H, 1)))
+        d["eref_{}".format(j)], d["ehyp_{}".format(j)] = ref, hyp
+        for inc in (False, True):
+            for ex in (False, True):
+                tag = "{}_i{}_x{}".format(j, int(inc), int(ex))
+                kw = dict(eos=0, include_eos=inc, exclude_last=ex, warn=False)
+                d["eoc_" + tag] = F.optimal_completion(ref, hyp, **kw)
+                d["eper_" + tag] = F.prefix_error_rates(ref, hyp, **kw)
+    save("string_edge", **d)
+
+
 def sclite_golden():
     from pydrobert.torch._parsing import read_trn
 
@@ -786,3 +838,7 @@ def image_f64_goldens():
 
 if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "image_f64"):
     image_f64_goldens()
+
+
+if __name__ == "__main__" and os.environ.get("PDT_GOLDEN_ONLY", "") in ("", "string_edge"):
+    string_edge_goldens()

@@ -13,6 +13,7 @@ import numpy as np
 import pytest
 import torch
 
+import _drift
 import oracle
 from pydrobert_amd import functional as F
 
@@ -51,17 +52,16 @@ def _oracle_search(lg, K, lens=None):
     return y, np.concatenate([p[1] for p in parts]), np.concatenate([p[2] for p in parts])
 
 
-def _check_search_sample(y, yl, yp, exp):
+def _check_search_sample(y, yl, yp, exp, config):
     """Tokens and lengths exact.  A prefix probability at these sizes is a product over 500-1000
     frames, every factor within an ulp or two of the reference's (reciprocal of the normaliser,
-    exp), so the products drift apart by up to ~2e-5 relative; the north star states the
-    tolerance on LOG-probabilities, where that is 2e-5 absolute on values of magnitude 20-90:
-    |log p - log p_ref| <= 1e-5 * max(1, |log p_ref|)."""
+    exp); the north star states the tolerance on LOG-probabilities: asserted as an ABSOLUTE bound
+    (``_drift.LOG_ATOL`` = 3e-5 on values of magnitude 20-90, i.e. < 1e-6 relative), and the measured
+    maximum of every configuration is recorded (tests/_drift.py -> profiles/r05_logprob_drift.json)."""
     ey, eyl, eyp = exp
     assert np.array_equal(yl, eyl), np.argwhere(yl != eyl)[:5]
     assert np.array_equal(y[: ey.shape[0]], ey), np.argwhere(y[: ey.shape[0]] != ey)[:5]
-    la, le = np.log(yp.astype(np.float64)), np.log(eyp.astype(np.float64))
-    assert (np.abs(la - le) <= RTOL * np.maximum(1.0, np.abs(le))).all(), np.abs(la - le).max()
+    _drift.check_log_probs(yp, eyp, config)
 
 
 def _check_search_properties(y, yl, yp, T, V, lens=None):
@@ -131,7 +131,7 @@ def test_c3_ctc_prefix_search(device):
     _check_search_properties(y, yl, yp, T, V)
     idx = torch.arange(0, N, N // 16)
     exp = _oracle_search(lg[:, idx].cpu().numpy(), K)
-    _check_search_sample(y[:, idx].cpu().numpy(), yl[idx].cpu().numpy(), yp[idx].cpu().numpy(), exp)
+    _check_search_sample(y[:, idx].cpu().numpy(), yl[idx].cpu().numpy(), yp[idx].cpu().numpy(), exp, "C3_search T=1000 V=1000 K=16 (16 utterances)")
     # ragged lengths: the same logits, every utterance cut somewhere
     g = torch.Generator(device=device).manual_seed(5)
     lens = torch.randint(T // 2, T + 1, (N,), device=device, generator=g)
@@ -146,7 +146,7 @@ def test_c3_ctc_prefix_search(device):
     assert bool((yl2[1] == 0).all()) and float(yp2[1, 0]) == 1.0 and bool(torch.isinf(yp2[1, 1:]).all())
     idx = torch.arange(2, N, N // 8)
     exp = _oracle_search(lg[:, idx].cpu().numpy(), K, lens[idx].cpu().numpy())
-    _check_search_sample(y2[:, idx].cpu().numpy(), yl2[idx].cpu().numpy(), yp2[idx].cpu().numpy(), exp)
+    _check_search_sample(y2[:, idx].cpu().numpy(), yl2[idx].cpu().numpy(), yp2[idx].cpu().numpy(), exp, "C3_search ragged lens (8 utterances)")
 
 
 def _cmp_ctc_step(act, exp, what):
@@ -255,8 +255,8 @@ def test_c3_searches_with_the_bigram_model_in_the_loop(device, switch):
             tmask = torch.arange(ty.shape[0], device=device).view(-1, 1, 1) < tyl.unsqueeze(0)
             same = (tyl == yl).all(1) & (torch.where(tmask, ty, 0) == torch.where(mask, y, 0)).all(0).all(1)
             assert int((~same).sum()) <= 8, (vm, int((~same).sum()))
-            la, lb = typ[same].double().log(), yp[same].double().log()
-            assert bool(((la - lb).abs() <= RTOL * lb.abs().clamp(min=1.0)).all()), (vm, float((la - lb).abs().max()))
+            _drift.check_log_probs(typ[same].cpu().numpy(), yp[same].cpu().numpy(),
+                                   "C3 + bigram LM, table route vs step route, valid_mixture={} (all 1024 utterances)".format(vm))
             # where the beams differ they hold near-tied masses: the sorted masses still agree
             sa, sb = typ[~same].sort(1)[0].double().log(), yp[~same].sort(1)[0].double().log()
             assert bool(((sa - sb).abs() <= 1e-4 * sb.abs().clamp(min=1.0)).all()), vm
@@ -382,7 +382,7 @@ def test_c5_shard(device):
     _check_search_properties(y, yl, yp, T, V)
     idx = torch.arange(0, N, N // 64)
     exp = _oracle_search(lg[:, idx].cpu().numpy(), K)
-    _check_search_sample(y[:, idx].cpu().numpy(), yl[idx].cpu().numpy(), yp[idx].cpu().numpy(), exp)
+    _check_search_sample(y[:, idx].cpu().numpy(), yl[idx].cpu().numpy(), yp[idx].cpu().numpy(), exp, "C5_shard decode T=512 V=5000 K=16 (64 utterances)")
     # the shard is independent of its neighbours: decoding half of it gives the same beams
     y2, yl2, yp2 = F.ctc_prefix_search(lg[:, : N // 2], K)
     assert torch.equal(y2, y[:, : N // 2]) and torch.equal(yl2, yl[: N // 2]) and torch.equal(yp2, yp[: N // 2])

@@ -56,6 +56,21 @@ def test_string_goldens_bit_exact(device):
                 assert np.array_equal(a.cpu().numpy(), g["oc_" + tag + "_x{}".format(ex)])
 
 
+def test_string_edge_shapes_like_the_live_reference(device):
+    """Empty hypothesis / reference, one utterance: what the live reference returns or raises
+    (``string_edge.npz``; ``optimal_completion`` of an empty hypothesis is ONE row, with and without
+    ``exclude_last``, _string.py:271-278, :286)."""
+    import _string_edge
+
+    class impl:
+        pass
+
+    for name in ("optimal_completion", "prefix_error_rates", "prefix_edit_distances", "error_rate", "edit_distance"):
+        setattr(impl, name, staticmethod(lambda *a, _f=getattr(F, name), **k: _f(*a, warn=False, **k)))
+    n = _string_edge.replay(impl, lambda a: T(a, device), lambda t: t.cpu().numpy())
+    assert n > 150
+
+
 def test_sclite_known_answer(device):
     g = load("sclite")
     errs = F.error_rate(T(g["ref"], device), T(g["hyp"], device), eos=-1, norm=False,
