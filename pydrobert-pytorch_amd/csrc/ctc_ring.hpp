@@ -88,6 +88,37 @@ __device__ __forceinline__ f32x2 exp_tame2(const f32x2 x) {
                __uint_as_float(__float_as_uint(y1) + (__float_as_uint(tm.y) << 23))};
 }
 
+// Reductions over each 32-lane HALF of a wave (the two-frames-per-pass producer of ctc_search.hip).
+// Maximum of floats that are not NaN, left in EVERY lane of the half: rotations inside the 16-lane rows
+// (max is idempotent: after ror 1, 2, 4, 8 every lane holds its row's maximum), then the two rows of a
+// half are exchanged by v_permlane16_swap (first result: rows 0, 0, 2, 2; second: rows 1, 1, 3, 3).
+__device__ __forceinline__ float half_max_all_f(float x) {
+  float v = x;
+  asm volatile(
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\tv_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// Sum over a half, left in ITS LAST lane (31 / 63): wave_sum_f's DPP steps without the last one, so the
+// two 16-lane row totals R0, R1 of a half come out as R0 + R1 in exactly that routine's association.
+__device__ __forceinline__ float half_sum_at31(float x) {
+  float v = x;
+  asm volatile(
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+      "s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+      "s_nop 1"
+      : "+v"(v));
+  return v;
+}
+
 // LDS ring slot shared by the producer and consumer waves of one utterance.
 struct RingLayout {
   int row_floats;   // V + 1 padded to 4

@@ -56,7 +56,10 @@ namespace pdt {
 // WC > 0: the beam width as a compile-time constant (a.W must equal it): the tier choices, list
 // lengths and table strides that depend on it fold away -- scalar work and scalar registers the
 // register-resident form has none to spare of (instantiated for the default width 16).
-template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false, int WC = -1, int VC = -1>
+// PAIR (the constant-shape instance, V = 256, W = 16): the producer takes TWO frames per pass, frame t in
+// lanes 0-31 and frame t + 1 in lanes 32-63 (32 lanes x 8 chunks + the blank): reductions, the 32-key
+// sort, the list and the header are paid once per pair of rows -- see the producer below.
+template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false, int WC = -1, int VC = -1, bool PAIR = false>
 __global__ void __launch_bounds__(256, INREG ? 8 : 4)
 ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   static_assert(!INREG || P == 1, "the register-resident row pass is a one-producer form");
@@ -129,6 +132,154 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
   if (idle) return;
 
   if (producer) {
+    if constexpr (PAIR) {
+      // ---- two frames per pass ---------------------------------------------------------------------
+      // Lane h = lane & 31 of a half holds the tokens h + 32 i, i = 0 .. 7, of ITS frame (lanes 0-31:
+      // frame t, lanes 32-63: frame t + 1; past the last frame the upper half repeats it into a slot
+      // nobody reads), lane h = 0 the blank as well.  Same bits as the one-frame form: the numerators
+      // are element-wise, and the normaliser is summed in that form's association -- its lane l
+      // accumulates the tokens l + 64 j, so a lane here keeps TWO partial sums (even chunks = its lane
+      // h, odd chunks = its lane h + 32), both go through the same DPP row steps, and the four row
+      // totals are combined as (R0 + R1) + (R2 + R3) like wave_sum_f's last two steps.
+      // Survivors of the guessed threshold are appended through an LDS cursor per half (ds_add_rtn: a
+      // unique slot per lane, no ballot / mbcnt arithmetic; their order does not matter, they are
+      // sorted), and a half whose count misses the window takes the complete selection of the
+      // one-frame form on its row in LDS, the whole wave working on it.
+      static_assert(!PAIR || (P == 1 && INREG && !GROW && WC == 16 && VC == 256 && NT == 4), "two frames per pass: V = 256, W = 16");
+      constexpr int kM = 32;  // ctc_list_len(256, 16, 16)
+      constexpr int kShortMin = PDT_SHORT_MIN, kShortMax = 32, kShortLo = PDT_SHORT_LO, kShortHi = PDT_SHORT_HI, kProbeRank = PDT_SHORT_PROBE;
+      constexpr u64 kFirstLanes = 0x0000000100000001ull;  // lane 0 of each half
+      int lp = lane;
+      asm volatile("" : "+v"(lp));
+      const int hl = lp & 31, half = lp >> 5;
+      const int row_bytes = rl.row_floats * 4;
+      unsigned char *const my_ring = ring + half * rl.slot_bytes;  // slot sl + half of the pass
+      int *cnt = want_full + 1;  // [2] cursors into the survivor buffers, as byte offsets from smem
+      const unsigned surv_off = (unsigned)(reinterpret_cast<unsigned char *>(surv32) - smem) + (unsigned)half * 256u;  // 64 words per half
+      const unsigned surv_lim = surv_off + 63u * 4u;
+      float thr = PDT_INF;  // logit offset of the guessed threshold from the row mean (none yet: one survivor, a miss)
+      float pre[8], preb = -PDT_INF;  // (preb: the blank's logit in the first lane of a half, -inf elsewhere)
+      const float *lgp = a.logits + n * (VC + 1) + hl;
+      if (Tn > 0) {
+        const float *r0 = lgp + (int64_t)min(half, Tn - 1) * a.lg_st;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) pre[i] = r0[i * 32];
+        if (lane_predicate<kFirstLanes>()) {
+          preb = r0[VC];
+          __hip_atomic_store(&cnt[half], (int)surv_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+      }
+      for (int t = 0, sl = 0; t < Tn; t += 2, sl ^= 2) {
+        // both slots free: at most NS frames in flight (NS = 4: the consumer holds the previous pair)
+        while (t + 1 - __hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) >= NS)
+          __builtin_amdgcn_s_sleep(2);
+        unsigned char *sb = my_ring + sl * rl.slot_bytes;
+        float *p = reinterpret_cast<float *>(sb);
+        int *tl_tok = reinterpret_cast<int *>(sb + row_bytes);
+        float *tl_pp = reinterpret_cast<float *>(tl_tok + PDT_WAVE);
+        unsigned char *pos = reinterpret_cast<unsigned char *>(tl_pp + PDT_WAVE);
+        float *hdr = reinterpret_cast<float *>(pos + rl.pos_bytes);
+        if (t >= NS) {  // un-index the list this slot held NS frames ago
+          const int Mprev = __float_as_int(hdr[2]);
+          if (hl < Mprev) pos[tl_tok[hl]] = 0xFF;
+        }
+        const bool short_now = __hip_atomic_load(want_full, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0;
+        // row maximum (every lane of the half) and the mean of the tokens (for the threshold only)
+        float mxl = fmax3_raw(pre[0], pre[1], pre[2]);
+        mxl = fmax3_raw(mxl, pre[3], pre[4]);
+        mxl = fmax3_raw(mxl, pre[5], pre[6]);
+        mxl = fmax3_raw(mxl, pre[7], preb);
+        const float mx = half_max_all_f(mxl);
+        f32x2 sx2 = f32x2{pre[0], pre[1]} + f32x2{pre[2], pre[3]};
+        sx2 += f32x2{pre[4], pre[5]};
+        sx2 += f32x2{pre[6], pre[7]};
+        const int last_of_half = lp | 31;
+        const float mean = shfl_f(half_sum_at31(sx2.x + sx2.y), last_of_half) * (1.0f / (float)VC);
+        // survivors: numerator >= the numerator of the guessed threshold (same exp routine as below is
+        // not needed: any threshold value gives an exact upper set of the list order)
+        unsigned tkey = 0xFFFFFFFFu;
+        if (short_now) tkey = fkey_nonneg(__builtin_amdgcn_exp2f(fminf(mean + thr - mx, 0.0f) * 0x1.715476p+0f));
+        float sA, sB;
+        auto token_chunk = [&](const int i, const float e, float &acc, const bool first) {
+          const int v = hl + i * 32;
+          p[v] = e;
+          acc = first ? e : acc + e;
+          const unsigned key = fkey_nonneg(e);
+          if (key >= tkey) {
+            const unsigned at = (unsigned)__hip_atomic_fetch_add(&cnt[half], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // 32-bit sort key: the value key's upper 23 bits, the token (inverted: lowest first) below
+            *reinterpret_cast<unsigned *>(smem + min(at, surv_lim)) = (key & ~511u) | (511u - (unsigned)v);
+          }
+        };
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+          const f32x2 e2 = exp_nonpos2(f32x2{pre[i], pre[i + 1]} - f32x2{mx, mx});
+          token_chunk(i, e2.x, sA, i == 0);
+          token_chunk(i + 1, e2.y, sB, i == 0);
+        }
+        const float eb = exp_nonpos(preb - mx);  // (+0 where there is no blank)
+        if (lane_predicate<kFirstLanes>()) p[VC] = eb;
+        sA += eb;
+        if (t + 2 < Tn) {
+          const float *nr = lgp + (int64_t)min(t + 2 + half, Tn - 1) * a.lg_st;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) pre[i] = nr[i * 32];
+          if (lane_predicate<kFirstLanes>()) preb = nr[VC];
+        }
+        const float s = shfl_f(half_sum_at31(sA) + half_sum_at31(sB), last_of_half);
+        const float inv0 = __builtin_amdgcn_rcpf(s);
+        const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
+        wave_sync();
+        const int used = __hip_atomic_load(&cnt[half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - (int)surv_off;  // bytes
+        if (lane_predicate<kFirstLanes>()) __hip_atomic_store(&cnt[half], (int)surv_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const bool okv = used >= 4 * kShortMin && used <= 4 * kShortMax;
+        const int nshort = used >> 2;
+        // ONE 32-key sort per half; exact unless two survivors agree in the upper 23 bits (then the
+        // (value, token) pairs are sorted instead)
+        const unsigned sk = (okv && hl < nshort) ? reinterpret_cast<const unsigned *>(smem + surv_off)[hl] : 0u;
+        const unsigned st = half_wave_sort_desc<unsigned>(sk);
+        const unsigned st_next = (unsigned)__builtin_amdgcn_mov_dpp((int)st, 0x130, 0xf, 0xf, true);  // wave_shl:1
+        int tok = 511 - (int)(st & 511u);
+        if (__ballot(okv && hl + 1 < nshort && (st >> 9) == (st_next >> 9)) != 0ull) {
+          const int tk0 = 511 - (int)(sk & 511u);
+          const u64 tk = half_wave_sort_desc<u64>((okv && hl < nshort) ? pack_key(fkey_nonneg(p[tk0]), (unsigned)tk0) : 0ull);
+          tok = (int)idx_of(tk);
+        }
+        if (okv && hl < nshort) {
+          tl_tok[hl] = tok;
+          tl_pp[hl] = p[tok] * inv;
+          pos[tok] = (unsigned char)hl;
+        }
+        {
+          const float step = fmaxf(fabsf(thr) * 0.03125f, 1e-3f);
+          thr += !okv ? 0.0f : (nshort > kShortHi ? step : (nshort < kShortLo ? -step : 0.0f));
+        }
+        if (lane_predicate<kFirstLanes>()) {
+          hdr[0] = inv;
+          hdr[2] = __int_as_float(okv ? nshort : kM);
+        }
+        const u64 bad = __ballot(!okv);
+        if (bad != 0ull) {
+          // a miss (or the consumer asked for complete lists): the complete selection, the whole wave on
+          // the half's row in LDS; its probe seeds the next guess of both halves
+          for (int h = 0; h < 2; ++h) {
+            if (((bad >> (32 * h)) & 1ull) == 0ull) continue;
+            unsigned char *sbh = ring + (sl + h) * rl.slot_bytes;
+            float *ph = reinterpret_cast<float *>(sbh);
+            int *tokh = reinterpret_cast<int *>(sbh + row_bytes);
+            float *pph = reinterpret_cast<float *>(tokh + PDT_WAVE);
+            unsigned char *posh = reinterpret_cast<unsigned char *>(pph + PDT_WAVE);
+            unsigned probe = 0u;
+            wave_sync();
+            build_shared_list<false>(ph, readlane_f(inv, 32 * h), VC, kM, surv, tokh, pph, posh, nullptr, &probe, kProbeRank);
+            thr = readlane_f(mx, 32 * h) + __logf(fkey_nonneg_inv(probe)) - readlane_f(mean, 32 * h);
+          }
+        }
+        wave_sync();
+        if (lane == 0) __hip_atomic_store(&ready[0], t + 2, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      return;
+    }
     // elements of the NEXT row of this wave held in registers while the current one is processed
     constexpr int kPrefetch = 8;
 #ifndef PDT_LONG_BATCH
@@ -595,16 +746,16 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
 #endif
 }
 
-template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false, int WC = -1, int VC = -1>
+template <int P, int NT = -1, bool INREG = (P == 1), bool GROW = false, int WC = -1, int VC = -1, bool PAIR = false>
 static int launch_ctc_search_p(const CtcArgs &a, const RingLayout &rl, hipStream_t stream) {
   const size_t smem = (size_t)rl.utt_bytes * rl.utt_per_wg;
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG, GROW, WC, VC>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_search_kernel<P, NT, INREG, GROW, WC, VC, PAIR>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
   const unsigned grid = (unsigned)((a.N + rl.utt_per_wg - 1) / rl.utt_per_wg);
-  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG, GROW, WC, VC>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
+  hipLaunchKernelGGL((ctc_search_kernel<P, NT, INREG, GROW, WC, VC, PAIR>), dim3(grid), dim3(64 * (P + 1) * rl.utt_per_wg), smem,
                      stream, a, rl);
   return (int)hipGetLastError();
 }
@@ -670,8 +821,11 @@ int launch_ctc_search(const CtcArgs &a, const CtcPlan &plan, const RingLayout &r
   {
     const RingLayout c = ring_layout(256, 16, PDT_RING_STAGES, PDT_UTT_PER_WG, 1);
     if (a.V == 256 && a.W == 16 && a.ckpt_shift == 5 && !a.exact_div && !a.no_lean_extra && a.lg_sv == 1 && a.lg_sn == 257 && c.nstage == rl.nstage && c.utt_per_wg == rl.utt_per_wg && c.utt_bytes == rl.utt_bytes &&
-        c.slot_bytes == rl.slot_bytes)
+        c.slot_bytes == rl.slot_bytes) {
+      // (two frames per producer pass: four ring slots, a pair of them per pass)
+      if (switches().ctc_pair != 0 && rl.nstage == 4) return launch_ctc_search_p<1, 4, true, false, 16, 256, true>(a, rl, stream);
       return launch_ctc_search_p<1, 4, true, false, 16, 256>(a, rl, stream);
+    }
   }
 #endif
 #ifndef PDT_NO_WIDTH16
