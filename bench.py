@@ -608,8 +608,12 @@ def ctc_kernel_name(V, W):
     # (the default shape -- width 16, 256 tokens, contiguous rows -- has its constants compiled in)
     wc = 16 if (nt == 4 and W == 16) else -1
     vc = 256 if (wc == 16 and V == 256) else -1
-    return "pdt::ctc_search_kernel<{}, {}, {}, {}, {}, {}>".format(
-        plan[0], nt, "true" if plan[3] == 1 else "false", "true" if plan[3] == 2 else "false", wc, vc)
+    # (... and its producer takes two frames per pass unless PDT_CTC_PAIR=0)
+    from pydrobert_amd import switches
+
+    pair = "true" if (vc == 256 and plan[1] == 4 and switches.get("PDT_CTC_PAIR") != 0) else "false"
+    return "pdt::ctc_search_kernel<{}, {}, {}, {}, {}, {}, {}>".format(
+        plan[0], nt, "true" if plan[3] == 1 else "false", "true" if plan[3] == 2 else "false", wc, vc, pair)
 
 
 def rendezvous_only(args, world, rank):

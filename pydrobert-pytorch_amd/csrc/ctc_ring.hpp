@@ -63,6 +63,11 @@ __device__ __forceinline__ f32x2 exp_nonpos2(f32x2 x) {
                __builtin_ldexpf(__builtin_amdgcn_exp2f(f.y), (int)n.y)};
 }
 
+__device__ __forceinline__ float fmin_raw(float a, float b) {
+  float r;
+  asm("v_min_f32_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
 __device__ __forceinline__ float fmin3_raw(float a, float b, float c) {
   float r;
   asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));

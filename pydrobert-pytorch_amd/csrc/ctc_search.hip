@@ -154,19 +154,21 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
       const int hl = lp & 31, half = lp >> 5;
       const int row_bytes = rl.row_floats * 4;
       unsigned char *const my_ring = ring + half * rl.slot_bytes;  // slot sl + half of the pass
-      int *cnt = want_full + 1;  // [2] cursors into the survivor buffers, as byte offsets from smem
-      const unsigned surv_off = (unsigned)(reinterpret_cast<unsigned char *>(surv32) - smem) + (unsigned)half * 256u;  // 64 words per half
-      const unsigned surv_lim = surv_off + 63u * 4u;
+      int *cnt = want_full + 1;  // [2] cursors into the survivor buffers: LDS addresses
+      typedef __attribute__((address_space(3))) unsigned lds_u32;
+      const unsigned surv_at = (unsigned)(uintptr_t)(lds_u32 *)surv32 + (unsigned)half * 256u;  // 64 words per half
+      const unsigned surv_lim = surv_at + 63u * 4u;
+      const unsigned ntok = 511u - (unsigned)hl;  // (the token, inverted, of chunk 0)
       float thr = PDT_INF;  // logit offset of the guessed threshold from the row mean (none yet: one survivor, a miss)
       float pre[8], preb = -PDT_INF;  // (preb: the blank's logit in the first lane of a half, -inf elsewhere)
-      const float *lgp = a.logits + n * (VC + 1) + hl;
+      // rows of the pass after this one: a running pointer; the row past the last frame is the last frame again
+      const float *nrow = a.logits + n * (VC + 1) + hl + (int64_t)min(half, Tn - 1) * a.lg_st;
       if (Tn > 0) {
-        const float *r0 = lgp + (int64_t)min(half, Tn - 1) * a.lg_st;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) pre[i] = r0[i * 32];
+        for (int i = 0; i < 8; ++i) pre[i] = nrow[i * 32];
         if (lane_predicate<kFirstLanes>()) {
-          preb = r0[VC];
-          __hip_atomic_store(&cnt[half], (int)surv_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          preb = nrow[VC];
+          __hip_atomic_store(&cnt[half], (int)surv_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
       }
       for (int t = 0, sl = 0; t < Tn; t += 2, sl ^= 2) {
@@ -190,54 +192,73 @@ ctc_search_kernel(const CtcArgs a, const RingLayout rl_arg) {
         mxl = fmax3_raw(mxl, pre[5], pre[6]);
         mxl = fmax3_raw(mxl, pre[7], preb);
         const float mx = half_max_all_f(mxl);
-        f32x2 sx2 = f32x2{pre[0], pre[1]} + f32x2{pre[2], pre[3]};
-        sx2 += f32x2{pre[4], pre[5]};
-        sx2 += f32x2{pre[6], pre[7]};
+        // TAME pass: every token within 86 of the maximum (all numerators normal floats): the cheaper exp
+        // of the same bits (exp_tame2: no clamp, rounding by the 1.5 * 2^23 trick, 2^n by an integer add)
+        float mnl = fmin3_raw(pre[0], pre[1], pre[2]);
+        mnl = fmin3_raw(mnl, pre[3], pre[4]);
+        mnl = fmin3_raw(mnl, pre[5], pre[6]);
+        mnl = fmin_raw(mnl, pre[7]);
+        const bool tame = __ballot(!(mnl - mx >= -86.0f)) == 0ull;
+        // (the mean of half the tokens: the threshold only has to track the level of the row)
+        const f32x2 sx2 = f32x2{pre[0], pre[1]} + f32x2{pre[2], pre[3]};
         const int last_of_half = lp | 31;
-        const float mean = shfl_f(half_sum_at31(sx2.x + sx2.y), last_of_half) * (1.0f / (float)VC);
-        // survivors: numerator >= the numerator of the guessed threshold (same exp routine as below is
-        // not needed: any threshold value gives an exact upper set of the list order)
-        unsigned tkey = 0xFFFFFFFFu;
-        if (short_now) tkey = fkey_nonneg(__builtin_amdgcn_exp2f(fminf(mean + thr - mx, 0.0f) * 0x1.715476p+0f));
+        const float mean = shfl_f(half_sum_at31(sx2.x + sx2.y), last_of_half) * (1.0f / 128.0f);
+        // survivors: numerator >= the numerator of the guessed threshold (v_exp_f32's accuracy is plenty:
+        // any threshold value gives an exact upper set of the list order; +inf: none)
+        float te = PDT_INF;
+        if (short_now) te = __builtin_amdgcn_exp2f(fminf(mean + thr - mx, 0.0f) * 0x1.715476p+0f);
+        // (the cursor's address: once per pass, not rematerialised in every chunk)
+        unsigned cnt_at = (unsigned)(uintptr_t)(lds_u32 *)(cnt + half);
+        asm volatile("" : "+v"(cnt_at));
         float sA, sB;
         auto token_chunk = [&](const int i, const float e, float &acc, const bool first) {
-          const int v = hl + i * 32;
-          p[v] = e;
+          p[hl + i * 32] = e;
           acc = first ? e : acc + e;
-          const unsigned key = fkey_nonneg(e);
-          if (key >= tkey) {
-            const unsigned at = (unsigned)__hip_atomic_fetch_add(&cnt[half], 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            // 32-bit sort key: the value key's upper 23 bits, the token (inverted: lowest first) below
-            *reinterpret_cast<unsigned *>(smem + min(at, surv_lim)) = (key & ~511u) | (511u - (unsigned)v);
+          if (e >= te) {
+            const unsigned at = __hip_atomic_fetch_add((lds_u32 *)(uintptr_t)cnt_at, 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // 32-bit sort key: the numerator's upper 23 bits (it is >= +0: its bit pattern is monotone),
+            // the token (inverted: lowest first) below -- never 0, the empty word
+            *(lds_u32 *)(uintptr_t)min(at, surv_lim) = (__float_as_uint(e) & ~511u) | ((ntok - 32u * (unsigned)i) & 511u);
           }
         };
+        if (tame) {
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-          const f32x2 e2 = exp_nonpos2(f32x2{pre[i], pre[i + 1]} - f32x2{mx, mx});
-          token_chunk(i, e2.x, sA, i == 0);
-          token_chunk(i + 1, e2.y, sB, i == 0);
+          for (int i = 0; i < 8; i += 2) {
+            const f32x2 e2 = exp_tame2(f32x2{pre[i], pre[i + 1]} - f32x2{mx, mx});
+            token_chunk(i, e2.x, sA, i == 0);
+            token_chunk(i + 1, e2.y, sB, i == 0);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 8; i += 2) {
+            const f32x2 e2 = exp_nonpos2(f32x2{pre[i], pre[i + 1]} - f32x2{mx, mx});
+            token_chunk(i, e2.x, sA, i == 0);
+            token_chunk(i + 1, e2.y, sB, i == 0);
+          }
         }
         const float eb = exp_nonpos(preb - mx);  // (+0 where there is no blank)
         if (lane_predicate<kFirstLanes>()) p[VC] = eb;
         sA += eb;
         if (t + 2 < Tn) {
-          const float *nr = lgp + (int64_t)min(t + 2 + half, Tn - 1) * a.lg_st;
+          // (two frames on; at the odd tail the upper half takes the frame the lower half arrives at)
+          nrow += (t + 3 < Tn || half == 0) ? 2 * a.lg_st : a.lg_st;
 #pragma unroll
-          for (int i = 0; i < 8; ++i) pre[i] = nr[i * 32];
-          if (lane_predicate<kFirstLanes>()) preb = nr[VC];
+          for (int i = 0; i < 8; ++i) pre[i] = nrow[i * 32];
+          if (lane_predicate<kFirstLanes>()) preb = nrow[VC];
         }
         const float s = shfl_f(half_sum_at31(sA) + half_sum_at31(sB), last_of_half);
         const float inv0 = __builtin_amdgcn_rcpf(s);
         const float inv = __builtin_fmaf(__builtin_fmaf(-s, inv0, 1.0f), inv0, inv0);
         wave_sync();
-        const int used = __hip_atomic_load(&cnt[half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - (int)surv_off;  // bytes
-        if (lane_predicate<kFirstLanes>()) __hip_atomic_store(&cnt[half], (int)surv_off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        const int used = __hip_atomic_load(&cnt[half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) - (int)surv_at;  // bytes
+        if (lane_predicate<kFirstLanes>()) __hip_atomic_store(&cnt[half], (int)surv_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const bool okv = used >= 4 * kShortMin && used <= 4 * kShortMax;
         const int nshort = used >> 2;
         // ONE 32-key sort per half; exact unless two survivors agree in the upper 23 bits (then the
         // (value, token) pairs are sorted instead)
-        const unsigned sk = (okv && hl < nshort) ? reinterpret_cast<const unsigned *>(smem + surv_off)[hl] : 0u;
-        const unsigned st = half_wave_sort_desc<unsigned>(sk);
+        const unsigned sk = (okv && hl < nshort) ? ((const lds_u32 *)(uintptr_t)surv_at)[hl] : 0u;
+        // (both lists within a 16-lane row: 10 stages instead of 15)
+        const unsigned st = __ballot(okv && nshort > 16) == 0ull ? row_sort_desc<unsigned>(sk) : half_wave_sort_desc<unsigned>(sk);
         const unsigned st_next = (unsigned)__builtin_amdgcn_mov_dpp((int)st, 0x130, 0xf, 0xf, true);  // wave_shl:1
         int tok = 511 - (int)(st & 511u);
         if (__ballot(okv && hl + 1 < nshort && (st >> 9) == (st_next >> 9)) != 0ull) {

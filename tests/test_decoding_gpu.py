@@ -286,6 +286,41 @@ def test_ctc_default_shape_instances_match_the_general_kernels(device):
             _check_search(F.ctc_prefix_search(dense[:60, :8].contiguous(), K, tl[:8].clamp(max=60)), exp, (V, K))
 
 
+def test_two_frames_per_producer_pass_same_bits_as_one(device, switch):
+    """V = 256, W = 16 (the BASELINE shape): the producer of ``ctc_search_kernel<1,4,true,false,16,256,true>``
+    takes two frames per pass, one per half wave (PDT_CTC_PAIR, round 5).  Same bits as the one-frame form
+    -- the normaliser is summed in that form's association -- on: odd and tiny frame counts (the upper
+    half repeats the last frame), ragged lengths incl. 0 and 1, flat rows (every pass misses the
+    short-list window), exact ties (few distinct logits: the (value, token) re-sort of a half), rows
+    with -inf logits (the clamped exp instead of the tame one), duplicated rows.  And against the oracle."""
+    rng = np.random.default_rng(505)
+    V, K = 256, 16
+    for it, (T, N, scale) in enumerate([(1, 5, 12.0), (2, 5, 12.0), (3, 9, 12.0), (65, 40, 12.0), (130, 33, 6.0), (64, 24, 0.0),
+                                        (97, 16, 12.0), (96, 16, 12.0), (40, 12, 9.0)]):
+        lg = rng.normal(size=(T, N, V + 1)).astype(np.float32)
+        np.put_along_axis(lg, rng.integers(0, V + 1, (T, N, 1)), scale, 2)
+        if it == 6:
+            lg = np.round(lg * 2) / 2  # exact ties everywhere
+        if it == 7:
+            lg[:, :, rng.integers(0, V, 60)] = -np.inf  # masked vocabulary: rows that are not tame
+        if it == 8:
+            lg[1::2] = lg[0::2][: lg[1::2].shape[0]]  # every frame twice
+        x = torch.from_numpy(lg).to(device)
+        lens = rng.integers(0, T + 1, N)
+        lens[:3] = [0, min(1, T), T]
+        for ln in (None, torch.from_numpy(lens).to(device)):
+            outs = []
+            for pair in (1, 0):
+                switch("PDT_CTC_PAIR", pair)
+                outs.append(F.ctc_prefix_search(x, K, ln))
+            for p, q in zip(*outs):
+                assert torch.equal(p, q), (it, T, N, scale, ln is not None)
+        if it in (3, 4):  # (tie-free inputs: the oracle's beams)
+            switch("PDT_CTC_PAIR", 1)
+            exp = oracle.ctc_prefix_search(lg, K, lens)
+            _check_search(F.ctc_prefix_search(x, K, torch.from_numpy(lens).to(device)), exp, (it, "oracle"))
+
+
 def test_lean_tier_extras_match_the_full_tiers(device, switch):
     """A frame whose winners include one prefix's third-and-deeper list entries, or two candidates
     that agree in the upper 26 bits of their masses, is decided beside the lean tier (ctc_frame.hpp:
