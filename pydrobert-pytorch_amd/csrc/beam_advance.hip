@@ -17,7 +17,7 @@ namespace pdt {
 // dense extension probabilities are independent and each is a chain of round trips to HBM for a
 // lone wave: the waves take prefixes k = w, w + NW, ... in turn (every wave with its own survivor
 // scratch), wave 0 runs the frame on the finished lists, all waves copy the histories.
-__global__ void __launch_bounds__(512) ctc_advance_kernel(const CtcAdvArgs a) {
+__global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6), NW = a.waves_per_wg;
@@ -134,7 +134,7 @@ int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
 // ... in turn; wave 0 merges the lists (values are kept with the tokens: no global load in the K
 // rounds); the history copy is spread over all the waves again.  N = 1024, K = 16, V = 1000:
 // 0.164 ms with one wave per element doing everything -> see DESIGN.md section 4.4.
-__global__ void __launch_bounds__(512) beam_advance_kernel(const BeamAdvArgs a) {
+__global__ void __launch_bounds__(512, 8) beam_advance_kernel(const BeamAdvArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6), NW = a.waves_per_wg;
