@@ -366,11 +366,11 @@ def other_configs(F, M, device, world, rank, dist, gather_check, say=lambda msg:
     out["C4_spec_augment_apply"] = {"workload": "N=2048 T=1000 F=80, 2 time + 2 freq masks + time warp", "ms": ms,
                                     "utt_per_s": N / ms * 1e3, "GBs": 2 * feats.numel() * 4 / ms / 1e6,
                                     "roofline": roof(2 * 4 * feats.numel(), ms,
-                                                     "pdt::spline_solve_kernel + pdt::warp_1d_grid + pdt::spec_augment_rows_kernel")}
+                                                     "pdt::spec_augment_rows_kernel (one launch: the time warp's spline solved in closed form inside it)")}
     ms = event_ms(lambda: sa(feats, lens))
     out["C4_SpecAugment_forward"] = {"workload": "draw + apply", "ms": ms, "utt_per_s": N / ms * 1e3,
                                      "roofline": roof(2 * 4 * feats.numel(), ms,
-                                                      "pdt::spec_augment_draw_kernel + the apply's kernels")}
+                                                      "pdt::spec_augment_draw_kernel + pdt::spec_augment_rows_kernel behind one operator")}
     img = feats.view(N, 1, T, Fq)
     src = torch.rand((N, 3, 2), device=device, generator=g) * torch.tensor([T - 1.0, Fq - 1.0], device=device)
     dst = src + torch.randn((N, 3, 2), device=device, generator=g)

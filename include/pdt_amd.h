@@ -29,6 +29,7 @@ extern "C" {
 #define PDT_OK 0
 #define PDT_E_ARG -1      /* malformed argument (null pointer, negative size, bad mode) */
 #define PDT_E_TOO_LONG -2 /* a sequence dimension exceeds what the kernel supports */
+#define PDT_E_UNSUPPORTED -3 /* this entry point has no kernel for the layout given; the general entry point has */
 
 #define PDT_MODE_FINAL 0
 #define PDT_MODE_PREFIX 1
@@ -458,6 +459,23 @@ int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, 
                            const float *freq_grid, const int64_t *t_0, const int64_t *t_len,
                            int64_t MT, const int64_t *f_0, const int64_t *f_len, int64_t MF,
                            float *out, void *stream);
+
+/* spec_augment_apply_parameters with the TIME WARP given by its parameters (w_0 = warp_src, w =
+ * warp_flow, float (N,); lengths int64 (N,) or NULL = all T; interpolation order) instead of a grid:
+ * warp_1d_grid's three-knot spline (_img.py:283-302) is solved in closed form (float64) and evaluated
+ * inside the one pass over the features -- one launch, no (N, T) grid in memory.  No frequency warp.
+ * PDT_E_UNSUPPORTED when the one-pass kernel does not take the layout (F not a multiple of 4 or above
+ * 256, strided or unaligned rows): form the grid with pdt_warp_1d_grid and call pdt_spec_augment_apply.
+ * bad_lengths (optional): an int32 in device-visible memory (e.g. pinned host memory) the caller has
+ * set to 0; an utterance whose length is outside [1, T] stores 1 there -- the reference's
+ * "values of lengths must be between (1, T)" check (_img.py:1037-1041) decided where the lengths are
+ * read, for the caller to look at once the stream has drained (the result is then to be dropped). */
+int pdt_spec_augment_apply_warp(const float *feats, int64_t N, int64_t T, int64_t F, int64_t f_sn,
+                                int64_t f_st, int64_t f_sf, const float *warp_src, const float *warp_flow,
+                                const int64_t *lengths, int order, const int64_t *t_0,
+                                const int64_t *t_len, int64_t MT, const int64_t *f_0,
+                                const int64_t *f_len, int64_t MF, float *out, int32_t *bad_lengths,
+                                void *stream);
 
 int pdt_dense_image_warp(const float *image, const float *flow, int64_t N, int64_t C, int64_t H,
                          int64_t W, int flow_is_hw, int mode, int padding, float *out,

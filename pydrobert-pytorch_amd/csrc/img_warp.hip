@@ -288,7 +288,48 @@ struct SpecAugArgs {
   const int64_t *t0, *tl, *f0, *fl;    // (N,MT) / (N,MF) masks or null
   int N, T, F, MT, MF;
   float *out;                          // (N,T,F) contiguous
+  // the time warp by its PARAMETERS instead of a grid (spec_augment_rows_kernel only): w_0, w (N,)
+  // float and the lengths (N,) int64 (null: all T) -- the three-knot spline of warp_1d_grid is solved
+  // in closed form and evaluated where the rows are planned, no (N, T) grid in memory
+  const float *tw_src, *tw_flow; const int64_t *tw_len; int tw_order;
+  // (with tw_len) set to 1 by an utterance whose length is not in [1, T]: the reference's input check
+  // (_img.py:1037-1041) made where the lengths are read; device-visible memory the caller zeroed, or null
+  int32_t *bad_lengths;
 };
+
+// warp_1d_grid's spline (_img.py:283-302) in closed form.  Knots c0 < c1 < c2 = {lo, dst, up}, values
+// {lo, src, up}; the bordered 5 x 5 system [[A, [c 1]], [[c 1]^T, 0]] [w; v] = [f; 0] with A_ij =
+// phi(|c_i - c_j|): the two constraints leave w = alpha u, u = (c1 - c2, c2 - c0, c0 - c1); u kills
+// the affine part, so alpha = u.f / u^T A u, and v from rows 0 and 2 of f - alpha A u = v0 c + v1.
+struct Warp1D {
+  double c[3], w[3], v0, v1;
+};
+__device__ inline Warp1D warp_1d_spline(double src, double flow, double len, int T, int order) {
+  const double eps = (double)FLT_EPSILON;
+  double s = fmax(fmin(src, len - 1.0), 0.0);
+  double d = fmax(fmin(s + flow, len - 1.0), 0.0);
+  s = (2.0 * s + 1.0) / T - 1.0;
+  d = (2.0 * d + 1.0) / T - 1.0;
+  const double lo = 1.0 / T - 1.0 - eps, up = (2.0 * len - 1.0) / T - 1.0 + eps;
+  Warp1D r;
+  r.c[0] = lo; r.c[1] = d; r.c[2] = up;
+  const double f0 = lo, f1 = s, f2 = up;
+  const double u0 = d - up, u1 = up - lo, u2 = lo - d;
+  const double a = phi_d(fabs(d - lo), order), b = phi_d(fabs(up - lo), order), e = phi_d(fabs(up - d), order);
+  const double Au0 = a * u1 + b * u2, Au1 = a * u0 + e * u2, Au2 = b * u0 + e * u1;
+  const double den = u0 * Au0 + u1 * Au1 + u2 * Au2;
+  const double alpha = den != 0.0 ? (u0 * f0 + u1 * f1 + u2 * f2) / den : 0.0;
+  r.w[0] = alpha * u0; r.w[1] = alpha * u1; r.w[2] = alpha * u2;
+  const double r0 = f0 - alpha * Au0, r2 = f2 - alpha * Au2;
+  r.v0 = (r2 - r0) / (up - lo);
+  r.v1 = r0 - r.v0 * lo;
+  return r;
+}
+__device__ __forceinline__ float warp_1d_eval(const Warp1D &sp, int j, int T, int order) {
+  const double t = (2.0 * j + 1.0) / T - 1.0;
+  return (float)(sp.w[0] * phi_d(fabs(t - sp.c[0]), order) + sp.w[1] * phi_d(fabs(t - sp.c[1]), order) +
+                 sp.w[2] * phi_d(fabs(t - sp.c[2]), order) + sp.v0 * t + sp.v1);
+}
 
 // One pass: bilinear gather along time and frequency + band masks.  Workgroup = 256 threads
 // walking a contiguous range of (t, f) positions of one utterance.
@@ -350,6 +391,16 @@ __global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArg
   const int T = a.T, F4 = a.F >> 2;
   const int t_begin = tile * kRowsPerTile, t_end = min(T, t_begin + kRowsPerTile);
   const int tid = (int)threadIdx.x;
+  const bool warped = a.tgrid != nullptr || a.tw_src != nullptr;
+  __shared__ Warp1D spline;
+  if (a.tw_src) {  // (uniform: one extra barrier per workgroup)
+    if (tid == 0) {
+      const int64_t len = a.tw_len ? a.tw_len[n] : (int64_t)T;
+      if (a.bad_lengths && tile == 0 && (len > T || len <= 0)) *a.bad_lengths = 1;
+      spline = warp_1d_spline((double)a.tw_src[n], (double)a.tw_flow[n], (double)len, T, a.tw_order);
+    }
+    __syncthreads();
+  }
   if (t_begin + tid < t_end) {
     const int t = t_begin + tid;
     bool masked = false;
@@ -359,8 +410,9 @@ __global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArg
     }
     int y0 = t;
     float w1 = 0.0f;
-    if (a.tgrid) {
-      const float iy = clip_coord(unnormalize(a.tgrid[n * T + t], T), T);
+    if (warped) {
+      const float g = a.tw_src ? warp_1d_eval(spline, t, T, a.tw_order) : a.tgrid[n * T + t];
+      const float iy = clip_coord(unnormalize(g, T), T);
       const float y0f = floorf(iy);
       y0 = (int)y0f;
       w1 = iy - y0f;
@@ -396,7 +448,7 @@ __global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArg
     if (y0 >= 0) {
       const float w1 = row_w1[r];
       const float4 r0 = *reinterpret_cast<const float4 *>(fn + (int64_t)y0 * a.f_st + 4 * f4);
-      if (a.tgrid && y0 + 1 < T) {
+      if (warped && y0 + 1 < T) {
         // same arithmetic as the 4-tap form with wx0 = 1, wx1 = 0; a row at y0 + 1 == T lies
         // outside the image and carries weight 0 under border padding
         const float w0 = ((float)y0 + 1.0f) - ((float)y0 + w1);
@@ -405,7 +457,7 @@ __global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArg
         v.y = r0.y * w0 + r1.y * w1;
         v.z = r0.z * w0 + r1.z * w1;
         v.w = r0.w * w0 + r1.w * w1;
-      } else if (a.tgrid) {
+      } else if (warped) {
         const float w0 = ((float)y0 + 1.0f) - ((float)y0 + w1);
         v.x = r0.x * w0; v.y = r0.y * w0; v.z = r0.z * w0; v.w = r0.w * w0;
       } else {
@@ -1217,6 +1269,34 @@ int pdt_spec_augment_apply(const float *feats, int64_t N, int64_t T, int64_t F, 
   else
     hipLaunchKernelGGL(spec_augment_apply_kernel, dim3((unsigned)(N * tiles)), dim3(256), 0,
                        (hipStream_t)stream, a, tiles);
+  return (int)hipGetLastError();
+}
+
+int pdt_spec_augment_apply_warp(const float *feats, int64_t N, int64_t T, int64_t F, int64_t f_sn,
+                                int64_t f_st, int64_t f_sf, const float *warp_src, const float *warp_flow,
+                                const int64_t *lengths, int order, const int64_t *t_0,
+                                const int64_t *t_len, int64_t MT, const int64_t *f_0,
+                                const int64_t *f_len, int64_t MF, float *out, int32_t *bad_lengths,
+                                void *stream) {
+  using namespace pdt;
+  if (N < 0 || T < 0 || F < 0 || MT < 0 || MF < 0 || order < 1) return PDT_E_ARG;
+  if (N == 0 || T == 0 || F == 0) return PDT_OK;
+  if (!feats || !out || !warp_src || !warp_flow || (MT > 0 && (!t_0 || !t_len)) || (MF > 0 && (!f_0 || !f_len)))
+    return PDT_E_ARG;
+  if (T * F >= (1ll << 31)) return PDT_E_TOO_LONG;
+  const bool rows_path = (F % 4 == 0) && F <= 256 && f_sf == 1 && (f_st % 4 == 0) && (f_sn % 4 == 0) &&
+                         ((uintptr_t)feats % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  if (!rows_path) return PDT_E_UNSUPPORTED;
+  SpecAugArgs a{};
+  a.feats = feats; a.f_sn = f_sn; a.f_st = f_st; a.f_sf = f_sf;
+  a.t0 = t_0; a.tl = t_len; a.f0 = f_0; a.fl = f_len;
+  a.N = (int)N; a.T = (int)T; a.F = (int)F; a.MT = (int)MT; a.MF = (int)MF;
+  a.out = out;
+  a.tw_src = warp_src; a.tw_flow = warp_flow; a.tw_len = lengths; a.tw_order = order;
+  a.bad_lengths = lengths ? bad_lengths : nullptr;
+  const int rtiles = (int)((T + kRowsPerTile - 1) / kRowsPerTile);
+  hipLaunchKernelGGL(spec_augment_rows_kernel, dim3((unsigned)(N * rtiles)), dim3(256), 0, (hipStream_t)stream, a,
+                     rtiles);
   return (int)hipGetLastError();
 }
 

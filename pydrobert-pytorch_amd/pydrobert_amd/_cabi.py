@@ -7,6 +7,7 @@ to load, every operator raises -- there is no fallback path.
 
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -16,6 +17,7 @@ LIB_PATH = os.environ.get("PDT_AMD_LIB", os.path.join(_HERE, "_lib", "libpdt_amd
 PDT_OK = 0
 PDT_E_ARG = -1
 PDT_E_TOO_LONG = -2
+PDT_E_UNSUPPORTED = -3
 MODE_FINAL, MODE_PREFIX = 0, 1
 WARN_REF_NO_EOS, WARN_HYP_NO_EOS, WARN_EMPTY_REF = 1, 2, 4
 
@@ -117,6 +119,10 @@ SIGNATURES = {
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _P, _I64, _P, _P, _I64, _P, _P],
     ),
+    "pdt_spec_augment_apply_warp": (
+        _INT,
+        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _P, _P, _INT, _P, _P, _I64, _P, _P, _I64, _P, _P, _P],
+    ),
     "pdt_dense_image_warp": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _INT, _INT, _INT, _P, _P]),
     "pdt_sparse_image_warp": (
         _INT,
@@ -210,6 +216,34 @@ def require_hip(*tensors):
         elif t.device != dev:
             raise RuntimeError("tensors are on different devices: {} and {}".format(dev, t.device))
     return dev
+
+
+_HOST_FLAGS = threading.local()
+
+
+class HostFlag:
+    """One int32 in pinned host memory: ``ptr`` for a kernel to store to, ``value`` for the host."""
+
+    def __init__(self):
+        self._t = torch.zeros(1, dtype=torch.int32, pin_memory=True)
+        self._np = self._t.numpy()  # (a view: reads and writes without torch's indexing machinery)
+        self.ptr = self._t.data_ptr()
+
+    @property
+    def value(self) -> int:
+        return int(self._np[0])
+
+
+def host_flag() -> HostFlag:
+    """One word in pinned host memory per host thread, zeroed: a word a kernel raises (a data-dependent
+    verdict the reference reaches with a reduction, a copy and a synchronisation in FRONT of the work)
+    for the host to read once the stream has drained.  A caller synchronises before it returns, so a
+    thread never has two in flight."""
+    flag = getattr(_HOST_FLAGS, "flag", None)
+    if flag is None:
+        flag = _HOST_FLAGS.flag = HostFlag()
+    flag._np[0] = 0
+    return flag
 
 
 def stream_ptr(device):

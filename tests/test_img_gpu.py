@@ -82,6 +82,101 @@ def test_spec_augment_apply_parameters(device, order, freq):
             assert (act[n, t_0[n, m] : t_0[n, m] + t[n, m]] == 0).all()
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_spec_augment_time_warp_in_one_launch(device, order):
+    """``spec_augment_apply_parameters`` with a time warp and no frequency warp is ONE kernel (round 5):
+    warp_1d_grid's three-knot spline is solved in closed form inside the pass over the features
+    (csrc/img_warp.hip warp_1d_spline).  Against the two-operator route through an explicit grid (the
+    Gauss-Jordan solve of ``warp_1d_grid``), against the float64 oracle on the valid frames, for lengths
+    down to 1 / 2 / 3 frames, with and without masks, strided features (the grid route again), and the
+    gradient of the fused operator against the grid route's."""
+    rng = np.random.default_rng(60 + order)
+    N, T, Fq = 24, 90, 12
+    feats = rng.normal(size=(N, T, Fq)).astype(np.float32)
+    lens = rng.integers(8, T + 1, N)
+    lens[:6] = [1, 2, 3, T, T - 1, 4]
+    # (targets kept away from the ends, as _draw does: a target clamped onto an end knot -- an eps away
+    # from it -- makes the 5 x 5 system singular to working precision, and every solver, the float64
+    # oracle's included, returns its own numbers there; the tiny lengths are checked for sanity only)
+    Wd = np.maximum(np.minimum(lens / 2 - 1, 8.0), 0.0)
+    w_0 = (rng.random(N) * (lens - 2 * Wd) + Wd).astype(np.float32)
+    w = (rng.random(N) * Wd - Wd / 2).astype(np.float32)
+    t_0 = rng.integers(0, T - 5, (N, 2)); t = rng.integers(0, 5, (N, 2))
+    f_0 = rng.integers(0, Fq - 2, (N, 1)); f = rng.integers(0, 3, (N, 1))
+    e = torch.empty(0)
+    x, ln = _t(feats, device), _t(lens, device)
+    for masks in (False, True):
+        mk = (_t(t_0, device), _t(t, device), _t(f_0, device), _t(f, device)) if masks else (e, e, e, e)
+        params = (_t(w_0, device), _t(w, device), e, e) + mk
+        act = F.spec_augment_apply_parameters(x, params, order, ln)
+        grid = F.warp_1d_grid(params[0], params[1], ln, T, order)
+        two = torch.ops.pydrobert_amd.spec_augment_apply(
+            x, grid, None, *(m.long().contiguous() if m.numel() else None for m in mk))
+        exp = oracle.spec_augment_apply_parameters(feats, (w_0, w, None, None) + ((t_0, t, f_0, f) if masks else (None,) * 4),
+                                                    order, lens)
+        valid = np.arange(T)[None, :, None] < lens[:, None, None]
+        a, b = act.cpu().numpy(), two.cpu().numpy()
+        ok = lens >= 8
+        assert np.isfinite(a).all()
+        assert np.abs(np.where(valid, a - exp, 0))[ok].max() < 1e-4, order
+        # the two solves agree far inside the oracle tolerance
+        assert np.abs(np.where(valid, a - b, 0))[ok].max() < 2e-5, order
+    # strided features: the general kernel through the grid, same numbers as on a contiguous copy
+    xs = torch.randn(N, T, 2 * Fq, device=device)[:, :, ::2]
+    params = (_t(w_0, device), _t(w, device), e, e, e, e, e, e)
+    vm = torch.from_numpy(valid & ok[:, None, None]).to(device)  # (beyond a length an order >= 2 spline is noise)
+    d = F.spec_augment_apply_parameters(xs, params, order, ln) - F.spec_augment_apply_parameters(xs.contiguous(), params, order, ln)
+    assert float((d * vm).abs().max()) < 2e-5
+    # gradient of the fused operator = gradient through the explicit grid
+    xg = x.clone().requires_grad_(True)
+    g_out = torch.randn(N, T, Fq, device=device)
+    (g1,) = torch.autograd.grad(F.spec_augment_apply_parameters(xg, params, order, ln), xg, g_out)
+    grid = F.warp_1d_grid(params[0], params[1], ln, T, order)
+    (g2,) = torch.autograd.grad(torch.ops.pydrobert_amd.spec_augment_apply(xg, grid, None, None, None, None, None), xg, g_out)
+    assert torch.allclose(g1[_t(ok, device)], g2[_t(ok, device)], atol=1e-4)
+    # lengths out of range: the verdict comes after the launch, the error is the reference's
+    with pytest.raises(RuntimeError, match="values of lengths"):
+        F.spec_augment_apply_parameters(x, params, order, torch.full((N,), T + 1, device=device))
+
+
+def test_spec_augment_forward_behind_one_operator(device):
+    """Training-mode ``SpecAugment.forward`` with a time warp and no frequency warp runs the draw and the
+    one-pass application behind one operator (round 5): the same numbers as ``apply_parameters`` of
+    ``draw_parameters`` from the same generator state, gradients included; a subclass with its own draw
+    is served through it; bad lengths raise the reference's error."""
+    N, T, Fq = 12, 120, 16
+    feats = torch.randn(N, T, Fq, device=device)
+    lens = torch.randint(30, T + 1, (N,), device=device)
+    for kw in (dict(), dict(num_freq_mask=0), dict(max_time_mask=0), dict(interpolation_order=2)):
+        sa = M.SpecAugment(max_time_warp=12.0, max_freq_warp=0.0, **kw).to(device)
+        for ln in (lens, None):
+            torch.manual_seed(7)
+            a = sa(feats, ln)
+            torch.manual_seed(7)
+            b = sa.apply_parameters(feats, sa.draw_parameters(feats, ln), ln)
+            assert torch.equal(a, b), kw
+    sa = M.SpecAugment(max_time_warp=12.0, max_freq_warp=0.0).to(device)
+    x = feats.clone().requires_grad_(True)
+    torch.manual_seed(9)
+    (g1,) = torch.autograd.grad(sa(x, lens), x, torch.ones_like(x))
+    torch.manual_seed(9)
+    (g2,) = torch.autograd.grad(sa.apply_parameters(x, sa.draw_parameters(x, lens), lens), x, torch.ones_like(x))
+    assert torch.allclose(g1, g2, atol=1e-5)
+
+    class NoWarp(M.SpecAugment):
+        def draw_parameters(self, feats, lengths=None):
+            p = super().draw_parameters(feats, lengths)
+            return (p[0], torch.zeros_like(p[1])) + tuple(p[2:])
+
+    nw = NoWarp(max_time_warp=12.0, max_freq_warp=0.0, max_time_mask=0, max_freq_mask=0).to(device)
+    vm = (torch.arange(T, device=device)[None, :] < lens[:, None]).unsqueeze(-1)
+    assert float(((nw(feats, lens) - feats) * vm).abs().max()) < 1e-4  # (a zero flow: the identity on the valid frames)
+    with pytest.raises(RuntimeError, match="values of lengths"):
+        sa(feats, torch.full((N,), T + 3, device=device))
+    with pytest.raises(RuntimeError, match="values of lengths"):
+        sa(feats, torch.zeros(N, dtype=torch.long, device=device))
+
+
 def test_spec_augment_masks_only_and_identity(device):
     rng = np.random.default_rng(3)
     N, T, Fq = 3, 40, 8
