@@ -397,6 +397,21 @@ def synthetic_bigram_dicts(V, successors=20, seed=0x5EED0007):
     return [d1, d2]
 
 
+def synthetic_trigram_dicts(V, successors=20, thirds=5, seed=0x5EED0017):
+    """n-gram tables of a back-off TRIGRAM model over V tokens (+ an out-of-vocabulary sos): the unigrams and
+    explicit bigrams of synthetic_bigram_dicts (now with back-off weights) and `thirds` random explicit
+    trigrams under every explicit bigram -- (V + 1) * successors * thirds of them."""
+    rng = np.random.default_rng(seed)
+    d1, d2 = synthetic_bigram_dicts(V, successors)
+    bo2 = rng.normal(size=len(d2)) * 0.1 - 0.4
+    d2 = {k: (v, float(bo2[i])) for i, (k, v) in enumerate(d2.items())}
+    d3 = {}
+    for (a, b_) in d2:
+        for c in rng.choice(V, thirds, replace=False):
+            d3[(a, b_, int(c))] = float(rng.normal() - 2.5)
+    return [d1, d2, d3]
+
+
 def speechlike_logits(T, N, V, device, seed, dicts, rate=0.045):
     """Logits for the searches WITH a language model: N(0,1) + 12 on one class per frame like
     peaky_logits, but the peak is the blank in most frames and otherwise the next token of a sequence
@@ -542,6 +557,40 @@ def lm_configs(F, M, device, args, ref, hyp, say=lambda msg: None):
             "ms": ms, "utterances_with_zero_best_mass": dead, "reps": 3,
         },
     }
+
+    # the same search with a TRIGRAM model: its (V + 1)^2 contexts as a 4 GB factor table (round 5; the
+    # frame-by-frame kernel of csrc/ctc_lm_step.hip, which served orders above two before, beside it)
+    dicts3 = synthetic_trigram_dicts(V3)
+    lm3 = M.LookupLanguageModel(V3, V3, [d.copy() for d in dicts3]).to(device)
+    search3 = M.CTCPrefixSearch(K, 0.2, lm3)
+    from pydrobert_amd import switches as _sw
+
+    with torch.no_grad():
+        search3(lg_speech[:8])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        search3(lg_speech[:2])  # (the table: built on the first call with this model)
+        torch.cuda.synchronize()
+        ms3 = event_ms(lambda: search3(lg_speech), reps=3, warm=1)
+        alive3 = float((search3(lg_speech)[2][:, 0] > 0).float().mean())
+        _sw.set("PDT_CTC_LM_TABLE", 0)
+        ms3_step = event_ms(lambda: search3(lg_speech), reps=1, warm=0)
+        _sw.set("PDT_CTC_LM_TABLE", 1)
+    from pydrobert_amd import _decoding as _dec3
+
+    tab3 = _dec3._FACTOR_TABLES.get(lm3)
+    out["C3_search_lookup_lm_order3"] = {
+        "workload": "CTCPrefixSearch(16, beta=0.2, LookupLanguageModel TRIGRAM: 20 explicit bigrams per token, 5 explicit "
+                    "trigrams per bigram), N=1024 T=1000 V=1000, speechlike logits",
+        "ms": ms3, "ms_per_frame": ms3 / T3, "utt_per_s": N3 / ms3 * 1e3, "reps": 3,
+        "utterances_with_positive_best_mass": alive3,
+        "factor_table_bytes": None if tab3 is None else int(tab3[1].numel() * 4),
+        "ms_frame_kernel_route": ms3_step,
+        "roofline": roof(search_bytes(T3, N3, V3, K), ms3, lm_kernel.replace("bigram", "trigram")),
+    }
+    del lm3, search3, tab3
+    _dec3._FACTOR_TABLES.clear()
+    torch.cuda.empty_cache()
 
     torch.manual_seed(5)
     gru = make_gru_lm(M, V3).to(device)

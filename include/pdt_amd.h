@@ -164,9 +164,9 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
                           void *stream);
 
 /* ---------------------------------------------------------------------------------------
- * CTC prefix beam search with a BIGRAM language model in the loop, every frame from one launch
+ * CTC prefix beam search with an N-GRAM language model in the loop, every frame from one launch
  * (reference _decoding.py:1064-1202 with shallow fusion / valid mixture, :1113-1135, around a
- * LookupLanguageModel of order two, _lm.py:403-515).
+ * LookupLanguageModel, _lm.py:403-515, whose contexts -- U^(order - 1) of them -- fit a table).
  *
  *   pdt_lm_factor_table: the model's factor of the mix for every context token, from its scores
  *     lm_log_probs (rows, V) contiguous (row c = the model's scores after context token c):
@@ -178,7 +178,12 @@ int pdt_ocd_loss_backward(const float *logits, int64_t H, int64_t N, int64_t V, 
  *     pdt_ctc_prefix_search (the softmax of :1093 is fused); factors (contexts, V) the table above,
  *     factor_max (contexts,) the largest value of every row (it bounds a prefix's extension masses:
  *     lists are built only for prefixes whose extensions can be among a frame's winners);
- *     sos_row the row of the empty prefix's context; a prefix's context is its last token.
+ *     sos_row the row of the empty prefix's context.  A prefix's row is its last (order - 1) tokens read as
+ *     digits in base ctx_base, start-of-sequence padding in front: an extension by token v moves row r to
+ *     (r mod ctx_mod) * ctx_base + v, with ctx_mod = ctx_base^(order - 2) and contexts = ctx_base * ctx_mod
+ *     (a bigram model: ctx_mod = 1, the row is the last token; a trigram model over U context symbols:
+ *     ctx_base = ctx_mod = U, U^2 rows -- 4 GB at U = 1001, V = 1000: sized for this card's HBM, built once
+ *     per model by the model's own scoring kernel over every context).
  *     width <= 32, V <= 5119.  workspace: pdt_ctc_lm_table_search_workspace_bytes (trie + checkpoints).
  * ------------------------------------------------------------------------------------- */
 int pdt_lm_factor_table(const float *lm_log_probs, int64_t rows, int64_t V, float beta, int valid_mixture,
@@ -186,8 +191,8 @@ int pdt_lm_factor_table(const float *lm_log_probs, int64_t rows, int64_t V, floa
 int64_t pdt_ctc_lm_table_search_workspace_bytes(int64_t T, int64_t N, int64_t V, int64_t width);
 int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st, int64_t lg_sn,
                             int64_t lg_sv, const int64_t *lens, int64_t width, int64_t S, const float *factors,
-                            const float *factor_max, int64_t contexts, int64_t f_stride, int64_t sos_row, float beta,
-                            int valid_mixture,
+                            const float *factor_max, int64_t contexts, int64_t f_stride, int64_t sos_row,
+                            int64_t ctx_base, int64_t ctx_mod, float beta, int valid_mixture,
                             int64_t *y, int64_t *y_lens, float *y_probs, void *workspace, void *stream);
 
 /* ---------------------------------------------------------------------------------------

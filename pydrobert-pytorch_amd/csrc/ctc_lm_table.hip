@@ -37,6 +37,10 @@ struct LmTabArgs {
   int64_t f_stride;
   int sos_row;           // the row of the empty prefix's context
   int contexts;
+  // contexts of more than one token (n-gram orders above two): a prefix's row is its last order - 1 tokens
+  // read as digits in base ctx_base (start-of-sequence padding in front), so an extension by token v moves
+  // row r to (r mod ctx_mod) * ctx_base + v, ctx_mod = ctx_base^(order - 2)  (a bigram model: base U, mod 1)
+  int ctx_base, ctx_mod;
   float beta;
   int valid_mixture;
 };
@@ -88,7 +92,7 @@ __host__ __device__ inline int lmtab_small_ints(int W) { return (3 * W * W + 5 *
 
 __host__ __device__ inline LmTabLayout lmtab_layout(int V, int W, int contexts) {
   LmTabLayout l;
-  l.fmax_floats = contexts <= 4096 ? (contexts + 3) & ~3 : 0;  // (16 KB at most: four workgroups share a CU)
+  l.fmax_floats = 0;  // (the rows' largest factors are fetched with the pairs, after every frame: no staging)
   l.row_floats = (V + 1 + 3) & ~3;
   l.rows_bytes = l.row_floats * 4 * kLmTabRows;
   const int lists = W * PDT_WAVE * 8, small = lmtab_small_ints(W) * 4;
@@ -135,13 +139,11 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   // [3 x 3] of a slot's row: the largest token probability, the second largest, the token of the largest
   float *row_stat = reinterpret_cast<float *>(flags + 16);
   int *build_count = flags + 13;  // frame << 6 | lists the published frame needs (0 in nine frames of ten: the workers stay out)
-  float *fmax_lds = reinterpret_cast<float *>(flags + 32);
   const int Tn = min(a.S, a.lens ? (int)min((int64_t)a.T, max((int64_t)0, a.lens[n])) : a.T);
   const float keep = 1.0f - A.beta;
   constexpr int kCtxRow = (1 << 30) - 1;
 
   if (wave == 0 && lane < 32) __hip_atomic_store(&flags[lane], 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-  for (int i = (int)threadIdx.x; i < ly.fmax_floats && i < A.contexts; i += 256) fmax_lds[i] = A.fmax[i];
   __syncthreads();  // flags initialised (the only workgroup barrier)
 
   auto ld_flag = [&](int *f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP); };
@@ -388,13 +390,15 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
   int open_lists_dbg_v = 0, *open_lists_dbg = &open_lists_dbg_v;
 #endif
   constexpr int kPairLoads = (WC > 0 ? WC * WC : kMaxWidth * kMaxWidth) / PDT_WAVE;
-  float fpv[kPairLoads], fv1 = 0.0f;
+  float fpv[kPairLoads], fv1 = 0.0f, fm = 0.0f;
+  int ctx = A.sos_row;  // this prefix's row of the table (its last order - 1 tokens)
   // (issued right after a frame has decided the new prefixes; read in publish(t1))
   auto fetch_pairs = [&](const int t1) {
     int lp = lane;
     asm volatile("" : "+v"(lp));
     const int lastc = min(max(bm.last, 0), V - 1);
-    const int c = bm.len > 0 ? lastc : A.sos_row;
+    const int c = min(max(ctx, 0), A.contexts - 1);
+    fm = A.fmax[c];  // the row's largest factor (publish()'s bound)
     // the factor of this prefix's context at frame t1's most probable token (publish()'s bound)
     wait_above(&row_ready[t1 % kLmTabRows], t1);
     fv1 = A.factors[(int64_t)c * A.f_stride + __float_as_int(row_stat[(t1 % kLmTabRows) * 3 + 2])];
@@ -414,13 +418,12 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
     const float tot = bm.nb + bm.b;
     const bool valid = lp < Kp && tot > -PDT_INF;
     const int lastc = min(max(bm.last, 0), V - 1);
-    const int c = bm.len > 0 ? lastc : A.sos_row;
+    const int c = min(max(ctx, 0), A.contexts - 1);
     const bool dead = readlane_f(tot, 0) == 0.0f;  // every mass underflowed: nothing left to decide
     const float p_blank = p[V], p1 = row_stat[(t % kLmTabRows) * 3], p2 = row_stat[(t % kLmTabRows) * 3 + 1];
     const float m2_lb = bm.nb * p[lastc] + tot * p_blank;
     const int n_valid = __popcll(__ballot(valid));
     const float tau = n_valid >= min(W, Kp * (V + 1)) ? wave_min(valid ? m2_lb : PDT_INF) : 0.0f;
-    const float fm = ly.fmax_floats ? fmax_lds[c] : A.fmax[c];  // (LDS: the look-up is on every frame's critical path)
     // the largest extension probability of this prefix, bounded: the frame's most probable token with
     // ITS factor (fv1), every other token at most the runner-up with the row's largest factor -- the mix
     // is monotone in both operands (before round 5: the largest probability with the largest factor,
@@ -527,6 +530,9 @@ ctc_lm_table_kernel(const LmTabArgs A, const LmTabLayout ly) {
       L.nxt_old = L.nxt_new;
       L.nxt_new = tmp;
       Kp = W;
+      // the new prefixes' rows: an extension shifts its token into the source's context
+      const int ctx_s = shfl_i(ctx, nk >= 0 ? ns : lane);
+      ctx = nk < 0 ? A.sos_row : ((nk == 0 || nk == 1) ? (int)((unsigned)ctx_s % (unsigned)A.ctx_mod) * A.ctx_base + nt_ : ctx_s);
     }
     if (t + 1 < Tn) fetch_pairs(t + 1);
     if (((t + 1) & ((1 << a.ckpt_shift) - 1)) == 0) {  // checkpoint (see CtcArgs::ckpt)
@@ -616,12 +622,13 @@ int64_t pdt_ctc_lm_table_search_workspace_bytes(int64_t T, int64_t N, int64_t V,
 
 int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V, int64_t lg_st, int64_t lg_sn,
                             int64_t lg_sv, const int64_t *lens, int64_t width, int64_t S, const float *factors,
-                            const float *factor_max, int64_t contexts, int64_t f_stride, int64_t sos_row, float beta,
-                            int valid_mixture,
+                            const float *factor_max, int64_t contexts, int64_t f_stride, int64_t sos_row,
+                            int64_t ctx_base, int64_t ctx_mod, float beta, int valid_mixture,
                             int64_t *y, int64_t *y_lens, float *y_probs, void *workspace, void *stream) {
   using namespace pdt;
   if (T < 0 || N < 0 || V < 1 || width < 1 || S < 0 || contexts < 1 || f_stride < V) return PDT_E_ARG;
-  if (sos_row < 0 || sos_row >= contexts || contexts < V) return PDT_E_ARG;
+  if (sos_row < 0 || sos_row >= contexts || contexts < V || ctx_base < V || ctx_mod < 1 || ctx_base * ctx_mod != contexts)
+    return PDT_E_ARG;
   if (contexts >= (1 << 30)) return PDT_E_TOO_LONG;  // (a context word keeps the row in 30 bits)
   if (N == 0) return PDT_OK;
   if (!y_lens || !y_probs || !factors || !factor_max || (T > 0 && (!logits || !workspace)) || (S > 0 && !y)) return PDT_E_ARG;
@@ -637,6 +644,7 @@ int pdt_ctc_lm_table_search(const float *logits, int64_t T, int64_t N, int64_t V
   a.ckpt = a.trie + T * N * width;
   a.exact_div = switches().ctc_exact_div == 1 ? 1 : 0;
   a.no_lean_extra = switches().ctc_lean_extra == 0 ? 1 : 0;
+  A.ctx_base = (int)ctx_base; A.ctx_mod = (int)ctx_mod;
   A.factors = factors; A.fmax = factor_max; A.f_stride = f_stride; A.contexts = (int)contexts; A.sos_row = (int)sos_row; A.beta = beta; A.valid_mixture = valid_mixture;
   const LmTabLayout ly = lmtab_layout((int)V, (int)width, (int)contexts);
   if ((size_t)ly.utt_bytes > 160 * 1024) return PDT_E_TOO_LONG;

@@ -85,7 +85,7 @@ SIGNATURES = {
     "pdt_ctc_lm_table_search_workspace_bytes": (_I64, [_I64, _I64, _I64, _I64]),
     "pdt_ctc_lm_table_search": (
         _INT,
-        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, _I64, _I64, _F, _INT, _P, _P, _P, _P, _P],
+        [_P, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _P, _I64, _I64, _I64, _I64, _I64, _F, _INT, _P, _P, _P, _P, _P],
     ),
     "pdt_beam_search_step": (
         _INT,

@@ -645,10 +645,13 @@ class CTCPrefixSearch(torch.nn.Module):
         """A bigram LookupLanguageModel whose (contexts, V) factor table stays in the Infinity Cache:
         the search of csrc/ctc_lm_table.hip (PDT_CTC_LM_TABLE=0: the other routes, for comparisons)."""
         lm = self.lm
-        if not switches.get("PDT_CTC_LM_TABLE") or not self._fuses_lookup_lm(logits) or lm.max_ngram != 2:
+        if not switches.get("PDT_CTC_LM_TABLE") or not self._fuses_lookup_lm(logits) or lm.max_ngram < 2:
             return False
         V = lm.vocab_size
-        return V + 1 <= 80 * 64 and (V + 1) * V * 4 <= _FACTOR_TABLE_MAX_BYTES and logits.dtype == torch.float
+        # (a row per context: U^(order - 1) of them -- 4 MB for a bigram model over 1000 tokens, 4 GB for a
+        # trigram model: the card has 288)
+        rows = (V + 1) ** (lm.max_ngram - 1)
+        return V + 1 <= 80 * 64 and rows < (1 << 30) and rows * V * 4 <= _FACTOR_TABLE_MAX_BYTES and logits.dtype == torch.float
 
     @torch.jit.unused
     def _lm_table_search(
@@ -660,7 +663,7 @@ class CTCPrefixSearch(torch.nn.Module):
         T, N, V = logits.size(0), logits.size(1), logits.size(2) - 1
         device = _cabi.require_hip(logits, lens, *_lm_buffers(lm))
         logits = _f32(logits)
-        factors, fmax, sos_row = _factor_table(lm, self.beta, self.valid_mixture, device)
+        factors, fmax, sos_row, ctx_base = _factor_table(lm, self.beta, self.valid_mixture, device)
         L = _cabi.lib()
         with torch.cuda.device(device):
             y = torch.empty((n_frames, N, W), device=device, dtype=torch.long)
@@ -673,7 +676,7 @@ class CTCPrefixSearch(torch.nn.Module):
                 rc = L.pdt_ctc_lm_table_search(
                     _cabi.ptr(logits), n_frames, N, V, logits.stride(0), logits.stride(1), logits.stride(2),
                     _cabi.ptr(lens_dev), W, n_frames, _cabi.ptr(factors), _cabi.ptr(fmax), factors.size(0),
-                    factors.stride(0), sos_row,
+                    factors.stride(0), sos_row, ctx_base, factors.size(0) // ctx_base,
                     float(self.beta), int(self.valid_mixture), _cabi.ptr(y), _cabi.ptr(y_lens), _cabi.ptr(y_probs),
                     _cabi.ptr(ws), _cabi.stream_ptr(device),
                 )  # fmt: skip
@@ -808,46 +811,62 @@ def _identity_of(*tensors):
 _BIGRAM_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 # ... and the factor tables of the mixes they have been searched with (_factor_table)
 _FACTOR_TABLES: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
-_FACTOR_TABLE_MAX_BYTES = 256 << 20  # (the table should stay in the Infinity Cache)
+_FACTOR_TABLE_MAX_BYTES = 6 << 30  # (a trigram model over 1000 tokens: 4 GB of this card's 288)
 
 
 def _bigram_scores(lm: "LookupLanguageModel", device: torch.device):
     """``(scores (U, V) float32, sos_row)`` of a bigram model: row ``c`` = its scores after context
     token ``c`` (the start-of-sequence token's row last when it lies outside the vocabulary) -- one
     call of the model's own scoring kernel over every context."""
+    scores, sos_row, _ = _context_scores(lm, device, 2)
+    return scores, sos_row
+
+
+def _context_scores(lm: "LookupLanguageModel", device: torch.device, order: Optional[int] = None):
+    """``(scores (U^(order-1), V) float32, sos_row, U)``: the model's scores after EVERY context of
+    ``order - 1`` symbols -- row ``r`` = the context whose symbols are the digits of ``r`` in base ``U``,
+    oldest first; the symbols are the V tokens, then the start-of-sequence token when it lies outside the
+    vocabulary (``U = V + 1``); ``sos_row`` = the all-sos context of the empty prefix (the reference pads
+    short histories with sos, _lm.py:403-515).  One call of the model's own scoring kernel."""
     V = lm.vocab_size
+    order = lm.max_ngram if order is None else order
     shift = 0 if (0 <= lm.sos < V) else 1
+    U, n1 = V + shift, order - 1
+    sos_sym = lm.sos if shift == 0 else V
     with torch.no_grad():
-        toks = torch.arange(V, device=device)
+        rows = torch.arange(U**n1, device=device)
+        digits = [(rows // (U ** (n1 - 1 - i))) % U for i in range(n1)]
+        hist = torch.stack(digits)  # (order - 1, rows), oldest symbol first
         if shift:
-            toks = torch.cat([toks, torch.tensor([lm.sos], device=device)])
-        table, _ = lm.calc_idx_log_probs(toks.unsqueeze(0), dict(), torch.tensor(1, device=device))
-    return _f32(table).contiguous(), (lm.sos if shift == 0 else V)
+            hist = torch.where(hist == V, torch.full_like(hist, lm.sos), hist)
+        table, _ = lm.calc_idx_log_probs(hist, dict(), torch.tensor(n1, device=device))
+    sos_row = sum(sos_sym * U**i for i in range(n1))
+    return _f32(table).contiguous(), sos_row, U
 
 
 def _factor_table(lm: "LookupLanguageModel", beta: float, valid_mixture: bool, device: torch.device):
-    """``(factors (U, V), row maxima (U,), sos_row)``: the model's factor of CTCPrefixSearch's mix for every context token
-    (include/pdt_amd.h: pdt_lm_factor_table), built once per model, mix and device and kept while every
-    trie buffer of the model is the same tensor at the same version (see BeamSearch._bigram_table for
-    what that does not see)."""
+    """``(factors (rows, V), row maxima (rows,), sos_row, U)``: the model's factor of CTCPrefixSearch's mix for
+    every context (include/pdt_amd.h: pdt_lm_factor_table), built once per model, mix and device and kept
+    while every trie buffer of the model is the same tensor at the same version (see
+    BeamSearch._bigram_table for what that does not see).  The factors overwrite the scores they are
+    formed from (a trigram model's table is gigabytes)."""
     ident = _identity_of(*_lm_buffers(lm))
     key = None if ident is None else (ident, str(device), float(beta), bool(valid_mixture))
     ent = _FACTOR_TABLES.get(lm)
     if key is not None and ent is not None and ent[0] == key:
-        return ent[1], ent[2], ent[3]
-    scores, sos_row = _bigram_scores(lm, device)
-    U, V = scores.shape
-    factors = torch.empty((U, V), device=device, dtype=torch.float)
+        return ent[1], ent[2], ent[3], ent[4]
+    factors, sos_row, U = _context_scores(lm, device)
+    rows, V = factors.shape
     with torch.cuda.device(device):
         rc = _cabi.lib().pdt_lm_factor_table(
-            _cabi.ptr(scores), U, V, float(beta), int(valid_mixture), _cabi.ptr(factors), factors.stride(0),
+            _cabi.ptr(factors), rows, V, float(beta), int(valid_mixture), _cabi.ptr(factors), factors.stride(0),
             _cabi.stream_ptr(device),
         )
     _cabi.check(rc, "pdt_lm_factor_table")
     fmax = factors.max(1)[0].contiguous()
     if key is not None:
-        _FACTOR_TABLES[lm] = (key, factors, fmax, sos_row)
-    return factors, fmax, sos_row
+        _FACTOR_TABLES[lm] = (key, factors, fmax, sos_row, U)
+    return factors, fmax, sos_row, U
 
 
 class BeamSearch(torch.nn.Module):

@@ -255,9 +255,11 @@ def test_scripted_lookup_lm():
     assert torch.equal(lm(hist, None, idx)[0], scripted(hist, None, idx)[0])
     search = M.CTCPrefixSearch(4, 0.3, lm)
     logits = torch.randn((7, 3, V + 1), device=DEV, generator=torch.Generator(DEV).manual_seed(5))
+    # (eager: the factor-table search with its fused softmax, for every order whose contexts fit a table since
+    # round 5; scripted: the frame loop on torch's softmax -- the same beams, probabilities to the last ulps)
     exp, act = search(logits), torch.jit.script(search)(logits)
-    for a, b in zip(exp, act):
-        assert torch.equal(a, b)
+    assert torch.equal(exp[0], act[0]) and torch.equal(exp[1], act[1])
+    assert torch.allclose(exp[2], act[2], rtol=1e-5, atol=0)
 
 
 @pytest.mark.parametrize("V", [7, 512, 513, 1024, 1500])

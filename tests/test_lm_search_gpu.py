@@ -103,6 +103,36 @@ def test_a_model_with_state_in_both_searches(beam_route, switch):
 
 
 @pytest.mark.parametrize("valid_mixture", [False, True])
+def test_c3_sample_ctc_search_with_a_trigram_model_against_the_oracle(valid_mixture, switch):
+    """The same at order THREE (round 5): the factor-table search over the model's (V + 1)^2 contexts -- a
+    4 GB table built by the model's own scoring kernel -- and the frame-kernel routes, against
+    oracle.ctc_prefix_search_lm around oracle.NGramLM (the defining back-off recursion) at T=1000, V=1000."""
+    import bench
+
+    T, N, V, K, beta = 1000, 5, 1000, 16, 0.2
+    dicts = bench.synthetic_trigram_dicts(V)
+    lm = M.LookupLanguageModel(V, V, [d.copy() for d in dicts]).to(DEV)
+    olm = oracle.NGramLM(V, V, dicts)
+    lg = bench.speechlike_logits(T, N, V, torch.device(DEV), 0x5EED0043 + int(valid_mixture), dicts)
+    lens = torch.tensor([T, T - 1, 640, T, 3], device=DEV)
+    ey, eyl, eyp = oracle.ctc_prefix_search_lm(lg.cpu().numpy(), K, lens.cpu().numpy(), olm, beta, valid_mixture)
+    assert eyl.max() > 40 and np.isfinite(eyp).all() and (eyp > 0).all(), (eyl.max(), eyp.min())
+    search = M.CTCPrefixSearch(K, beta, lm, valid_mixture=valid_mixture)
+    for route in ("table", "search"):
+        for name, value in CTC_ROUTES[route].items():
+            switch(name, value)
+        with torch.no_grad():
+            y, yl, yp = _np(search(lg, lens))
+        assert np.array_equal(yl, eyl), (route, np.argwhere(yl != eyl)[:5])
+        assert np.array_equal(_masked(y, yl)[: ey.shape[0]], ey), (route, np.argwhere(_masked(y, yl)[: ey.shape[0]] != ey)[:5])
+        _drift.check_log_probs(yp, eyp, "C3 + trigram LM vs oracle, T=1000 V=1000 K=16, route {}, valid_mixture={}".format(route, valid_mixture))
+    from pydrobert_amd import _decoding as _dec
+
+    _dec._FACTOR_TABLES.clear()  # (4 GB a model: not kept for the rest of the suite)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("valid_mixture", [False, True])
 def test_c3_sample_ctc_search_with_the_bigram_model_against_the_oracle(valid_mixture, switch):
     """C3's shape per utterance (T=1000, V=1000, K=16; BASELINE config 3 with the shipped n-gram model
     in the loop) for a sample of utterances: every route of the package against oracle.ctc_prefix_search_lm
