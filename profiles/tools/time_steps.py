@@ -29,3 +29,11 @@ print("ctc_prefix_search_advance ms", ["%.4f" % event_ms(lambda: F.ctc_prefix_se
 ext = args[0][0].contiguous()
 args2 = ((ext, args[0][1], args[0][2]),) + args[1:]
 print("ctc_prefix_search_advance (dense ext rows) ms", ["%.4f" % event_ms(lambda: F.ctc_prefix_search_advance(*args2)) for _ in range(3)])
+# host cost per call: many calls back to back, wall clock (the GPU queue absorbs them)
+import time
+for name, fn in (("beam_search_advance (no lens)", lambda: F.beam_search_advance(lpt, K, lpp, yb)),
+                 ("ctc_prefix_search_advance", lambda: F.ctc_prefix_search_advance(*args))):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(200): fn()
+    t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+    print("%s: host %.1f us per call to enqueue, %.1f us per call until the queue drained" % (name, (t1 - t0) / 200 * 1e6, (t2 - t0) / 200 * 1e6))

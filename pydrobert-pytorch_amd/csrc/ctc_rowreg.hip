@@ -81,6 +81,8 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
   u64 *surv0 = reinterpret_cast<u64 *>(cs + consumer_scratch_bytes(W));
   int *consumed = reinterpret_cast<int *>(surv0 + P * PDT_SURV_CAP);  // frames the consumer finished
   int *ready = consumed + 1;                                          // [nstage <= 4] frame + 1 held by a slot
+  int *cursor = ready + 4;                                            // [P <= 3] a producer's cursor into its survivor buffer
+  static_assert(P <= 3, "three cursors fit the flag words");
   auto slot_tok = [&](int sl) { return reinterpret_cast<int *>(ring + (size_t)sl * rl.slot_bytes); };
   auto slot_p = [&](int sl) { return reinterpret_cast<float *>(slot_tok(sl) + PDT_WAVE); };
   auto slot_hdr = [&](int sl) { return slot_p(sl) + PDT_WAVE; };
@@ -114,6 +116,7 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
         if (i < NF || i < nt_) r[i] = row[i * PDT_WAVE];
       if (lane <= rem_) rt = row[nt_ * PDT_WAVE];
     }
+    float thr_off = PDT_INF;  // the guessed survivor threshold: logit offset from the mean per-lane maximum (none yet)
     int sl = pr % NS;
     for (int t = pr; t < Tn; t += P, sl = sl + P >= NS ? sl + P - NS : sl + P) {
       // (laundered: nothing derived from the lane index or the chunk count is loop-invariant to the
@@ -139,27 +142,56 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       // takes exp_tame2 below; rows with masked (-inf) or far-off elements the general routine
       const bool tame = wave_min(lmn) - mx >= -86.0f;
       // ---- pass B: the tokens that can be among the M best -----------------------------------
-      // The list is ordered by (numerator, token), and exp() is monotone: the M-th largest per-lane
-      // maximum LOGIT bounds the M-th best from below.  Survivors are taken a margin below it -- 2^-16
-      // in the logit is 128 ulps of the numerator, beyond anything rounding can reorder -- so every
-      // token whose numerator ties with or exceeds the M-th best is among them, and ranking the
-      // survivors by their numerators gives the list the other forms build from a row of numerators.
-      const unsigned sorted_max = wave_sort_desc<unsigned>(fkey(lmx));
-      const float tau_x = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1));
-      const float tq = tau_x - fmaxf(0x1p-16f, fabsf(tau_x) * 0x1p-20f);
-      int count = 0;
-      auto survivors = [&](const float x, const int v, const bool pred) {
-        const u64 bal = __ballot(pred);
-        if (bal) {
-          const int at = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(bal >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)bal, 0u));
-          if (pred && at < PDT_SURV_CAP) surv[at] = ((u64)__float_as_uint(x) << 32) | (unsigned)v;
-          count += __popcll(bal);
-        }
-      };
+      // The list is ordered by (numerator, token), and exp() is monotone: a logit threshold that at least
+      // M tokens reach -- with a margin of 2^-16 in the logit, 128 ulps of the numerator, beyond anything
+      // rounding can reorder -- selects every token whose numerator ties with or exceeds the M-th best,
+      // and ranking the survivors by their numerators gives the list the other forms build from a row of
+      // numerators.  The threshold is GUESSED (round 5): the mean of the per-lane maxima plus an offset that
+      // follows the survivor count from row to row (the exact one -- the M-th largest per-lane maximum, a
+      // 64-key sort -- seeds it and takes over whenever a guess leaves fewer than M survivors, more than
+      // the buffer holds, or the M-th survivor inside the margin: checked below, after the ranking).
+      // Survivors are appended through an LDS cursor (ds_add_rtn: a slot per lane, no ballot / mbcnt
+      // arithmetic; their order does not matter, they are sorted).
+      typedef __attribute__((address_space(3))) unsigned lds_u32r;
+      typedef __attribute__((address_space(3))) u64 lds_u64r;
+      const unsigned surv_at = (unsigned)(uintptr_t)(lds_u64r *)surv, surv_lim = surv_at + (PDT_SURV_CAP - 1) * 8u;
+      unsigned cur_at = (unsigned)(uintptr_t)(lds_u32r *)(cursor + pr);
+      asm volatile("" : "+v"(cur_at));
+      auto collect = [&](const float thr) -> int {
+        if (lp == 0) *(lds_u32r *)(uintptr_t)cur_at = surv_at;
+        wave_sync();
+        auto survivors = [&](const float x, const int v, const bool pred) {
+          if (pred) {
+            const unsigned at = __hip_atomic_fetch_add((lds_u32r *)(uintptr_t)cur_at, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            *(lds_u64r *)(uintptr_t)min(at, surv_lim) = ((u64)__float_as_uint(x) << 32) | (unsigned)v;
+          }
+        };
 #pragma unroll
-      for (int i = 0; i < NR; ++i)
-        if (i < NF || i < nt) survivors(r[i], lp + i * PDT_WAVE, r[i] >= tq);
-      survivors(rt, lp + nt * PDT_WAVE, is_tok && rt >= tq);
+        for (int i = 0; i < NR; ++i)
+          if (i < NF || i < nt) survivors(r[i], lp + i * PDT_WAVE, r[i] >= thr);
+        survivors(rt, lp + nt * PDT_WAVE, is_tok && rt >= thr);
+        wave_sync();
+        return (int)((*(lds_u32r *)(uintptr_t)cur_at - surv_at) >> 3);
+      };
+      const float margin_of = 0x1p-16f;
+      bool guessed = thr_off < PDT_INF;
+      float tq = 0.0f, lmx_mean = 0.0f;
+      int count = 0;
+      if (guessed) {
+        lmx_mean = wave_sum_f(lmx > -PDT_INF ? lmx : mx) * (1.0f / PDT_WAVE);
+        tq = lmx_mean + thr_off;
+        count = collect(tq);
+        guessed = count >= M && count <= PDT_SURV_CAP;
+      }
+      if (!guessed) {
+        const unsigned sorted_max = wave_sort_desc<unsigned>(fkey(lmx));
+        const float tau_x = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1));
+        tq = tau_x - fmaxf(margin_of, fabsf(tau_x) * 0x1p-20f);
+        count = collect(tq);
+        // (seed the next rows' guesses a little below this row's exact threshold)
+        if (lmx_mean == 0.0f) lmx_mean = wave_sum_f(lmx > -PDT_INF ? lmx : mx) * (1.0f / PDT_WAVE);
+        thr_off = (tq - lmx_mean) - 0.15f;
+      }
       // ---- pass C: softmax numerators and their sum (:1093), e[v] = exp(x[v] - max) ----------
       // per-lane sums over v = lane, lane + 64, ... in order, then the DPP reduction: the other
       // forms' arithmetic.  A chunk's register is free once its numerator is in the sum: the next
@@ -201,10 +233,28 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       wave_sync();
       u64 tk = 0ull;
       if (count <= PDT_SURV_CAP) {
-        const u64 rec = lp < count ? surv[lp] : 0ull;
-        const unsigned key = fkey_nonneg(exp_nonpos(__uint_as_float((unsigned)(rec >> 32)) - mx));
-        tk = wave_sort_desc<u64>(lp < count ? pack_key(key, (unsigned)rec) : 0ull);
-      } else {
+        u64 rec = lp < count ? surv[lp] : 0ull;
+        if (guessed) {
+          // M survivors must clear the guessed threshold by the margin (a token just below the threshold
+          // could otherwise tie with the M-th best in the numerator) -- else the exact threshold, once more
+          const float xm = lp < count ? __uint_as_float((unsigned)(rec >> 32)) : -PDT_INF;
+          if (__popcll(__ballot(xm - tq >= fmaxf(margin_of, fabsf(xm) * 0x1p-20f))) < M) {
+            const unsigned sorted_max = wave_sort_desc<unsigned>(fkey(lmx));
+            const float tau_x = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1));
+            tq = tau_x - fmaxf(margin_of, fabsf(tau_x) * 0x1p-20f);
+            count = collect(tq);
+            rec = (count <= PDT_SURV_CAP && lp < count) ? surv[lp] : 0ull;
+            guessed = false;
+          }
+          // keep the survivor count around three quarters of the buffer
+          thr_off += count > 52 ? 0.05f : (count < M + 8 ? -0.05f : 0.0f);
+        }
+        if (count <= PDT_SURV_CAP) {
+          const unsigned key = fkey_nonneg(exp_nonpos(__uint_as_float((unsigned)(rec >> 32)) - mx));
+          tk = wave_sort_desc<u64>(lp < count ? pack_key(key, (unsigned)rec) : 0ull);
+        }
+      }
+      if (count > PDT_SURV_CAP) {
         // heavy ties / clustered values: chunked top-64 merge.  Rare, and a register file cannot be
         // indexed by a loop counter: the row is read again (L2)
         const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
