@@ -538,7 +538,7 @@ def lm_configs(F, M, device, args, ref, hyp, say=lambda msg: None):
     lg_speech = speechlike_logits(T3, N3, V3, device, 0x5EED0009, dicts)
     lg = peaky_logits(T3, N3, V3, device, 0x5EED0003)
     search = M.CTCPrefixSearch(K, 0.2, lm)
-    lm_kernel = "pdt::ctc_lm_table_kernel<16> (factor table of the bigram model; csrc/ctc_lm_table.hip)"
+    lm_kernel = "pdt::ctc_lm_table_kernel<16, 16> (factor table of the bigram model; csrc/ctc_lm_table.hip)"
     with torch.no_grad():
         search(lg[:8])
         ms_speech = event_ms(lambda: search(lg_speech), reps=3, warm=1)
@@ -845,9 +845,10 @@ def run_rank(args):
     # HBM bytes per launch and instruction counts from the rocprofv3 PMC passes (profiles/), only
     # when they were collected for this very configuration
     traffic, valu = None, None
-    tpath = os.path.join(ROOT, "profiles", "r04_ctc_traffic.json")
-    if not os.path.exists(tpath):
-        tpath = os.path.join(ROOT, "profiles", "r03_ctc_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r05_ctc_traffic.json")
+    for older in ("r04_ctc_traffic.json", "r03_ctc_traffic.json"):
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", older)
     tname = os.path.basename(tpath)
     if dom == "ctc_prefix_search" and os.path.exists(tpath):
         rec = json.load(open(tpath))
