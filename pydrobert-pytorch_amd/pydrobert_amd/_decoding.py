@@ -1030,8 +1030,10 @@ class BeamSearch(torch.nn.Module):
         # call the language model up to `check_every - 1` times past the reference's stopping point (their
         # output is cut off again) -- invisible for a stateless, deterministic model like this package's
         # LookupLanguageModel, but a stochastic or stateful user model would see extra calls: those are
-        # checked every iteration, as the reference does (_decoding.py:426), unless the caller says
-        # otherwise through `host_check_interval`.
+        # checked every iteration unless the caller says otherwise through `host_check_interval`.  Even
+        # then the count of iteration i is read AFTER the model's call of iteration i has been issued, so
+        # such a model sees AT MOST ONE call more than under the reference, which breaks before calling
+        # it (_decoding.py:426); the call's output is discarded.
         check_every = self.host_check_interval
         if check_every is None:
             check_every = 8 if type(self.lm) is LookupLanguageModel else 1
