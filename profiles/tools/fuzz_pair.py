@@ -1,0 +1,65 @@
+"""Fuzz of the two-frames-per-pass producer (V = 256, W = 16; PDT_CTC_PAIR) against the one-frame form
+(torch.equal) and, on tie-free inputs, the oracle:   python profiles/tools/fuzz_pair.py SEED SECONDS"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "pydrobert-pytorch_amd")):
+    sys.path.insert(0, p)
+import numpy as np, torch
+import oracle
+from pydrobert_amd import functional as F, switches
+dev = "cuda"
+rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
+t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
+V, K = 256, 16
+n = bad = vs_oracle = bad_oracle = 0
+while time.time() < t_end:
+    n += 1
+    T, N = int(rng.choice([1, 2, 3, 5, 17, 64, 65, 130, 257])), int(rng.integers(1, 40))
+    kind = int(rng.integers(0, 7))
+    lg = rng.normal(size=(T, N, V + 1)).astype(np.float32) * float(rng.choice([1.0, 1.0, 3.0]))
+    peak = rng.integers(0, V + 1, (T, N, 1))
+    if kind == 3:
+        peak = np.where(rng.random((T, N, 1)) < 0.9, V, peak)  # blank-dominated
+    np.put_along_axis(lg, peak, float(rng.choice([0.0, 4.0, 8.0, 12.0, 20.0])), 2)
+    if kind == 0:
+        lg = np.round(lg * 2) / 2  # exact ties
+    elif kind == 1:
+        for _ in range(T * N // 3):
+            t, b = rng.integers(0, T), rng.integers(0, N)
+            i, j = rng.integers(0, V, 2)
+            lg[t, b, j] = lg[t, b, i]  # duplicated logits
+    elif kind == 2:
+        lg[:, :, rng.integers(0, V, int(rng.integers(1, 200)))] = -np.inf  # masked vocabulary
+    elif kind == 4:
+        lg[:, :, :V] -= 90.0 * (rng.random((T, N, V)) < 0.02)  # far-off elements: rows that are not tame
+    lens = None if rng.random() < 0.4 else torch.from_numpy(rng.integers(0, T + 1, N)).to(dev)
+    x = torch.from_numpy(lg).to(dev)
+    outs = []
+    for pair in (1, 0):
+        switches.set("PDT_CTC_PAIR", pair)
+        outs.append(F.ctc_prefix_search(x, K, lens))
+    if not all(torch.equal(a, b) for a, b in zip(*outs)):
+        bad += 1
+        print("MISMATCH pair/one-frame: case", n, "T", T, "N", N, "kind", kind, flush=True)
+    if kind >= 5 and n % 4 == 0:  # tie-free: against the oracle
+        vs_oracle += 1
+        ey, eyl, eyp = oracle.ctc_prefix_search(lg, K, None if lens is None else lens.cpu().numpy())
+        y, yl, yp = (o.cpu().numpy() for o in outs[0])
+        fin = np.isfinite(eyp)
+        # (masses that have underflowed to 0 all tie -- the reference's topk leaves them where they fall --
+        #  and two entries whose masses agree to ~1e-6 may swap: the known classes; compare what is decided)
+        decided = fin & (eyp > 0)
+        same = np.array_equal(yl[fin], eyl[fin]) and np.array_equal(y, ey)
+        if not same:
+            srt = lambda a: np.sort(np.where(decided, a, 0), 1)
+            close = np.allclose(srt(yp), srt(eyp), rtol=1e-4, atol=0)
+            gaps = np.abs(np.diff(np.sort(np.where(decided, eyp, 0).astype(np.float64), 1), axis=1)) / np.maximum(np.sort(eyp, 1)[:, 1:], 1e-300)
+            near_tie = bool((gaps[np.sort(decided, 1)[:, 1:]] < 1e-5).any()) or not decided.all()
+            if not (close and near_tie):
+                bad_oracle += 1
+                print("MISMATCH oracle: case", n, "T", T, "N", N, "kind", kind, "sorted masses close:", close, flush=True)
+        elif decided.any() and np.abs(np.log(yp[decided].astype(np.float64)) - np.log(eyp[decided].astype(np.float64))).max() > 3e-5:
+            bad_oracle += 1
+            print("MISMATCH oracle probabilities: case", n, flush=True)
+switches.set("PDT_CTC_PAIR", 1)
+print("fuzz_pair: %d cases, %d pair / one-frame mismatches; %d against the oracle, %d mismatches outside the near-tie / underflow classes" % (n, bad, vs_oracle, bad_oracle))

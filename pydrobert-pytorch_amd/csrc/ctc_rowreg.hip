@@ -27,6 +27,10 @@
 #include "ctc_ring.hpp"
 #include "switches.hpp"
 
+#ifndef PDT_ROWREG_GUESS_MARGIN  // (a variant build with a huge one sends every guessed row down the
+#define PDT_ROWREG_GUESS_MARGIN 0x1p-16f  // margin-failure path: profiles/tools/dump_rowreg.py compares)
+#endif
+
 namespace pdt {
 
 struct RowregLayout {
@@ -182,6 +186,8 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
         tq = lmx_mean + thr_off;
         count = collect(tq);
         guessed = count >= M && count <= PDT_SURV_CAP;
+        // keep the survivor count around three quarters of the buffer
+        if (guessed) thr_off += count > 52 ? 0.05f : (count < M + 8 ? -0.05f : 0.0f);
       }
       if (!guessed) {
         const unsigned sorted_max = wave_sort_desc<unsigned>(fkey(lmx));
@@ -232,29 +238,24 @@ ctc_rowreg_kernel(const CtcArgs a, const RowregLayout rl) {
       // ---- the sorted list: survivors ranked by (numerator key, token) -----------------------
       wave_sync();
       u64 tk = 0ull;
-      if (count <= PDT_SURV_CAP) {
-        u64 rec = lp < count ? surv[lp] : 0ull;
-        if (guessed) {
-          // M survivors must clear the guessed threshold by the margin (a token just below the threshold
-          // could otherwise tie with the M-th best in the numerator) -- else the exact threshold, once more
-          const float xm = lp < count ? __uint_as_float((unsigned)(rec >> 32)) : -PDT_INF;
-          if (__popcll(__ballot(xm - tq >= fmaxf(margin_of, fabsf(xm) * 0x1p-20f))) < M) {
-            const unsigned sorted_max = wave_sort_desc<unsigned>(fkey(lmx));
-            const float tau_x = fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1));
-            tq = tau_x - fmaxf(margin_of, fabsf(tau_x) * 0x1p-20f);
-            count = collect(tq);
-            rec = (count <= PDT_SURV_CAP && lp < count) ? surv[lp] : 0ull;
-            guessed = false;
-          }
-          // keep the survivor count around three quarters of the buffer
-          thr_off += count > 52 ? 0.05f : (count < M + 8 ? -0.05f : 0.0f);
-        }
-        if (count <= PDT_SURV_CAP) {
-          const unsigned key = fkey_nonneg(exp_nonpos(__uint_as_float((unsigned)(rec >> 32)) - mx));
-          tk = wave_sort_desc<u64>(lp < count ? pack_key(key, (unsigned)rec) : 0ull);
+      if (count <= PDT_SURV_CAP && guessed) {
+        // M survivors must clear the guessed threshold by the margin (a token just below the threshold
+        // could otherwise tie with the M-th best in the numerator).  Checked on the survivor RECORDS --
+        // the registers hold the next row by now (a round-5 fuzz run caught a redo of pass B here
+        // reading them) -- and a failure, rare as it is, takes the path that reads the row again:
+        // every token, the chunked merge below
+        const float xm = lp < count ? __uint_as_float((unsigned)(surv[lp] >> 32)) : -PDT_INF;
+        if (__popcll(__ballot(xm - tq >= fmaxf(PDT_ROWREG_GUESS_MARGIN, fabsf(xm) * 0x1p-20f))) < M) {
+          count = PDT_SURV_CAP + 1;
+          tq = -PDT_INF;
+          thr_off -= 0.1f;
         }
       }
-      if (count > PDT_SURV_CAP) {
+      if (count <= PDT_SURV_CAP) {
+        const u64 rec = lp < count ? surv[lp] : 0ull;
+        const unsigned key = fkey_nonneg(exp_nonpos(__uint_as_float((unsigned)(rec >> 32)) - mx));
+        tk = wave_sort_desc<u64>(lp < count ? pack_key(key, (unsigned)rec) : 0ull);
+      } else {
         // heavy ties / clustered values: chunked top-64 merge.  Rare, and a register file cannot be
         // indexed by a loop counter: the row is read again (L2)
         const float *row = a.logits + (int64_t)t * a.lg_st + n * a.lg_sn;
