@@ -351,7 +351,7 @@ def other_configs(F, M, device, world, rank, dist, gather_check, say=lambda msg:
     ms = event_ms(lambda: F.beam_search_advance(lpt, K, lpp, yb, ybl))
     out["C3_beam_search_advance"] = {"workload": "one step, N=1024 K=16 V=1000 S=100", "ms": ms,
                                      "roofline": roof((4 * K * V + 8 * S * K + 8 * (S + 1) * K + 4 * 8 * K) * N, ms,
-                                                      "pdt::beam_advance_kernel")}
+                                                      "pdt::beam_advance_flat_kernel")}
     del lg, lpt, yb, step_args
     # C4: SpecAugment N=2048 x 1000 x 80
     N, T, Fq = 2048, 1000, 80
@@ -635,7 +635,7 @@ def lm_configs(F, M, device, args, ref, hyp, say=lambda msg: None):
         "table_build_ms": table_ms,
         "table_build_note": "the model's dense (context, token) table + row statistics, built once per model (not in `ms`)",
         "row_bytes_from_cache": 4.0 * N3 * K * V3 * 100,
-        "roofline": roof(hist_bytes + 4 * (V3 + 1) * V3, ms, "pdt::beam_step_kernel (table form)",
+        "roofline": roof(hist_bytes + 4 * (V3 + 1) * V3, ms, "pdt::beam_step_flat_kernel (table form)",
                          "HBM bytes = the history copies + one read of the table; 6.5 GB of score rows come from the "
                          "table in cache and are not HBM traffic: the loop is bound by the step kernel's latency"),
     }

@@ -280,9 +280,9 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
  *   has_eos / eos in [0, V); finish_all_paths; pad_value (written clamped, see pad_from).
  *   y_next (S + 1, N, width) int64 contiguous, y_next_lens / next_src (N, width) int64,
  *   log_probs_next (N, width) float32.
- *   active [1] int32: incremented once per batch element that was NOT finished at the start of this
+ *   active [1] int32: set to 1 if some batch element was NOT finished at the start of this
  *   iteration (the caller zeroes it; reading 0 means the reference would have left its loop before
- *   this iteration -- every later row of y is padding).
+ *   this iteration -- every later row of y is padding).  A flag, not a count: plain stores.
  *   pad_from (N,) int32, INT32_MAX initially: the first row of y that is padding for a finished
  *   element; the caller writes pad_value into rows >= pad_from[n] at the end.
  *   width, Kp <= 64.

@@ -72,7 +72,7 @@ summary("pmc_warp", "sparse_warp_bands", "r05_sparse_warp.json",
         {"config": {"N": 2048, "C": 1, "H": 1000, "W": 80, "centres": 7, "order": 2},
          "algorithmic_bytes_per_launch": 2 * 4 * 2048 * 1000 * 80})
 S = 100
-summary("pmc_beam_advance", "beam_advance_kernel", "r05_advance_beam.json",
+summary("pmc_beam_advance", "beam_advance_flat_kernel", "r05_advance_beam.json",
         {"config": {"N": 1024, "K": 16, "V": 1000, "S": S}, "algorithmic_bytes_per_launch": (4 * 16 * 1000 + 8 * S * 16 + 8 * (S + 1) * 16 + 4 * 8 * 16) * 1024})
 summary("pmc_ctc_advance", "ctc_advance_kernel", "r05_advance_ctc.json",
         {"config": {"N": 1024, "K": 16, "V": 1000, "S": S},

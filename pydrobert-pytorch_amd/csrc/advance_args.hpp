@@ -22,6 +22,7 @@ struct CtcAdvArgs {
   uint8_t *next_isp;                              // (N, W, W)
   uint8_t *next_nonext;                           // (N, W)
   int frame_bytes, waves_per_wg;  // LDS of the frame routine (the per-wave survivor scratch follows it)
+  int ext_shared;                 // ext_sk == 0: every prefix reads the same row of extension probabilities
 };
 
 struct BeamAdvArgs {

@@ -11,6 +11,10 @@
 #include "ctc_frame.hpp"
 #include "switches.hpp"
 
+#ifndef PDT_ADV_PHASES  // (diagnostic builds: 1 = stop after the per-prefix lists, 2 = before the history copy)
+#define PDT_ADV_PHASES 0
+#endif
+
 namespace pdt {
 
 // One WORKGROUP per batch element (a.waves_per_wg waves).  The Kp per-prefix selections over the
@@ -30,7 +34,10 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
   u64 *my_surv = reinterpret_cast<u64 *>(smem + a.frame_bytes) + (size_t)wave * PDT_SURV_CAP;
 
   const int M = ctc_list_len(V, W, Kp);
-  for (int k = wave; k < Kp; k += NW) {
+  // (prefixes that share ONE row of extension probabilities -- the search without a language model hands
+  // over nonext.unsqueeze(1).expand(N, K', V), stride 0 -- share one list: built once, copied below)
+  const int n_lists = a.ext_shared ? 1 : Kp;
+  for (int k = wave; k < n_lists; k += NW) {
     // (rows of 513 .. 1024 elements are read once, into 16 registers per lane: 0.056 -> 0.047 ms at
     // V = 1000; shorter rows measured no better that way, longer ones are streamed twice)
     const float *xk = a.ext + n * a.ext_sn + k * a.ext_sk;
@@ -45,6 +52,16 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
   for (int v = (int)threadIdx.x; v < V; v += NW * PDT_WAVE) p[v] = a.nonext[n * a.ne_sn + v * a.ne_sv];
   if (threadIdx.x == 0) p[V] = a.blank[n * a.bl_sn];
   __syncthreads();
+  if (n_lists < Kp) {
+    for (int idx = PDT_WAVE + (int)threadIdx.x; idx < Kp * PDT_WAVE; idx += NW * PDT_WAVE) {
+      L.tl_tok[idx] = L.tl_tok[idx & (PDT_WAVE - 1)];
+      L.tl_p[idx] = L.tl_p[idx & (PDT_WAVE - 1)];
+    }
+    __syncthreads();
+  }
+#if PDT_ADV_PHASES == 1
+  return;
+#endif
 
   DenseCtx dc;
   dc.ext = a.ext + n * a.ext_sn;
@@ -93,6 +110,9 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
     }
   }
   __syncthreads();
+#if PDT_ADV_PHASES == 2
+  return;
+#endif
   // history rows of the source prefix, below the position just written
   for (int idx = (int)threadIdx.x; idx < (S + 1) * W; idx += NW * PDT_WAVE) {
     const int s = idx / W, i = idx - s * W;
@@ -119,6 +139,7 @@ int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
   if (smem > 160 * 1024) return PDT_E_TOO_LONG;
   a.waves_per_wg = nw;
   a.frame_bytes = (int)frame;
+  a.ext_shared = (a.Kp > 1 && a.ext_sk == 0 && switches().step_flat != 0) ? 1 : 0;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_advance_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -166,6 +187,9 @@ __global__ void __launch_bounds__(512, 8) beam_advance_kernel(const BeamAdvArgs 
     wave_sync();
   }
   __syncthreads();
+#if PDT_ADV_PHASES == 1
+  return;
+#endif
   if (wave == 0) {
     const bool live = lane < Kp;
     const int *mytl = tl + (live ? lane : 0) * PDT_WAVE;
@@ -203,7 +227,184 @@ __global__ void __launch_bounds__(512, 8) beam_advance_kernel(const BeamAdvArgs 
     }
   }
   __syncthreads();
+#if PDT_ADV_PHASES == 2
+  return;
+#endif
   for (int idx = (int)threadIdx.x; idx < a.S_out * W; idx += NW * PDT_WAVE) {
+    const int s = idx / W, i = idx - s * W;
+    const int src = srcs[i];
+    const int pl = plens[i];
+    int64_t v;
+    if (src < 0)
+      v = 0;
+    else if (s == pl || s >= S)  // :130/:135 the appended token row, :137 the scatter
+      v = toks[i];
+    else
+      v = a.y_prev[(int64_t)s * a.yp_ss + n * a.yp_sn + src * a.yp_sk];
+    a.y_next[((int64_t)s * a.N + n) * W + i] = v;
+  }
+}
+
+// -------------------------------------------------------------------------------------------
+// The FLAT form (round 5), for dense log_probs_t (the K' * V candidates of a batch element contiguous):
+// the K winners are the K largest of ALL the candidates -- no per-prefix lists (sixteen 64-key sorts +
+// sixteen survivor sorts per batch element: the lists were 26 of the kernel's 35 us, vector-issue bound).
+// The candidates sit in the registers of the element's eight waves, flat index f = k * V + v = 64 * chunk +
+// lane, up to kFlatRegs chunks per wave, every load in flight at once:
+//   1. per-lane maxima -> one "column" maximum per lane over the eight waves (LDS); the K-th largest of
+//      the 64 columns is a lower bound tau of the K-th largest candidate (wave 0: one 64-key sort);
+//   2. every wave appends its candidates >= tau to ONE survivor list (LDS cursor), typically K .. K + 4;
+//   3. wave 0 sorts them by (sum, lowest flat index first): lane i holds winner i.
+// Fewer than K columns with a finite maximum (tau = -inf: finished beams, whose rows are -inf but for one
+// token): the survivors are the finite candidates, and -inf candidates fill the rest in flat order, as the
+// lists did.  More survivors than the list holds (top candidates crowding a few lanes): every candidate
+// again from memory through the chunked top-64 merge.  Same winners, same order, same bits as the list form.
+constexpr int kFlatWaves = 8, kFlatRegs = 32;
+
+__global__ void __launch_bounds__(64 * kFlatWaves, 6) beam_advance_flat_kernel(const BeamAdvArgs a) {
+  __shared__ unsigned colmax[kFlatWaves * PDT_WAVE];
+  __shared__ u64 surv[PDT_SURV_CAP];
+  __shared__ unsigned ctl[4];  // [0] the threshold (float bits), [1] the survivor cursor
+  __shared__ int srcs[PDT_WAVE], toks[PDT_WAVE], plens[PDT_WAVE];
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: so is everything derived)
+  const int64_t n = blockIdx.x;
+  const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
+  const int K = min(W, (int)min((int64_t)Kp * V, (int64_t)PDT_WAVE));  // :121
+  const int FV = Kp * V, total = (FV + PDT_WAVE - 1) >> 6;
+  const int per = (total + kFlatWaves - 1) / kFlatWaves;  // chunks per wave, <= kFlatRegs (the launcher)
+  const float *lpt = a.lpt + n * a.lt_sn;
+  if (threadIdx.x == 0) ctl[1] = 0u;
+  // log_probs_prev of prefix k in lane k (K' <= 64): a candidate's addend is one permute away
+  const float bias_v = lane < Kp ? a.lpp[n * a.lp_sn + lane * a.lp_sk] : 0.0f;
+
+  // ---- 1. the candidates, (log_probs_prev[k] + log_probs_t[k, v]) + 0 (:122; + 0.0f: the two zeros tie)
+  const int c0 = wave * per;
+  const int f0 = c0 * PDT_WAVE + lane;
+  float x[kFlatRegs];
+#pragma unroll
+  for (int j = 0; j < kFlatRegs; ++j) {
+    x[j] = -PDT_INF;  // (beyond the candidates: never a survivor, see the threshold below)
+    if (j < per) {
+      if ((c0 + j + 1) * PDT_WAVE <= FV)
+        x[j] = lpt[f0 + j * PDT_WAVE];
+      else if ((c0 + j) * PDT_WAVE < FV && f0 + j * PDT_WAVE < FV)
+        x[j] = lpt[f0 + j * PDT_WAVE];
+    }
+  }
+  // (every load in flight before the first is used: the sums in a second loop; a lane's prefix k moves on
+  // by at most one per chunk, V > 64)
+  float lmax = -PDT_INF;
+  {
+    int k = f0 / V, v = f0 - k * V;
+#pragma unroll
+    for (int j = 0; j < kFlatRegs; ++j) {
+      if ((j & 7) == 0) __builtin_amdgcn_sched_barrier(0);  // (eight permutes ahead at most: registers)
+      x[j] = (shfl_f(bias_v, k) + x[j]) + 0.0f;
+      lmax = fmaxf(lmax, x[j]);
+      v += PDT_WAVE;
+      const bool wrap = v >= V;
+      v -= wrap ? V : 0;
+      k += wrap ? 1 : 0;
+    }
+  }
+  colmax[wave * PDT_WAVE + lane] = fkey(lmax);
+  __syncthreads();
+#if PDT_ADV_PHASES == 1
+  if (lmax != 12345.0f) return;
+#endif
+  if (wave == 0) {
+    unsigned cm = colmax[lane];
+#pragma unroll
+    for (int w = 1; w < kFlatWaves; ++w) cm = max(cm, colmax[w * PDT_WAVE + lane]);
+    const unsigned sorted_max = wave_sort_desc<unsigned>(cm);
+    // x >= the lowest finite float <=> x > -inf: the padding and the -inf candidates stay out
+    const float tau = fmaxf(fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, K - 1)), -3.4028234664e38f);
+    if (lane == 0) ctl[0] = __float_as_uint(tau);
+  }
+  __syncthreads();
+  // ---- 2. survivors ------------------------------------------------------------------------
+  const float tau = __uint_as_float(ctl[0]);
+#if PDT_ADV_PHASES == 3
+  if (tau != 12345.0f) return;
+#endif
+  if (__ballot(lmax >= tau)) {
+#pragma unroll
+    for (int j = 0; j < kFlatRegs; ++j) {
+      const bool pred = x[j] >= tau;
+      if (__ballot(pred)) {
+        if (pred) {
+          const unsigned at = atomicAdd(&ctl[1], 1u);
+          if (at < PDT_SURV_CAP) surv[at] = pack_key(fkey(x[j]), (unsigned)(f0 + j * PDT_WAVE));
+        }
+      }
+    }
+  }
+  __syncthreads();
+#if PDT_ADV_PHASES == 4
+  return;
+#endif
+  // ---- 3. the winners in order ---------------------------------------------------------------
+  if (wave == 0) {
+    const int count = (int)ctl[1];
+    u64 tk = 0ull;
+    int filled = 0;  // winners that are in tk
+    if (count <= PDT_SURV_CAP) {
+      tk = wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
+      filled = min(count, K);
+    } else {
+      // every candidate, -inf ones included, from memory
+      for (int g0 = 0; g0 < FV; g0 += PDT_WAVE) {
+        const int f = g0 + lane;
+        const float xv = f < FV ? (a.lpp[n * a.lp_sn + (f / V) * a.lp_sk] + lpt[f]) + 0.0f : 0.0f;
+        tk = wave_merge_top64(tk, f < FV ? pack_key(fkey(xv), (unsigned)f) : 0ull);
+      }
+      filled = K;
+    }
+    const int flat = (int)idx_of(tk);
+    int new_src = flat / V, new_tok = flat - new_src * V;
+    float new_lp = fkey_inv(key_of(tk));
+    if (filled < K) {
+      // tau = -inf and fewer than K finite candidates: -inf candidates in flat order behind them
+      int have = filled;
+      for (int g0 = 0; g0 < FV && have < K; g0 += PDT_WAVE) {
+        const int f = g0 + lane;
+        const int k = f / V;
+        const bool is = f < FV && (a.lpp[n * a.lp_sn + k * a.lp_sk] + lpt[f]) + 0.0f == -PDT_INF;
+        const u64 b = __ballot(is);
+        const int rank = have + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+        // winner number `rank` is this lane's candidate: hand it to lane `rank`
+        if (is && rank < K) {
+          srcs[rank] = k;
+          toks[rank] = f - k * V;
+        }
+        have += __popcll(b);
+      }
+      wave_sync();
+      if (lane >= filled && lane < K) {
+        new_src = srcs[lane];
+        new_tok = toks[lane];
+        new_lp = -PDT_INF;
+      }
+      wave_sync();
+    }
+    if (lane < W) {
+      const bool valid = lane < K;
+      const int plen = valid ? (a.lens ? (int)a.lens[n * a.le_sn + new_src * a.le_sk] : S) : -1;
+      a.lp_next[n * W + lane] = valid ? new_lp : -PDT_INF;  // :145-153 for the overflow
+      a.next_src[n * W + lane] = valid ? new_src : 0;
+      a.y_next_lens[n * W + lane] = valid ? plen + 1 : 0;
+      srcs[lane] = valid ? new_src : -1;
+      toks[lane] = new_tok;
+      plens[lane] = plen;
+    }
+  }
+  __syncthreads();
+#if PDT_ADV_PHASES == 2
+  return;
+#endif
+  for (int idx = (int)threadIdx.x; idx < a.S_out * W; idx += kFlatWaves * PDT_WAVE) {
     const int s = idx / W, i = idx - s * W;
     const int src = srcs[i];
     const int pl = plens[i];
@@ -222,6 +423,12 @@ int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
   const bool force_wide = switches().step_wide != 0;
   if (force_wide || a.W > PDT_WAVE || a.Kp > PDT_WAVE) return launch_beam_advance_wide(a, stream);  // (advance_wide.hip)
+  const int64_t cands = (int64_t)a.Kp * a.V;
+  if (switches().step_flat != 0 && a.V > PDT_WAVE && a.lt_sv == 1 && a.lt_sk == a.V &&
+      cands <= (int64_t)kFlatWaves * kFlatRegs * PDT_WAVE) {
+    hipLaunchKernelGGL(beam_advance_flat_kernel, dim3((unsigned)a.N), dim3(64 * kFlatWaves), 0, stream, a);
+    return (int)hipGetLastError();
+  }
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   const size_t smem = ((size_t)nw * PDT_SURV_CAP * 8 + (size_t)a.Kp * PDT_WAVE * 8 + (size_t)a.W * 12 + 15) & ~(size_t)15;

@@ -18,6 +18,7 @@
 // One workgroup per batch element, as beam_advance_kernel: the waves take the prefixes' selections
 // in turn, wave 0 merges, all waves copy the history.  Ties: lowest flat index k * V + v.
 #include "ctc_frame.hpp"
+#include "switches.hpp"
 
 namespace pdt {
 
@@ -32,7 +33,7 @@ struct BeamStepArgs {
   int64_t *y_next;                   // (S + 1, N, W)
   int64_t *y_next_lens, *next_src;   // (N, W)
   float *lp_next;                    // (N, W)
-  int32_t *active;                   // [1]: += batch elements NOT finished at the start of this iteration
+  int32_t *active;                   // [1]: set to 1 when some batch element was NOT finished at the start of this iteration
   int32_t *pad_from;                 // (N,): first row of y that is padding (INT32_MAX: none yet)
   int waves_per_wg;
   // table form (pdt_beam_search_step_table): the scores of prefix (n, k) are row rows[n * Kp + k] of
@@ -125,7 +126,9 @@ __global__ void __launch_bounds__(512) beam_step_kernel(const BeamStepArgs a) {
     }
     return;
   }
-  if (threadIdx.x == 0) atomicAdd(a.active, 1);
+  // (a flag, not a count: a thousand atomic increments of one word are ~15 us of memory-side
+  // serialisation per launch -- round 5; the host only asks whether it is zero)
+  if (threadIdx.x == 0 && *(volatile int32_t *)a.active == 0) *(volatile int32_t *)a.active = 1;
 
   // ---- per-prefix lists of the best tokens, ranked by the candidate value itself ------------------
   // log_probs_prev[k] + log_softmax(scores[k])[v] (:441, :122); an ended path offers eos alone, at
@@ -217,6 +220,238 @@ __global__ void __launch_bounds__(512) beam_step_kernel(const BeamStepArgs a) {
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// The FLAT form (round 5; beam_advance.hip's beam_advance_flat_kernel has the argument), for the table
+// route: the K winners are the K largest of ALL the candidates -- no sorted list per prefix.  The rows of
+// the K' prefixes are separate rows of the model's table, so the 64-token chunks are numbered row by row,
+// c = k * ceil(V / 64) + chunk, up to kStepFlatRegs per wave; an ended path offers eos alone (:448-458).
+//   1. per-lane maxima -> one "column" maximum per lane over the eight waves; the K-th largest of the 64
+//      is a lower bound tau of the K-th largest candidate;
+//   2. every wave appends its candidates >= tau to one survivor list (LDS cursor);
+//   3. wave 0 sorts them by (value, lowest k * V + v first): lane i holds winner i.
+// tau = -inf (fewer than K columns with a finite maximum: most paths ended): the survivors are the finite
+// candidates, -inf ones of paths that have not ended fill up in flat order.  A survivor list that overflows:
+// every candidate again, from memory, through the chunked top-64 merge.  Same results as the list form.
+constexpr int kStepFlatWaves = 8, kStepFlatRegs = 32;
+
+__global__ void __launch_bounds__(64 * kStepFlatWaves, 6) beam_step_flat_kernel(const BeamStepArgs a) {
+  __shared__ unsigned colmax[kStepFlatWaves * PDT_WAVE];
+  __shared__ u64 surv[PDT_SURV_CAP];
+  __shared__ unsigned ctl[4];  // [0] the threshold (float bits), [1] the survivor cursor
+  __shared__ int srcs[PDT_WAVE], toks[PDT_WAVE], plens[PDT_WAVE];
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (scalar: so is everything derived)
+  const int64_t n = blockIdx.x;
+  const int V = a.V, W = a.W, Kp = a.Kp, S = a.S;
+  const int K = min(W, (int)min((int64_t)Kp * V, (int64_t)PDT_WAVE));  // :121
+  if (threadIdx.x == 0) ctl[1] = 0u;
+
+  // Two round trips to memory before the arithmetic, not five: what a chunk needs of its prefix k is
+  // fetched by lane k of EVERY wave (the same few words: cache hits) -- length, table row, addend first;
+  // then, together, the token that tells whether the path has ended (:413-420), the row's statistics and
+  // the wave's chunks of the rows themselves (an ended path's are fetched for nothing).
+  const int len_v = lane < Kp ? (int)a.lens[n * a.le_sn + lane * a.le_sk] : 0;
+  const int64_t r_v = lane < Kp ? a.rows[n * Kp + lane] : 0;
+  const float bias_v = lane < Kp ? a.lpp[n * a.lp_sn + lane * a.lp_sk] : 0.0f;
+  const bool may_end = lane < Kp && a.has_eos && S > 0 && len_v > 0;
+  const int64_t last_tok = may_end ? a.y_prev[(int64_t)(len_v - 1) * a.yp_ss + n * a.yp_sn + lane * a.yp_sk] : -1;
+  const float mx_v = lane < Kp ? a.row_stats[2 * r_v] : 0.0f;
+  const float lse_v = lane < Kp ? a.row_stats[2 * r_v + 1] : 0.0f;
+  const unsigned r_lo = (unsigned)r_v, r_hi = (unsigned)((u64)r_v >> 32);
+  const int eos = (int)a.eos;
+  const int CH = (V + PDT_WAVE - 1) >> 6, total = Kp * CH;
+  const int per = (total + kStepFlatWaves - 1) / kStepFlatWaves;  // chunks per wave, <= kStepFlatRegs (the launcher)
+  const int c0 = wave * per;
+  const int k0 = c0 / CH, ci0 = c0 - k0 * CH;
+  float x[kStepFlatRegs];
+  {
+    int k = k0, ci = ci0;
+#pragma unroll
+    for (int j = 0; j < kStepFlatRegs; ++j) {
+      x[j] = -PDT_INF;  // (beyond a row, beyond the candidates: never a survivor, see the threshold below)
+      if (j < per && c0 + j < total) {
+        const u64 r = ((u64)(unsigned)__builtin_amdgcn_readlane((int)r_hi, k) << 32) |
+                      (unsigned)__builtin_amdgcn_readlane((int)r_lo, k);
+        const float *row = a.scores + (int64_t)r * a.sc_sk;
+        const int v = ci * PDT_WAVE + lane;
+        if (ci + 1 < CH || v < V) x[j] = row[v];
+        if (++ci == CH) ci = 0, ++k;
+      }
+    }
+  }
+  const u64 ended_mask = __ballot(may_end && last_tok == a.eos);
+
+  // ---- is this element finished (:421-424) -----------------------------------------------------
+  bool done = false;
+  if (a.has_eos && S > 0) {
+    const u64 all = Kp >= 64 ? ~0ull : ((1ull << Kp) - 1ull);
+    done = a.finish_all ? (ended_mask & all) == all : (ended_mask & 1ull) != 0;
+  }
+  if (done) {
+    // the beam it had, brought to `width` (:479-486; K' == width from the second iteration on),
+    // one more row of padding
+    if (threadIdx.x == 0 && a.pad_from[n] > S) a.pad_from[n] = S;
+    for (int i = (int)threadIdx.x; i < W; i += kStepFlatWaves * PDT_WAVE) {
+      const bool has = i < Kp;
+      a.lp_next[n * W + i] = has ? a.lpp[n * a.lp_sn + i * a.lp_sk] : -PDT_INF;
+      a.y_next_lens[n * W + i] = has ? a.lens[n * a.le_sn + i * a.le_sk] : 0;
+      a.next_src[n * W + i] = has ? i : 0;
+    }
+    for (int idx = (int)threadIdx.x; idx < (S + 1) * W; idx += kStepFlatWaves * PDT_WAVE) {
+      const int s = idx / W, i = idx - s * W;
+      int64_t v = 0;
+      if (s == S)
+        v = a.pad_clamped;
+      else if (i < Kp)
+        v = a.y_prev[(int64_t)s * a.yp_ss + n * a.yp_sn + i * a.yp_sk];
+      a.y_next[((int64_t)s * a.N + n) * W + i] = v;
+    }
+    return;
+  }
+  // (a flag, not a count: the host only asks whether it is zero, and a thousand atomic increments of one
+  // word serialise)
+  if (threadIdx.x == 0 && *(volatile int32_t *)a.active == 0) *(volatile int32_t *)a.active = 1;
+
+  // ---- 1. the candidates: log_probs_prev[k] + log_softmax(scores[k])[v] (:441, :122) -----------------
+  // (every load in flight before the first is used: the values are formed in a second loop)
+  float lmax = -PDT_INF;
+  {
+    int k = k0, ci = ci0;
+#pragma unroll
+    for (int j = 0; j < kStepFlatRegs; ++j) {
+      if (j < per && c0 + j < total) {
+        const float bias = readlane_f(bias_v, k);
+        const int v = ci * PDT_WAVE + lane;
+        if ((ended_mask >> k) & 1ull) {
+          x[j] = v == eos ? (bias + 0.0f) + 0.0f : -PDT_INF;  // eos alone, at no cost (:448-458)
+        } else {
+          const float val = (bias + ((x[j] - readlane_f(mx_v, k)) - readlane_f(lse_v, k))) + 0.0f;
+          x[j] = (ci + 1 < CH || v < V) ? val : -PDT_INF;
+        }
+        lmax = fmaxf(lmax, x[j]);
+        if (++ci == CH) ci = 0, ++k;
+      }
+    }
+  }
+  colmax[wave * PDT_WAVE + lane] = fkey(lmax);
+  __syncthreads();
+  if (wave == 0) {
+    unsigned cm = colmax[lane];
+#pragma unroll
+    for (int w = 1; w < kStepFlatWaves; ++w) cm = max(cm, colmax[w * PDT_WAVE + lane]);
+    const unsigned sorted_max = wave_sort_desc<unsigned>(cm);
+    // x >= the lowest finite float <=> x > -inf: the padding and the -inf candidates stay out
+    const float tau = fmaxf(fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, K - 1)), -3.4028234664e38f);
+    if (lane == 0) ctl[0] = __float_as_uint(tau);
+  }
+  __syncthreads();
+  // ---- 2. survivors ------------------------------------------------------------------------
+  const float tau = __uint_as_float(ctl[0]);
+  if (__ballot(lmax >= tau)) {
+#pragma unroll
+    for (int j = 0; j < kStepFlatRegs; ++j) {
+      const bool pred = x[j] >= tau;
+      if (__ballot(pred)) {
+        const int c = c0 + j, k = c / CH, ci = c - k * CH;
+        if (pred) {
+          const unsigned at = atomicAdd(&ctl[1], 1u);
+          if (at < PDT_SURV_CAP) surv[at] = pack_key(fkey(x[j]), ((unsigned)k << 20) | (unsigned)(ci * PDT_WAVE + lane));
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 3. the winners in order ---------------------------------------------------------------
+  if (wave == 0) {
+    const int count = (int)ctl[1];
+    auto value_at = [&](const int k, const int v) {  // candidate (k, v) of a path that has not ended, from memory
+      const int64_t r = a.rows[n * Kp + k];
+      return (a.lpp[n * a.lp_sn + k * a.lp_sk] + ((a.scores[r * a.sc_sk + v] - a.row_stats[2 * r]) - a.row_stats[2 * r + 1])) + 0.0f;
+    };
+    u64 tk = 0ull;
+    int have = 0;  // winners that are in tk
+    if (count <= PDT_SURV_CAP) {
+      tk = wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
+      have = min(count, K);
+    } else {
+      // every candidate, -inf ones included, from memory
+      int cands = 0;
+      for (int k = 0; k < Kp; ++k) {
+        if ((ended_mask >> k) & 1ull) {
+          const float xv = (a.lpp[n * a.lp_sn + k * a.lp_sk] + 0.0f) + 0.0f;
+          tk = wave_merge_top64(tk, lane == 0 ? pack_key(fkey(xv), ((unsigned)k << 20) | (unsigned)eos) : 0ull);
+          cands += 1;
+        } else {
+          for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
+            const int v = v0 + lane;
+            const float xv = v < V ? value_at(k, v) : 0.0f;
+            tk = wave_merge_top64(tk, v < V ? pack_key(fkey(xv), ((unsigned)k << 20) | (unsigned)v) : 0ull);
+          }
+          cands += V;
+        }
+      }
+      have = min(cands, K);
+    }
+    int new_src = (int)(idx_of(tk) >> 20), new_tok = (int)(idx_of(tk) & 0xfffffu);
+    float new_lp = fkey_inv(key_of(tk));
+    if (have < K && count <= PDT_SURV_CAP) {
+      // tau = -inf and fewer than K finite candidates: -inf candidates of the paths that have not ended, in
+      // flat order, behind them
+      const int filled = have;
+      for (int k = 0; k < Kp && have < K; ++k) {
+        if ((ended_mask >> k) & 1ull) continue;
+        for (int v0 = 0; v0 < V && have < K; v0 += PDT_WAVE) {
+          const int v = v0 + lane;
+          const bool is = v < V && value_at(k, v) == -PDT_INF;
+          const u64 b = __ballot(is);
+          const int rank = have + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+          if (is && rank < K) {  // winner number `rank`: handed to lane `rank`
+            srcs[rank] = k;
+            toks[rank] = v;
+          }
+          have += __popcll(b);
+        }
+      }
+      have = min(have, K);
+      wave_sync();
+      if (lane >= filled && lane < have) {
+        new_src = srcs[lane];
+        new_tok = toks[lane];
+        new_lp = -PDT_INF;
+      }
+      wave_sync();
+    }
+    const int src_len = shfl_i(len_v, new_src);  // (the lengths are in lane k since the start; every lane takes part)
+    if (lane < W) {
+      const bool valid = lane < have;
+      const int plen = valid ? src_len : -1;
+      const int grew = valid ? 1 - (int)((ended_mask >> (new_src & 63)) & 1ull) : 0;  // ended sources stay as long as they were (:465-468)
+      a.lp_next[n * W + lane] = valid ? new_lp : -PDT_INF;  // :145-153 for the overflow
+      a.next_src[n * W + lane] = valid ? new_src : 0;
+      a.y_next_lens[n * W + lane] = valid ? plen + grew : 0;
+      srcs[lane] = valid ? new_src : -1;
+      toks[lane] = new_tok;
+      plens[lane] = plen;
+    }
+  }
+  __syncthreads();
+  for (int idx = (int)threadIdx.x; idx < (S + 1) * W; idx += kStepFlatWaves * PDT_WAVE) {
+    const int s = idx / W, i = idx - s * W;
+    const int src = srcs[i];
+    const int pl = plens[i];
+    int64_t v;
+    if (src < 0)
+      v = 0;
+    else if (s == pl || s >= S)  // :130/:135 the appended token row, :137 the scatter
+      v = toks[i];
+    else
+      v = a.y_prev[(int64_t)s * a.yp_ss + n * a.yp_sn + src * a.yp_sk];
+    a.y_next[((int64_t)s * a.N + n) * W + i] = v;
+  }
+}
+
 }  // namespace pdt
 
 namespace pdt {
@@ -261,6 +496,11 @@ static int beam_step_entry(const float *scores, int64_t sc_sn, int64_t sc_sk, in
   a.pad_clamped = pad_value < 0 ? 0 : (pad_value > V - 1 ? V - 1 : pad_value);
   a.y_next = y_next; a.y_next_lens = y_next_lens; a.lp_next = log_probs_next; a.next_src = next_src;
   a.active = active; a.pad_from = pad_from;
+  if (switches().step_flat != 0 && rows && row_stats && sc_sv == 1 && V > PDT_WAVE && V < (1 << 20) &&
+      Kp * ((V + PDT_WAVE - 1) / PDT_WAVE) <= kStepFlatWaves * kStepFlatRegs) {
+    hipLaunchKernelGGL(beam_step_flat_kernel, dim3((unsigned)a.N), dim3(64 * kStepFlatWaves), 0, (hipStream_t)stream, a);
+    return (int)hipGetLastError();
+  }
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   a.waves_per_wg = nw;

@@ -469,7 +469,9 @@ __global__ void __launch_bounds__(256) spec_augment_rows_kernel(const SpecAugArg
       v.z = (keep & 4u) ? v.z : 0.0f;
       v.w = (keep & 8u) ? v.w : 0.0f;
     }
-    *reinterpret_cast<float4 *>(on + (int64_t)(t_begin + r) * a.F + 4 * f4) = v;
+    // (non-temporal: written once, never read here -- apply 0.30 -> 0.29 ms on the box that measured both)
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4 *>(on + (int64_t)(t_begin + r) * a.F + 4 * f4));
   }
 }
 

@@ -69,6 +69,7 @@ const SwitchName kSwitchNames[] = {
     {"PDT_LM_CACHE", &Switches::lm_cache, 0},           {"PDT_LM_PERSISTENT", &Switches::lm_persistent, 1},
     {"PDT_LM_STEP_WAVES", &Switches::lm_step_waves, 0}, {"PDT_WARP_BANDS", &Switches::warp_bands, 1},
     {"PDT_CTC_LEAN_EXTRA", &Switches::ctc_lean_extra, 1}, {"PDT_CTC_PAIR", &Switches::ctc_pair, 1},
+    {"PDT_STEP_FLAT", &Switches::step_flat, 1},
 };
 }  // namespace
 

@@ -20,6 +20,8 @@ struct Switches {
   int warp_bands;      // PDT_WARP_BANDS     1  sparse_image_warp: a lane = a column of four rows (0: four pixels 256 apart)
   int lm_step_waves;   // PDT_LM_STEP_WAVES  0  waves per utterance of the n-gram frame kernel (0: by shape; 1, 2, 4 or 8)
   int ctc_pair;        // PDT_CTC_PAIR       1  CTC search at V = 256, W = 16: the producer takes two frames per pass, one per half wave (0: one; same bits)
+  int step_flat;       // PDT_STEP_FLAT      1  step functions: one selection over all K' * V candidates (beam) / one list for prefixes that share
+                       //                       their extension row (CTC) (0: a sorted list per prefix; same results)
   int ctc_lean_extra;  // PDT_CTC_LEAN_EXTRA 1  CTC frame: one-prefix and tie frames decided beside the lean tier (0: by the full tiers, same results)
 };
 

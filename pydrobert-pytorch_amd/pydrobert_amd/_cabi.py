@@ -247,7 +247,49 @@ def host_flag() -> HostFlag:
 
 
 def stream_ptr(device):
-    return torch.cuda.current_stream(device).cuda_stream
+    try:  # (the raw handle, without a Stream object around it)
+        return torch._C._cuda_getCurrentRawStream(device.index)
+    except (AttributeError, TypeError):
+        return torch.cuda.current_stream(device).cuda_stream
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def on_device(device):
+    """``with on_device(d):`` -- torch.cuda.device(d), or nothing when ``d`` is the current device already
+    (the guard's own bookkeeping is several microseconds of a step function's call)."""
+    if device.index is None or device.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(device)
+
+
+def plain_call(*tensors):
+    """True when a call has nothing for the dispatcher to do: no tracing (torch.compile / make_fx / fake
+    tensors), no function transform, no dispatch or function mode, and no input autograd would follow.
+    The Python wrappers then call the implementation behind their ``custom_op`` directly -- the dispatch of
+    a Python custom op costs ~16 us, as much as a step function's kernel.  Same code either way."""
+    if torch.compiler.is_compiling():
+        return False
+    try:
+        if (torch._C._len_torch_dispatch_stack() or torch._C._len_torch_function_stack()
+                or torch._C._functorch.peek_interpreter_stack() is not None):
+            return False
+    except AttributeError:  # (another torch: leave it to the dispatcher)
+        return False
+    grad = torch.is_grad_enabled()
+    for t in tensors:
+        if t is not None and (type(t) is not torch.Tensor or (grad and t.requires_grad)):
+            return False
+    return True
 
 
 def ptr(t):

@@ -35,17 +35,18 @@ MAX_CTC_WIDTH = 32
 
 
 def _f32(t: torch.Tensor) -> torch.Tensor:
-    t = t.detach()
+    if t.requires_grad:
+        t = t.detach()
     return t if t.dtype == torch.float else t.float()
 
 
 def _i64(t: torch.Tensor) -> torch.Tensor:
-    t = t.detach()
+    if t.requires_grad:
+        t = t.detach()
     return t if t.dtype == torch.long else t.long()
 
 
-@custom_op("pydrobert_amd::beam_search_advance", mutates_args=())
-def _beam_search_advance_op(
+def _beam_search_advance_impl(
     log_probs_t: torch.Tensor,
     width: int,
     log_probs_prev: torch.Tensor,
@@ -90,7 +91,7 @@ def _beam_search_advance_op(
         elif bool((ypl != 0).any()):
             raise RuntimeError("Invalid lengths for t=0")  # :139-140
     S_out = S + (1 if grow else 0)
-    with torch.cuda.device(device):
+    with _cabi.on_device(device):
         y_next = torch.empty((S_out, N, width), device=device, dtype=torch.long)
         y_next_lens = torch.empty((N, width), device=device, dtype=torch.long)
         next_src = torch.empty((N, width), device=device, dtype=torch.long)
@@ -106,6 +107,18 @@ def _beam_search_advance_op(
             )  # fmt: skip
             _cabi.check(rc, "pdt_beam_search_advance")
     return y_next, y_next_lens, lp_next.to(log_probs_t.dtype), next_src
+
+
+@custom_op("pydrobert_amd::beam_search_advance", mutates_args=())
+def _beam_search_advance_op(
+    log_probs_t: torch.Tensor,
+    width: int,
+    log_probs_prev: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_lens: Optional[torch.Tensor],
+    grows: Optional[bool] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    return _beam_search_advance_impl(log_probs_t, width, log_probs_prev, y_prev, y_prev_lens, grows)
 
 
 @_beam_search_advance_op.register_fake
@@ -163,13 +176,16 @@ def beam_search_advance(
 
     Returns ``(y_next, y_next_lens, log_probs_next, next_src)``.
     """
+    if not torch.jit.is_scripting():
+        # nothing to trace, transform or differentiate: the implementation behind the operator, directly
+        if _cabi.plain_call(log_probs_t, log_probs_prev, y_prev, y_prev_lens):
+            return _beam_search_advance_impl(log_probs_t, width, log_probs_prev, y_prev, y_prev_lens)
     return torch.ops.pydrobert_amd.beam_search_advance(
         log_probs_t, width, log_probs_prev, y_prev, y_prev_lens
     )
 
 
-@custom_op("pydrobert_amd::ctc_prefix_search_advance", mutates_args=())
-def _ctc_prefix_search_advance_op(
+def _ctc_prefix_search_advance_impl(
     ext: torch.Tensor,
     nonext: torch.Tensor,
     blank: torch.Tensor,
@@ -233,11 +249,11 @@ def _ctc_prefix_search_advance_op(
     dtype = ext.dtype
     ext, nonext, blank, nb, b = (_f32(x) for x in (ext, nonext, blank, nb, b))
     yp, last, lens = _i64(y_prev), _i64(y_prev_last), _i64(y_prev_lens)
-    isp = prev_is_prefix.detach()
+    isp = prev_is_prefix.detach() if prev_is_prefix.requires_grad else prev_is_prefix
     if isp.dtype != torch.bool:
         isp = isp.bool()
     W = int(width)
-    with torch.cuda.device(device):
+    with _cabi.on_device(device):
         y_next = torch.empty((S + 1, N, W), device=device, dtype=torch.long)
         o_last = torch.empty((N, W), device=device, dtype=torch.long)
         o_lens = torch.empty((N, W), device=device, dtype=torch.long)
@@ -261,7 +277,30 @@ def _ctc_prefix_search_advance_op(
                 _cabi.stream_ptr(device),
             )  # fmt: skip
             _cabi.check(rc, "pdt_ctc_prefix_search_advance")
-    return y_next, o_last, o_lens, o_nb.to(dtype), o_b.to(dtype), o_isp, o_src, o_non
+    if dtype != torch.float:
+        o_nb, o_b = o_nb.to(dtype), o_b.to(dtype)
+    return y_next, o_last, o_lens, o_nb, o_b, o_isp, o_src, o_non
+
+
+@custom_op("pydrobert_amd::ctc_prefix_search_advance", mutates_args=())
+def _ctc_prefix_search_advance_op(
+    ext: torch.Tensor,
+    nonext: torch.Tensor,
+    blank: torch.Tensor,
+    width: int,
+    nb: torch.Tensor,
+    b: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_last: torch.Tensor,
+    y_prev_lens: torch.Tensor,
+    prev_is_prefix: torch.Tensor,
+) -> Tuple[
+    torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+    torch.Tensor, torch.Tensor,
+]:  # fmt: skip
+    return _ctc_prefix_search_advance_impl(
+        ext, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix
+    )
 
 
 @_ctc_prefix_search_advance_op.register_fake
@@ -360,6 +399,15 @@ def ctc_prefix_search_advance(
     Returns ``(y_next, y_next_last, y_next_lens, (nb_probs_next, b_probs_next),
     next_is_prefix, next_src, next_is_nonext)``.
     """
+    if not torch.jit.is_scripting():
+        # nothing to trace, transform or differentiate: the implementation behind the operator, directly
+        if _cabi.plain_call(probs_t[0], probs_t[1], probs_t[2], probs_prev[0], probs_prev[1], y_prev,
+                            y_prev_last, y_prev_lens, prev_is_prefix):  # fmt: skip
+            y_next, last, lens, nb, b, isp, src, non = _ctc_prefix_search_advance_impl(
+                probs_t[0], probs_t[1], probs_t[2], width, probs_prev[0], probs_prev[1], y_prev,
+                y_prev_last, y_prev_lens, prev_is_prefix,
+            )  # fmt: skip
+            return y_next, last, lens, (nb, b), isp, src, non
     y_next, last, lens, nb, b, isp, src, non = torch.ops.pydrobert_amd.ctc_prefix_search_advance(
         probs_t[0], probs_t[1], probs_t[2], width, probs_prev[0], probs_prev[1], y_prev,
         y_prev_last, y_prev_lens, prev_is_prefix,
@@ -441,8 +489,7 @@ def ctc_prefix_search(
     return CTCPrefixSearch(width)(logits, lens)
 
 
-@custom_op("pydrobert_amd::fusion_ext", mutates_args=())
-def _fusion_ext_op(
+def _fusion_ext_impl(
     lm_log_probs: torch.Tensor, nonext: torch.Tensor, blank: torch.Tensor, beta: float, valid_mixture: bool
 ) -> torch.Tensor:
     """Extension probabilities ``(N, K', V)`` of one frame from the LM scores ``(N * K', V)`` and
@@ -455,7 +502,7 @@ def _fusion_ext_op(
     Kp = lm_log_probs.size(0) // N if N else 1
     device = _cabi.require_hip(lm_log_probs, nonext, blank)
     lm, ne, bl = _f32(lm_log_probs).contiguous(), _f32(nonext), _f32(blank)
-    with torch.cuda.device(device):
+    with _cabi.on_device(device):
         out = torch.empty((N, Kp, V), device=device, dtype=torch.float)
         if N and V:
             rc = _cabi.lib().pdt_fusion_ext(
@@ -464,6 +511,20 @@ def _fusion_ext_op(
             )  # fmt: skip
             _cabi.check(rc, "pdt_fusion_ext")
     return out.to(nonext.dtype)
+
+
+@custom_op("pydrobert_amd::fusion_ext", mutates_args=())
+def _fusion_ext_op(
+    lm_log_probs: torch.Tensor, nonext: torch.Tensor, blank: torch.Tensor, beta: float, valid_mixture: bool
+) -> torch.Tensor:
+    return _fusion_ext_impl(lm_log_probs, nonext, blank, beta, valid_mixture)
+
+
+def _fusion_ext(lm_log_probs, nonext, blank, beta, valid_mixture):
+    """The operator, or -- nothing tracing, transforming or differentiating -- what is behind it."""
+    if _cabi.plain_call(lm_log_probs, nonext, blank):
+        return _fusion_ext_impl(lm_log_probs, nonext, blank, beta, valid_mixture)
+    return torch.ops.pydrobert_amd.fusion_ext(lm_log_probs, nonext, blank, beta, valid_mixture)
 
 
 @_fusion_ext_op.register_fake
@@ -755,9 +816,14 @@ class CTCPrefixSearch(torch.nn.Module):
                     lm_lp, state_next = self.lm.calc_idx_log_probs(y.flatten(1), state, y_lens.flatten())
                     if not (torch.is_grad_enabled() and (lm_lp.requires_grad or probs.requires_grad)):
                         # one pass over the LM scores instead of four (csrc/fusion_ext.hip)
-                        ext_t = torch.ops.pydrobert_amd.fusion_ext(
-                            lm_lp.reshape(N * Kp, V), nonext_t, blank_t, self.beta, self.valid_mixture
-                        )
+                        if torch.jit.is_scripting():
+                            ext_t = torch.ops.pydrobert_amd.fusion_ext(
+                                lm_lp.reshape(N * Kp, V), nonext_t, blank_t, self.beta, self.valid_mixture
+                            )
+                        else:
+                            ext_t = _fusion_ext(
+                                lm_lp.reshape(N * Kp, V), nonext_t, blank_t, self.beta, self.valid_mixture
+                            )
                     elif self.valid_mixture:  # convex combination that still sums to 1 - blank (:1120-1128)
                         lm_p = lm_lp.softmax(-1).view(N, Kp, V) * (1 - blank_t.view(N, 1, 1))
                         ext_t = (1.0 - self.beta) * ext_t + self.beta * lm_p
@@ -1047,27 +1113,31 @@ class BeamSearch(torch.nn.Module):
         out_dtype = torch.float
         dense = self._bigram_table(device)
         first_rows = None if dense is None else torch.full((N, 1), dense[2], dtype=torch.long, device=device)
+        if dense is not None:  # (what does not change from one iteration to the next, once)
+            table, stats, _ = dense
+            table_args = (_cabi.ptr(table), table.stride(0), table.stride(1), table.size(0), _cabi.ptr(stats))
+            eos_args = (int(has_eos), int(self.eos or 0), int(self.finish_all_paths), int(self.pad_value))
+            counts_ptr, pad_from_ptr, stream = counts.data_ptr(), _cabi.ptr(pad_from), _cabi.stream_ptr(device)
+            step_table = L.pdt_beam_search_step_table
         while t < max_iters:
             if dense is not None:
                 # a bigram table model: the prefixes' rows of its dense table, by their last tokens
-                table, stats, _ = dense
                 rows = first_rows if t == 0 else y[t - 1]
-                with torch.cuda.device(device):
+                with _cabi.on_device(device):
                     y_new = torch.empty((t + 1, N, W), dtype=torch.long, device=device)
                     lens_new = torch.empty((N, W), dtype=torch.long, device=device)
                     lp_new = torch.empty((N, W), device=device)
                     src = torch.empty((N, W), dtype=torch.long, device=device)
-                    rc = L.pdt_beam_search_step_table(
-                        _cabi.ptr(table), table.stride(0), table.stride(1), table.size(0), _cabi.ptr(stats),
-                        _cabi.ptr(rows), N, Kp, V, W,
-                        _cabi.ptr(log_probs), log_probs.stride(0), log_probs.stride(1),
-                        _cabi.ptr(y), t, y.stride(0), y.stride(1), y.stride(2),
-                        _cabi.ptr(lens), lens.stride(0), lens.stride(1), int(has_eos), int(self.eos or 0),
-                        int(self.finish_all_paths), int(self.pad_value), _cabi.ptr(y_new), _cabi.ptr(lens_new),
-                        _cabi.ptr(lp_new), _cabi.ptr(src), counts.data_ptr() + 4 * (t % check_every),
-                        _cabi.ptr(pad_from), _cabi.stream_ptr(device),
+                    rc = step_table(
+                        *table_args, rows.data_ptr(), N, Kp, V, W,
+                        log_probs.data_ptr(), log_probs.stride(0), log_probs.stride(1),
+                        y.data_ptr(), t, y.stride(0), y.stride(1), y.stride(2),
+                        lens.data_ptr(), lens.stride(0), lens.stride(1), *eos_args,
+                        y_new.data_ptr(), lens_new.data_ptr(), lp_new.data_ptr(), src.data_ptr(),
+                        counts_ptr + 4 * (t % check_every), pad_from_ptr, stream,
                     )  # fmt: skip
-                _cabi.check(rc, "pdt_beam_search_step_table")
+                if rc:
+                    _cabi.check(rc, "pdt_beam_search_step_table")
                 y, lens, log_probs, Kp = y_new, lens_new, lp_new, W
                 t += 1
                 if has_eos and (t % check_every == 0 or t == max_iters):

@@ -31,7 +31,7 @@ _HOST_DEFAULTS = {
 _NATIVE = (
     "PDT_LEV_BITPAR", "PDT_OC_BITPAR", "PDT_OC_WAVES", "PDT_CTC_EXACT_DIV", "PDT_CTC_ROWREG",
     "PDT_STEP_WIDE", "PDT_LM_CACHE", "PDT_LM_PERSISTENT", "PDT_LM_STEP_WAVES", "PDT_WARP_BANDS", "PDT_CTC_LEAN_EXTRA",
-    "PDT_CTC_PAIR",
+    "PDT_CTC_PAIR", "PDT_STEP_FLAT",
 )  # fmt: skip
 
 

@@ -539,6 +539,64 @@ def test_beam_search_advance_without_growth(device):
         assert np.array_equal(np.where(valid, act[0], 0), np.where(valid, exp[0], 0)), it
 
 
+def _flat_case(rng, kind):
+    N, Kp = int(rng.integers(1, 4)), int(rng.integers(1, 17))
+    V = int(rng.integers(65, min(1100, 64 * (256 // Kp)) + 1))
+    W, S = int(rng.integers(1, 40)), int(rng.integers(0, 5))
+    lpt = np.log(rng.dirichlet(np.ones(V), (N, Kp))).astype(np.float32)
+    lpp = rng.normal(size=(N, Kp)).astype(np.float32)
+    if kind == 1:  # finished beams: a row is -inf but for one token (the same lane in every row)
+        done = rng.random((N, Kp)) < 0.7
+        if rng.random() < 0.5:
+            done[0] = True  # ... every beam of an element
+        eos = int(rng.integers(0, V))
+        row = np.full(V, -np.inf, np.float32)
+        row[eos] = 0.0
+        lpt[done] = row
+    elif kind == 2:  # exact ties everywhere
+        lpt = np.round(lpt * 2) / 2
+        lpp = np.round(lpp * 2) / 2
+    elif kind == 3:  # the best candidates crowd one lane: more survivors than the list holds
+        lane = int(rng.integers(0, 64))
+        lpt[:, :, lane::64] += 30.0
+    elif kind == 4:  # -inf nearly everywhere: fewer finite candidates than the width
+        keep = rng.random(lpt.shape) < 3.0 / lpt[0].size
+        lpt = np.where(keep, lpt, -np.inf).astype(np.float32)
+    yp = rng.integers(0, V, (S, N, Kp))
+    ypl = rng.integers(0, S + 1, (N, Kp)) if rng.random() < 0.5 else None
+    return lpt, W, lpp, yp, ypl
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
+def test_beam_search_advance_flat_selection(device, switch, kind):
+    """Rows of more than 64 tokens that fit the registers of a workgroup: the K winners come from ONE
+    selection over all K' * V candidates (beam_advance_flat_kernel, round 5) -- against the oracle, and
+    bit for bit against the sorted-list-per-prefix form (PDT_STEP_FLAT=0), contiguous and strided rows."""
+    rng = np.random.default_rng(500 + kind)
+    tt = lambda a: None if a is None else torch.from_numpy(a).to(device)  # noqa: E731
+    for it in range(30):
+        lpt, W, lpp, yp, ypl = _flat_case(rng, kind)
+        exp = oracle.beam_search_advance(lpt, W, lpp, yp, ypl)
+        lpt_d = tt(lpt)
+        if it % 3 == 2:  # token stride 2
+            wide = torch.zeros(lpt.shape[:2] + (2 * lpt.shape[2],), device=device)
+            wide[..., ::2] = lpt_d
+            lpt_d = wide[..., ::2]
+        outs = []
+        for flat in (1, 0):
+            switch("PDT_STEP_FLAT", flat)
+            outs.append([x.cpu().numpy() for x in F.beam_search_advance(lpt_d, W, tt(lpp), tt(yp), tt(ypl))])
+        act, lists = outs
+        K = min(W, lpt.shape[1] * lpt.shape[2])
+        for a, b in zip(act, lists):
+            assert np.array_equal(a, b), (kind, it)
+        assert act[0].shape == exp[0].shape, (kind, it, act[0].shape, exp[0].shape)
+        assert np.array_equal(act[2], exp[2]), (kind, it)
+        # (-inf candidates tie: the kernels take the lowest flat index, the oracle's stable sort as well)
+        assert np.array_equal(act[1], exp[1]) and np.array_equal(act[3], exp[3]), (kind, it)
+        assert np.array_equal(act[0][..., :K], exp[0][..., :K]), (kind, it)
+
+
 def test_beam_search_advance_wider_than_a_wave(device):
     """Widths and beam counts above 64 take the plain workgroup form: same answers, ties to the
     lowest flat index k * V + v (quantised values make exact ties common)."""

@@ -197,7 +197,10 @@ def test_beam_search_reads_a_bigram_models_table(sos, switch):
     as the fused iterations around the model's own forward (PDT_BEAM_TABLE=0) and as the step-by-step
     loop; a changed model gets a new table."""
     rng = np.random.default_rng(4100 + sos)
-    for V, W, N, eos, iters in [(7, 3, 4, 0, 12), (12, 8, 3, None, 9), (40, 16, 5, 5, 20), (5, 5, 2, 1, 6)]:
+    # (vocabularies above 64 tokens: the flat selection of beam_step_flat_kernel, round 5 -- also against the
+    # sorted-list-per-prefix form of the same route, PDT_STEP_FLAT=0)
+    for V, W, N, eos, iters in [(7, 3, 4, 0, 12), (12, 8, 3, None, 9), (40, 16, 5, 5, 20), (5, 5, 2, 1, 6),
+                                (130, 16, 4, 3, 25), (70, 6, 3, None, 10), (300, 40, 3, 7, 30)]:
         dicts = random_dicts(rng, V, 2, 0.5, sos if sos < 0 else None)
         for v in range(V):
             dicts[0].setdefault(v, (float(rng.normal()), float(rng.normal())))
@@ -210,6 +213,13 @@ def test_beam_search_reads_a_bigram_models_table(sos, switch):
             outs.append(search(dict(), batch_size=N, max_iters=iters))
         (y, yl, lp), (y1, yl1, lp1), (y2, yl2, lp2) = outs
         what = (sos, V, W, N, eos)
+        if V > 64:
+            switch("PDT_BEAM_FUSED", "1")
+            switch("PDT_BEAM_TABLE", "1")
+            switch("PDT_STEP_FLAT", 0)
+            y3, yl3, lp3 = search(dict(), batch_size=N, max_iters=iters)
+            switch("PDT_STEP_FLAT", 1)
+            assert torch.equal(y, y3) and torch.equal(yl, yl3) and torch.equal(lp, lp3), what
         assert y.shape == y1.shape and torch.equal(y, y1) and torch.equal(yl, yl1) and torch.equal(lp, lp1), what
         assert torch.equal(yl, yl2) and torch.allclose(lp, lp2, rtol=1e-5, atol=1e-6), what
         switch("PDT_BEAM_FUSED", "1")
