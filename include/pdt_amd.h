@@ -254,6 +254,25 @@ int pdt_ctc_prefix_search_advance(
     uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The same step with the extension probabilities formed inside it (reference _decoding.py:1110-1135
+ * in front of :636-934): lm_log_probs (N * Kp, V) float32 contiguous -- the language model's scores of
+ * the frame, any normalisation -- are mixed with nonext / blank as pdt_fusion_ext mixes them
+ * (shallow fusion p * exp(beta * log_softmax(lm)), or the valid mixture), to the bit, and never
+ * written: what a call of pdt_fusion_ext followed by pdt_ctc_prefix_search_advance returns, in one
+ * kernel.  PDT_E_UNSUPPORTED for V above 1024, Kp or width above 32, or LDS beyond 160 KB: the two
+ * calls serve those.
+ * ------------------------------------------------------------------------------------- */
+int pdt_ctc_prefix_search_advance_lm(
+    const float *lm_log_probs, float beta, int valid_mixture, const float *nonext, int64_t ne_sn,
+    int64_t ne_sv, const float *blank, int64_t bl_sn, int64_t N, int64_t Kp, int64_t V, int64_t width,
+    const float *nb_prev, int64_t nb_sn, int64_t nb_sk, const float *b_prev, int64_t b_sn, int64_t b_sk,
+    const int64_t *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn, int64_t yp_sk,
+    const int64_t *y_prev_last, int64_t la_sn, int64_t la_sk, const int64_t *y_prev_lens, int64_t le_sn,
+    int64_t le_sk, const uint8_t *prev_is_prefix, int64_t ip_sn, int64_t ip_sa, int64_t ip_sb,
+    int64_t *y_next, int64_t *y_next_last, int64_t *y_next_lens, float *nb_next, float *b_next,
+    uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * beam_search_advance (reference _decoding.py:41-155): one beam-search step.
  *   log_probs_t (N, Kp, V), log_probs_prev (N, Kp) float32; y_prev (S, N, Kp) int64;
  *   y_prev_lens (N, Kp) int64 or NULL (all S).  S_out = rows of y_next: S + 1 when

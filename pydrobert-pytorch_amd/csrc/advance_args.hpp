@@ -23,6 +23,11 @@ struct CtcAdvArgs {
   uint8_t *next_nonext;                           // (N, W)
   int frame_bytes, waves_per_wg;  // LDS of the frame routine (the per-wave survivor scratch follows it)
   int ext_shared;                 // ext_sk == 0: every prefix reads the same row of extension probabilities
+  // the fused form (pdt_ctc_prefix_search_advance_lm): no ext -- the language model's scores (N * Kp, V),
+  // contiguous, mixed with the frame's probabilities on the fly (fusion_ext.hip's arithmetic)
+  const float *lm;
+  float beta;
+  int valid_mixture;
 };
 
 struct BeamAdvArgs {

@@ -9,8 +9,12 @@
 // candidate index (the reference's torch.topk leaves them unspecified).
 #include "advance_args.hpp"
 #include "ctc_frame.hpp"
+#include "row_reduce.hpp"
 #include "switches.hpp"
 
+#ifndef PDT_FUSED_STEP_WAVES
+#define PDT_FUSED_STEP_WAVES 4
+#endif
 #ifndef PDT_ADV_PHASES  // (diagnostic builds: 1 = stop after the per-prefix lists, 2 = before the history copy)
 #define PDT_ADV_PHASES 0
 #endif
@@ -21,7 +25,14 @@ namespace pdt {
 // dense extension probabilities are independent and each is a chain of round trips to HBM for a
 // lone wave: the waves take prefixes k = w, w + NW, ... in turn (every wave with its own survivor
 // scratch), wave 0 runs the frame on the finished lists, all waves copy the histories.
-__global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a) {
+// FUSED (round 5, pdt_ctc_prefix_search_advance_lm): the extension probabilities are never written --
+// a wave reads its prefix's row of language-model scores once (registers), reduces it, mixes it with the
+// frame's probabilities (the arithmetic of fusion_ext.hip, to the bit) into a row of its own in LDS and
+// selects from there; what the frame reads of a row besides its list -- the entries at the prefixes' last
+// tokens -- goes to a K' x K' table (DenseCtx::etab).  One kernel and 4 V bytes per prefix instead of two
+// kernels and 12 V: fusion_ext 43 us + step 45 us -> see DESIGN.md section 4.4.
+template <bool FUSED>
+__global__ void __launch_bounds__(512, FUSED ? 4 : 8) ctc_advance_kernel(const CtcAdvArgs a) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = lane_id();
   const int wave = (int)(threadIdx.x >> 6), NW = a.waves_per_wg;
@@ -36,7 +47,88 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
   const int M = ctc_list_len(V, W, Kp);
   // (prefixes that share ONE row of extension probabilities -- the search without a language model hands
   // over nonext.unsqueeze(1).expand(N, K', V), stride 0 -- share one list: built once, copied below)
-  const int n_lists = a.ext_shared ? 1 : Kp;
+  const int n_lists = FUSED ? 0 : (a.ext_shared ? 1 : Kp);
+  float *etab = nullptr;
+  if constexpr (FUSED) {
+    const int row_floats = (V + 3) & ~3;
+    float *rows_w = reinterpret_cast<float *>(smem + a.frame_bytes + (size_t)NW * PDT_SURV_CAP * 8);
+    etab = rows_w;  // [Kp x Kp]; behind it ONE row for the rare fall-back below (wave 0's turn only)
+    float *row = etab + ((Kp * Kp + 3) & ~3);
+    (void)row_floats;
+    const float keep = 1.0f - a.beta, beta = a.beta;
+    const bool vm = a.valid_mixture != 0;
+    const float scale = vm ? 1.0f - a.blank[n * a.bl_sn] : 0.0f;
+    const float *pc = a.nonext + n * a.ne_sn;
+    const int lastc = lane < Kp ? (int)min(max(a.last[n * a.la_sn + lane * a.la_sk], (int64_t)0), (int64_t)(V - 1)) : 0;
+    const float p_last = lane < Kp ? pc[(int64_t)lastc * a.ne_sv] : 0.0f;
+    unsigned overflowed = 0u;  // bit k / NW (wave-uniform): rows of this wave whose survivor buffer overflowed
+    // the frame's probabilities are the same for every row of the element: once, in registers
+    float pr[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int v = lane + i * PDT_WAVE;
+      pr[i] = (i * PDT_WAVE < V && v < V) ? pc[(int64_t)v * a.ne_sv] : 0.0f;
+    }
+    for (int k = wave; k < Kp; k += NW) {
+      const float *x = a.lm + (n * Kp + k) * (int64_t)V;
+      float r[16];
+      const RowStats st = row_stats<false, true, 16>(x, 1, V, r);  // (V <= 1024: the launcher)
+      const float log_sum = logf(st.sum);
+      auto mix = [&](const float p, const float xv) {
+        if (vm) {
+          const float lm_p = (expf(xv - st.mx) / st.sum) * scale;
+          return keep * p + beta * lm_p;
+        }
+        return p * expf(beta * ((xv - st.mx) - log_sum));
+      };
+      // what the frame reads of this row besides its list: the entries at the prefixes' last tokens
+      if (lane < Kp) etab[k * Kp + lane] = mix(p_last, x[lastc]);
+      unsigned keys[16];  // ordering keys of the mixed values (every one >= +0), 0 beyond the row
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int v = lane + i * PDT_WAVE;
+        keys[i] = 0u;
+        if (i * PDT_WAVE < V && v < V) keys[i] = fkey_nonneg(mix(pr[i], r[i]));
+      }
+      u64 tk;
+      if (wave_top_sorted_keys<16>(keys, M, my_surv, tk)) {
+        if (lane < M) {
+          L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
+          L.tl_p[k * PDT_WAVE + lane] = fkey_nonneg_inv(key_of(tk));
+        }
+      } else {
+        overflowed |= 1u << (k / NW);
+      }
+      wave_sync();
+    }
+    // heavy ties in a row (more survivors than the buffer holds): the row through LDS and the chunked merge,
+    // one wave at a time -- they share the one LDS row
+    for (int w = 0; w < NW; ++w) {
+      if (__syncthreads_or(wave == w && overflowed != 0u)) {
+        if (wave == w) {
+          for (int k = wave; k < Kp; k += NW) {
+            if (!((overflowed >> (k / NW)) & 1u)) continue;
+            const float *x = a.lm + (n * Kp + k) * (int64_t)V;
+            float r[16];
+            const RowStats st = row_stats<false, true, 16>(x, 1, V, r);
+            const float log_sum = logf(st.sum);
+            for (int v = lane; v < V; v += PDT_WAVE) {
+              const float p = pc[(int64_t)v * a.ne_sv], xv = x[v];
+              row[v] = vm ? keep * p + beta * ((expf(xv - st.mx) / st.sum) * scale) : p * expf(beta * ((xv - st.mx) - log_sum));
+            }
+            wave_sync();
+            const u64 tk = wave_top_sorted<false, true>(row, V, M, my_surv);
+            if (lane < M) {
+              L.tl_tok[k * PDT_WAVE + lane] = (int)idx_of(tk);
+              L.tl_p[k * PDT_WAVE + lane] = fkey_nonneg_inv(key_of(tk));
+            }
+            wave_sync();
+          }
+        }
+        __syncthreads();
+      }
+    }
+  }
   for (int k = wave; k < n_lists; k += NW) {
     // (rows of 513 .. 1024 elements are read once, into 16 registers per lane: 0.056 -> 0.047 ms at
     // V = 1000; shorter rows measured no better that way, longer ones are streamed twice)
@@ -52,7 +144,7 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
   for (int v = (int)threadIdx.x; v < V; v += NW * PDT_WAVE) p[v] = a.nonext[n * a.ne_sn + v * a.ne_sv];
   if (threadIdx.x == 0) p[V] = a.blank[n * a.bl_sn];
   __syncthreads();
-  if (n_lists < Kp) {
+  if (!FUSED && n_lists < Kp) {
     for (int idx = PDT_WAVE + (int)threadIdx.x; idx < Kp * PDT_WAVE; idx += NW * PDT_WAVE) {
       L.tl_tok[idx] = L.tl_tok[idx & (PDT_WAVE - 1)];
       L.tl_p[idx] = L.tl_p[idx & (PDT_WAVE - 1)];
@@ -64,9 +156,13 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
 #endif
 
   DenseCtx dc;
-  dc.ext = a.ext + n * a.ext_sn;
-  dc.ext_sk = a.ext_sk;
-  dc.ext_sv = a.ext_sv;
+  dc.ext = FUSED ? nullptr : a.ext + n * a.ext_sn;
+  dc.ext_sk = FUSED ? 0 : a.ext_sk;
+  dc.ext_sv = FUSED ? 0 : a.ext_sv;
+  if constexpr (FUSED) {
+    dc.etab = etab;
+    dc.etab_stride = Kp;
+  }
   dc.y_prev = a.y_prev + n * a.yp_sn;
   dc.yp_ss = a.yp_ss;
   dc.yp_sk = a.yp_sk;
@@ -130,22 +226,32 @@ __global__ void __launch_bounds__(512, 8) ctc_advance_kernel(const CtcAdvArgs a)
 int launch_ctc_advance(CtcAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
   const bool force_wide = switches().step_wide != 0;
+  if (a.lm && (force_wide || a.W > kMaxWidth || a.Kp > kMaxWidth || a.V > 16 * PDT_WAVE)) return PDT_E_UNSUPPORTED;
   if (force_wide || a.W > kMaxWidth || a.Kp > kMaxWidth) return launch_ctc_advance_wide(a, stream);  // (advance_wide.hip)
   int nw = 1;
   while (nw < 8 && nw * 2 <= a.Kp) nw *= 2;  // waves per element: a power of two <= min(Kp, 8)
   size_t frame = (size_t)((a.V + 1 + 3) & ~3) * 4 + FrameLds::bytes(a.V, a.W, a.Kp, true);
   frame = (frame + 15) & ~(size_t)15;
-  const size_t smem = frame + (size_t)nw * PDT_SURV_CAP * 8;  // + one survivor scratch per wave
-  if (smem > 160 * 1024) return PDT_E_TOO_LONG;
+  const bool fused = a.lm != nullptr;
+  // (the fused form needs ~110 vector registers: four waves per SIMD.  Four-wave workgroups keep every batch
+  // element of N = 1024 resident at once -- four rows per wave -- where eight-wave ones run in two rounds)
+  if (fused && nw > PDT_FUSED_STEP_WAVES) nw = PDT_FUSED_STEP_WAVES;
+  size_t smem = frame + (size_t)nw * PDT_SURV_CAP * 8;  // + one survivor scratch per wave
+  if (fused) smem += ((size_t)((a.V + 3) & ~3) + (size_t)((a.Kp * a.Kp + 3) & ~3)) * 4;  // + the K' x K' table, one mixed row (ties)
+  if (smem > 160 * 1024) return fused ? PDT_E_UNSUPPORTED : PDT_E_TOO_LONG;
   a.waves_per_wg = nw;
   a.frame_bytes = (int)frame;
-  a.ext_shared = (a.Kp > 1 && a.ext_sk == 0 && switches().step_flat != 0) ? 1 : 0;
+  a.ext_shared = (!fused && a.Kp > 1 && a.ext_sk == 0 && switches().step_flat != 0) ? 1 : 0;
+  const void *kern = fused ? reinterpret_cast<const void *>(ctc_advance_kernel<true>)
+                           : reinterpret_cast<const void *>(ctc_advance_kernel<false>);
   if (smem > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(ctc_advance_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
-  hipLaunchKernelGGL(ctc_advance_kernel, dim3((unsigned)a.N), dim3(64 * nw), smem, stream, a);
+  if (fused)
+    hipLaunchKernelGGL(ctc_advance_kernel<true>, dim3((unsigned)a.N), dim3(64 * nw), smem, stream, a);
+  else
+    hipLaunchKernelGGL(ctc_advance_kernel<false>, dim3((unsigned)a.N), dim3(64 * nw), smem, stream, a);
   return (int)hipGetLastError();
 }
 
@@ -461,6 +567,40 @@ int pdt_ctc_prefix_search_advance(
   if (V >= (1 << 30) || S >= (1 << 26) || N >= (1ll << 31)) return PDT_E_TOO_LONG;
   CtcAdvArgs a{};
   a.ext = ext; a.ext_sn = ext_sn; a.ext_sk = ext_sk; a.ext_sv = ext_sv;
+  a.nonext = nonext; a.ne_sn = ne_sn; a.ne_sv = ne_sv;
+  a.blank = blank; a.bl_sn = bl_sn;
+  a.nb_prev = nb_prev; a.pb_sn = nb_sn; a.pb_sk = nb_sk;
+  a.b_prev = b_prev; a.pbb_sn = b_sn; a.pbb_sk = b_sk;
+  a.y_prev = y_prev; a.yp_ss = yp_ss; a.yp_sn = yp_sn; a.yp_sk = yp_sk;
+  a.last = y_prev_last; a.la_sn = la_sn; a.la_sk = la_sk;
+  a.lens = y_prev_lens; a.le_sn = le_sn; a.le_sk = le_sk;
+  a.isp = prev_is_prefix; a.ip_sn = ip_sn; a.ip_sa = ip_sa; a.ip_sb = ip_sb;
+  a.N = (int)N; a.Kp = (int)Kp; a.V = (int)V; a.W = (int)width; a.S = (int)S;
+  a.y_next = y_next; a.y_next_last = y_next_last; a.y_next_lens = y_next_lens;
+  a.next_src = next_src; a.nb_next = nb_next; a.b_next = b_next;
+  a.next_isp = next_is_prefix; a.next_nonext = next_is_nonext;
+  return launch_ctc_advance(a, (hipStream_t)stream);
+}
+
+int pdt_ctc_prefix_search_advance_lm(
+    const float *lm_log_probs, float beta, int valid_mixture, const float *nonext, int64_t ne_sn,
+    int64_t ne_sv, const float *blank, int64_t bl_sn, int64_t N, int64_t Kp, int64_t V, int64_t width,
+    const float *nb_prev, int64_t nb_sn, int64_t nb_sk, const float *b_prev, int64_t b_sn, int64_t b_sk,
+    const int64_t *y_prev, int64_t S, int64_t yp_ss, int64_t yp_sn, int64_t yp_sk,
+    const int64_t *y_prev_last, int64_t la_sn, int64_t la_sk, const int64_t *y_prev_lens, int64_t le_sn,
+    int64_t le_sk, const uint8_t *prev_is_prefix, int64_t ip_sn, int64_t ip_sa, int64_t ip_sb,
+    int64_t *y_next, int64_t *y_next_last, int64_t *y_next_lens, float *nb_next, float *b_next,
+    uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext, void *stream) {
+  using namespace pdt;
+  if (N < 0 || Kp < 1 || V < 1 || width < 1 || S < 0) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!lm_log_probs || !nonext || !blank || !nb_prev || !b_prev || !y_prev_last || !y_prev_lens ||
+      !prev_is_prefix || (S > 0 && !y_prev) || !y_next || !y_next_last || !y_next_lens ||
+      !nb_next || !b_next || !next_is_prefix || !next_src || !next_is_nonext)
+    return PDT_E_ARG;
+  if (V >= (1 << 30) || S >= (1 << 26) || N >= (1ll << 31)) return PDT_E_TOO_LONG;
+  CtcAdvArgs a{};
+  a.lm = lm_log_probs; a.beta = beta; a.valid_mixture = valid_mixture;
   a.nonext = nonext; a.ne_sn = ne_sn; a.ne_sv = ne_sv;
   a.blank = blank; a.bl_sn = bl_sn;
   a.nb_prev = nb_prev; a.pb_sn = nb_sn; a.pb_sk = nb_sk;

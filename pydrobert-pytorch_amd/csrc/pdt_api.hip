@@ -110,7 +110,7 @@ extern "C" {
 //    pdt_beam_search_step_table, pdt_row_log_softmax_stats
 // 7: pdt_amd_set_switch / pdt_amd_get_switch; the four-utterances-per-wave CTC form left the library
 // 9: pdt_spec_augment_apply_warp; pdt_ctc_lm_table_search takes ctx_base / ctx_mod; PDT_E_UNSUPPORTED
-int pdt_amd_abi_version(void) { return 9; }
+int pdt_amd_abi_version(void) { return 10; }
 
 int pdt_amd_set_switch(const char *name, int value) {
   if (!name) return PDT_E_ARG;

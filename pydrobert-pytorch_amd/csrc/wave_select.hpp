@@ -394,6 +394,35 @@ __device__ __forceinline__ u64 wave_top_sorted_regs(const float *xb, const int64
                                                           soft_lse);
 }
 
+// The same selection over a row a wave already HOLDS as ordering keys: keys[i] belongs to element
+// lane + 64 i, 0 where there is none.  Returns false when the survivor buffer overflows (heavy ties): the
+// caller falls back to a form that can walk the row again.
+template <int NR>
+__device__ __forceinline__ bool wave_top_sorted_keys(const unsigned (&keys)[NR], const int M, u64 *surv, u64 &out) {
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));
+  unsigned lmax = 0u;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) lmax = max(lmax, keys[i]);
+  const unsigned sorted_max = wave_sort_desc<unsigned>(lmax);
+  const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)sorted_max, M - 1);
+  int count = 0;
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const bool pred = keys[i] >= tau && keys[i] != 0u;
+    const u64 b = __ballot(pred);
+    if (b) {
+      const int pos = count + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+      if (pred && pos < PDT_SURV_CAP) surv[pos] = pack_key(keys[i], (unsigned)(lane + i * PDT_WAVE));
+      count += __popcll(b);
+    }
+  }
+  wave_sync();
+  if (count > PDT_SURV_CAP) return false;
+  out = wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
+  return true;
+}
+
 template <bool LONG = false, bool NONNEG = false>
 __device__ __forceinline__ u64 wave_top_sorted(const float *x, int V, int M, u64 *surv,
                                                const unsigned *lmax_in = nullptr,

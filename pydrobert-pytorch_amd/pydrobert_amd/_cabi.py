@@ -64,6 +64,12 @@ SIGNATURES = {
         + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64]
         + [_P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     ),
+    "pdt_ctc_prefix_search_advance_lm": (
+        _INT,
+        [_P, _F, _INT, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64]
+        + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64]
+        + [_P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    ),
     "pdt_beam_search_advance": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]

@@ -196,10 +196,14 @@ def _ctc_prefix_search_advance_impl(
     y_prev_last: torch.Tensor,
     y_prev_lens: torch.Tensor,
     prev_is_prefix: torch.Tensor,
-) -> Tuple[
+    lm_mix: Optional[Tuple[float, bool]] = None,
+) -> Optional[Tuple[
     torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
     torch.Tensor, torch.Tensor,
-]:  # fmt: skip
+]]:  # fmt: skip
+    # `lm_mix` = (beta, valid_mixture): `ext` then holds the language model's scores (N, K', V) and the
+    # kernel mixes them with the frame's probabilities itself (pdt_ctc_prefix_search_advance_lm); None is
+    # returned when that entry point does not take the shapes (the caller makes the two calls)
     if width < 1:
         raise RuntimeError("width must be positive")
     if ext.dim() != 3:
@@ -246,7 +250,7 @@ def _ctc_prefix_search_advance_impl(
         )
     device = _cabi.require_hip(ext, nonext, blank, nb, b, y_prev, y_prev_last, y_prev_lens,
                                prev_is_prefix)  # fmt: skip
-    dtype = ext.dtype
+    dtype = ext.dtype if lm_mix is None else nonext.dtype
     ext, nonext, blank, nb, b = (_f32(x) for x in (ext, nonext, blank, nb, b))
     yp, last, lens = _i64(y_prev), _i64(y_prev_last), _i64(y_prev_lens)
     isp = prev_is_prefix.detach() if prev_is_prefix.requires_grad else prev_is_prefix
@@ -262,7 +266,25 @@ def _ctc_prefix_search_advance_impl(
         o_b = torch.empty((N, W), device=device, dtype=torch.float)
         o_isp = torch.empty((N, W, W), device=device, dtype=torch.bool)
         o_non = torch.empty((N, W), device=device, dtype=torch.bool)
-        if N:
+        if N and lm_mix is not None:
+            ext = ext.contiguous()
+            rc = _cabi.lib().pdt_ctc_prefix_search_advance_lm(
+                _cabi.ptr(ext), float(lm_mix[0]), int(lm_mix[1]),
+                _cabi.ptr(nonext), nonext.stride(0), nonext.stride(1),
+                _cabi.ptr(blank), blank.stride(0), N, Kp, V, W,
+                _cabi.ptr(nb), nb.stride(0), nb.stride(1), _cabi.ptr(b), b.stride(0), b.stride(1),
+                _cabi.ptr(yp), S, yp.stride(0), yp.stride(1), yp.stride(2),
+                _cabi.ptr(last), last.stride(0), last.stride(1),
+                _cabi.ptr(lens), lens.stride(0), lens.stride(1),
+                _cabi.ptr(isp), isp.stride(0), isp.stride(1), isp.stride(2),
+                _cabi.ptr(y_next), _cabi.ptr(o_last), _cabi.ptr(o_lens), _cabi.ptr(o_nb),
+                _cabi.ptr(o_b), _cabi.ptr(o_isp), _cabi.ptr(o_src), _cabi.ptr(o_non),
+                _cabi.stream_ptr(device),
+            )  # fmt: skip
+            if rc == _cabi.PDT_E_UNSUPPORTED:
+                return None
+            _cabi.check(rc, "pdt_ctc_prefix_search_advance_lm")
+        elif N:
             rc = _cabi.lib().pdt_ctc_prefix_search_advance(
                 _cabi.ptr(ext), ext.stride(0), ext.stride(1), ext.stride(2),
                 _cabi.ptr(nonext), nonext.stride(0), nonext.stride(1),
@@ -301,6 +323,83 @@ def _ctc_prefix_search_advance_op(
     return _ctc_prefix_search_advance_impl(
         ext, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix
     )
+
+
+def _ctc_prefix_search_advance_lm_impl(
+    lm_log_probs: torch.Tensor,
+    beta: float,
+    valid_mixture: bool,
+    nonext: torch.Tensor,
+    blank: torch.Tensor,
+    width: int,
+    nb: torch.Tensor,
+    b: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_last: torch.Tensor,
+    y_prev_lens: torch.Tensor,
+    prev_is_prefix: torch.Tensor,
+) -> Tuple[
+    torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+    torch.Tensor, torch.Tensor,
+]:  # fmt: skip
+    """``fusion_ext`` + ``ctc_prefix_search_advance`` as ONE kernel: the extension probabilities (reference
+    _decoding.py:1110-1135) are formed inside the step and never written.  ``lm_log_probs`` is ``(N, K', V)``.
+    No gradient; shapes the kernel does not take (V > 1024, beams above 32) make the two calls here."""
+    out = _ctc_prefix_search_advance_impl(
+        lm_log_probs, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix,
+        (beta, valid_mixture),
+    )  # fmt: skip
+    if out is None:
+        N, Kp, V = lm_log_probs.shape
+        ext = _fusion_ext_impl(lm_log_probs.reshape(N * Kp, V), nonext, blank, beta, valid_mixture)
+        out = _ctc_prefix_search_advance_impl(
+            ext, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix
+        )
+    return out
+
+
+@custom_op("pydrobert_amd::ctc_prefix_search_advance_lm", mutates_args=())
+def _ctc_prefix_search_advance_lm_op(
+    lm_log_probs: torch.Tensor,
+    beta: float,
+    valid_mixture: bool,
+    nonext: torch.Tensor,
+    blank: torch.Tensor,
+    width: int,
+    nb: torch.Tensor,
+    b: torch.Tensor,
+    y_prev: torch.Tensor,
+    y_prev_last: torch.Tensor,
+    y_prev_lens: torch.Tensor,
+    prev_is_prefix: torch.Tensor,
+) -> Tuple[
+    torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor,
+    torch.Tensor, torch.Tensor,
+]:  # fmt: skip
+    return _ctc_prefix_search_advance_lm_impl(
+        lm_log_probs, beta, valid_mixture, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens,
+        prev_is_prefix,
+    )  # fmt: skip
+
+
+@_ctc_prefix_search_advance_lm_op.register_fake
+def _(lm_log_probs, beta, valid_mixture, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix):
+    N, W, S = lm_log_probs.shape[0], width, y_prev.shape[0]
+    i64 = lambda *s: y_prev.new_empty(s, dtype=torch.long)  # noqa: E731
+    return (
+        i64(S + 1, N, W), i64(N, W), i64(N, W), nonext.new_empty((N, W)), nonext.new_empty((N, W)),
+        nonext.new_empty((N, W, W), dtype=torch.bool), i64(N, W), nonext.new_empty((N, W), dtype=torch.bool),
+    )  # fmt: skip
+
+
+def _ctc_step_with_lm_scores(lm_log_probs, beta, valid_mixture, nonext, blank, width, nb, b, y_prev, y_prev_last,
+                             y_prev_lens, prev_is_prefix):
+    """The operator above, or -- nothing tracing, transforming or differentiating -- what is behind it."""
+    args = (lm_log_probs, beta, valid_mixture, nonext, blank, width, nb, b, y_prev, y_prev_last, y_prev_lens,
+            prev_is_prefix)  # fmt: skip
+    if _cabi.plain_call(lm_log_probs, nonext, blank, nb, b, y_prev, y_prev_last, y_prev_lens, prev_is_prefix):
+        return _ctc_prefix_search_advance_lm_impl(*args)
+    return torch.ops.pydrobert_amd.ctc_prefix_search_advance_lm(*args)
 
 
 @_ctc_prefix_search_advance_op.register_fake
@@ -802,6 +901,8 @@ class CTCPrefixSearch(torch.nn.Module):
             nonext_t, blank_t = probs[t, :, :V], probs[t, :, V]
             ext_t = nonext_t.unsqueeze(1).expand(N, Kp, V)
             state_next: Dict[str, torch.Tensor] = dict()
+            mix_in_step = False
+            lm_lp = nonext_t
             if one_kernel:
                 # (the model keeps no state between frames: nothing to extract or mix afterwards; the
                 # history alternates between two buffers of the final size: no allocation per frame)
@@ -815,11 +916,14 @@ class CTCPrefixSearch(torch.nn.Module):
                 if fuse:
                     lm_lp, state_next = self.lm.calc_idx_log_probs(y.flatten(1), state, y_lens.flatten())
                     if not (torch.is_grad_enabled() and (lm_lp.requires_grad or probs.requires_grad)):
-                        # one pass over the LM scores instead of four (csrc/fusion_ext.hip)
+                        # one pass over the LM scores instead of four (csrc/fusion_ext.hip) -- scripted;
+                        # else inside the step kernel itself, below
                         if torch.jit.is_scripting():
                             ext_t = torch.ops.pydrobert_amd.fusion_ext(
                                 lm_lp.reshape(N * Kp, V), nonext_t, blank_t, self.beta, self.valid_mixture
                             )
+                        elif switches.get("PDT_CTC_STEP_MIX"):
+                            mix_in_step = True
                         else:
                             ext_t = _fusion_ext(
                                 lm_lp.reshape(N * Kp, V), nonext_t, blank_t, self.beta, self.valid_mixture
@@ -829,10 +933,22 @@ class CTCPrefixSearch(torch.nn.Module):
                         ext_t = (1.0 - self.beta) * ext_t + self.beta * lm_p
                     else:  # shallow fusion: p_ctc * p_lm ** beta (:1130-1135)
                         ext_t = ext_t * (self.beta * lm_lp.log_softmax(-1)).exp().view(N, Kp, V)
-            y_new, last_new, lens_new, masses, is_prefix, src, kept = ctc_prefix_search_advance(
-                (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
-            )
-            nb_new, b_new = masses
+            if torch.jit.is_scripting():
+                y_new, last_new, lens_new, masses, is_prefix, src, kept = ctc_prefix_search_advance(
+                    (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
+                )
+                nb_new, b_new = masses
+            else:
+                if mix_in_step:
+                    y_new, last_new, lens_new, nb_new, b_new, is_prefix, src, kept = _ctc_step_with_lm_scores(
+                        lm_lp.reshape(N, Kp, V), self.beta, self.valid_mixture, nonext_t, blank_t, W, nb, b, y,
+                        y_last, y_lens, is_prefix,
+                    )  # fmt: skip
+                else:
+                    y_new, last_new, lens_new, masses, is_prefix, src, kept = ctc_prefix_search_advance(
+                        (ext_t, nonext_t, blank_t), W, (nb, b), y, y_last, y_lens, is_prefix
+                    )
+                    nb_new, b_new = masses
             if self.lm is not None:
                 if fuse:
                     rows = (src + (first_rows if Kp == 1 else beam_rows)).flatten()

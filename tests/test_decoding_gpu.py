@@ -497,6 +497,51 @@ def test_ctc_prefix_search_advance_broadcast_ext(device):
     _cmp_ctc_step(act, exp, "broadcast")
 
 
+@pytest.mark.parametrize("V,W", [(5, 3), (64, 8), (65, 16), (300, 7), (1000, 16), (1024, 32), (1025, 4)])
+def test_ctc_step_forms_the_extension_probabilities_itself(device, V, W):
+    """pdt_ctc_prefix_search_advance_lm (round 5): the language model's scores go into the step, which mixes
+    them with the frame's probabilities as fusion_ext does and never writes the result -- every output of
+    fusion_ext + ctc_prefix_search_advance, to the bit, over a run of frames whose state is the kernel's
+    own; both mixtures.  V = 1025 is past the kernel's rows: the operator makes the two calls itself.
+    Also here: prefixes that share one expand()ed row of extension probabilities share one list
+    (PDT_STEP_FLAT) -- same outputs as with a row each."""
+    from pydrobert_amd import _decoding as D
+
+    g = torch.Generator(device=device).manual_seed(V * 31 + W)
+    N, T = 5, 14
+    for valid_mixture in (False, True):
+        nb, b = torch.zeros((N, 1), device=device), torch.ones((N, 1), device=device)
+        y = torch.zeros((0, N, 1), dtype=torch.long, device=device)
+        last = lens = torch.zeros((N, 1), dtype=torch.long, device=device)
+        isp = torch.ones((N, 1, 1), dtype=torch.bool, device=device)
+        for t in range(T):
+            Kp = nb.shape[1]
+            p = (torch.randn((N, V + 1), device=device, generator=g) * 1.5).softmax(1)
+            nonext, blank = p[:, :V], p[:, V]
+            lm = torch.randn((N, Kp, V), device=device, generator=g) * 2.0
+            if t % 4 == 3:
+                lm[:, :, ::3] = float("-inf")  # masked tokens
+            ext = torch.ops.pydrobert_amd.fusion_ext(lm.reshape(N * Kp, V), nonext, blank, 0.3, valid_mixture)
+            two = torch.ops.pydrobert_amd.ctc_prefix_search_advance(ext, nonext, blank, W, nb, b, y, last, lens, isp)
+            one = D._ctc_step_with_lm_scores(lm, 0.3, valid_mixture, nonext, blank, W, nb, b, y, last, lens, isp)
+            via_op = torch.ops.pydrobert_amd.ctc_prefix_search_advance_lm(
+                lm, 0.3, valid_mixture, nonext, blank, W, nb, b, y, last, lens, isp
+            )
+            for i, (u, v, w) in enumerate(zip(one, two, via_op)):
+                valid = slice(None)
+                if i == 0:  # rows of y beyond the lengths are unspecified
+                    m = torch.arange(u.shape[0], device=device).view(-1, 1, 1) < two[2].unsqueeze(0)
+                    u, v, w = u * m, v * m, w * m
+                assert torch.equal(u[valid], v[valid]) and torch.equal(u[valid], w[valid]), (V, W, valid_mixture, t, i)
+            # the no-LM form of the same frame: one shared row against a row each
+            shared = F.ctc_prefix_search_advance((nonext.unsqueeze(1).expand(N, Kp, V), nonext, blank), W, (nb, b), y, last, lens, isp)
+            each = F.ctc_prefix_search_advance((nonext.unsqueeze(1).expand(N, Kp, V).contiguous(), nonext, blank), W, (nb, b), y, last, lens, isp)
+            flat = lambda o: [o[0] * (torch.arange(o[0].shape[0], device=device).view(-1, 1, 1) < o[2].unsqueeze(0)), o[1], o[2], o[3][0], o[3][1], o[4], o[5], o[6]]  # noqa: E731
+            for i, (u, v) in enumerate(zip(flat(shared), flat(each))):
+                assert torch.equal(u, v), ("shared", V, W, t, i)
+            y, last, lens, nb, b, isp = two[0], two[1], two[2], two[3], two[4], two[5]
+
+
 @pytest.mark.parametrize("with_lens", [False, True])
 def test_beam_search_advance_random(device, with_lens):
     rng = np.random.default_rng(31 + with_lens)
