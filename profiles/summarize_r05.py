@@ -53,7 +53,7 @@ rec = {
         "SQ_INSTS_LDS_per_launch": head["SQ_INSTS_LDS"], "wave_time_split": head["wave_time_split"],
         "valu_pipe_busy_frac_measured": head.get("valu_pipe_busy_frac"), "valu_cycles_per_inst_measured": head.get("valu_cycles_per_inst"),
         "valu_issue_cycles": issue,
-        "valu_issue_note": "profiles/r05_valu_issue_cost.txt: ns per wave64 instruction per SIMD with four waves resident, "
+        "valu_issue_note": "profiles/r04_valu_issue_cost.txt (round 4, not re-measured): ns per wave64 instruction per SIMD with four waves resident, "
                            "turned into shader cycles by the s_memtime / s_memrealtime clock of the same kernel "
                            "(profiles/tools/micro/valu_cost.hip): add / sub / and / or / xor / mov / right shifts / f32 add, "
                            "mul 2.5; everything else (fma, min / max, compares, cndmask, DPP, lshl, any SGPR operand) 4.3; "

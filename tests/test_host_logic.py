@@ -326,3 +326,43 @@ def test_shallow_fusion_dict_plumbing():
     assert set(lm.merge_dicts(first, second)) == set(prev)
     with pytest.raises(RuntimeError, match="does not start with"):
         lm.split_dicts({"three.x": torch.zeros(1)})
+
+
+def test_direct_calls_only_when_the_dispatcher_has_nothing_to_do():
+    """`_cabi.plain_call`: the step functions' wrappers call the implementation behind their operator only in
+    plain eager mode -- not for inputs autograd would follow, tensor subclasses (fake tensors), under a
+    dispatch or function mode, or inside a functorch transform."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from torch.overrides import TorchFunctionMode
+    from torch.utils._python_dispatch import TorchDispatchMode
+
+    from pydrobert_amd import _cabi
+
+    a, b = torch.zeros(3), torch.zeros(3, dtype=torch.long)
+    assert _cabi.plain_call(a, b, None)
+    g = torch.zeros(3, requires_grad=True)
+    assert not _cabi.plain_call(a, g)
+    with torch.no_grad():
+        assert _cabi.plain_call(a, g)
+    with FakeTensorMode() as mode:
+        assert not _cabi.plain_call(a)
+        assert not _cabi.plain_call(mode.from_tensor(a))
+    assert not _cabi.plain_call(FakeTensorMode().from_tensor(a))
+
+    class Quiet(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            return func(*args, **(kwargs or {}))
+
+    with Quiet():
+        assert not _cabi.plain_call(a)
+
+    class QuietF(TorchFunctionMode):
+        def __torch_function__(self, func, types, args=(), kwargs=None):
+            return func(*args, **(kwargs or {}))
+
+    with QuietF():
+        assert not _cabi.plain_call(a)
+    seen = []
+    torch.vmap(lambda x: (seen.append(_cabi.plain_call(x)), x)[1])(torch.zeros(2, 3))
+    assert seen == [False]
+    assert _cabi.plain_call(a)
