@@ -6,12 +6,13 @@ for p in (ROOT, os.path.join(ROOT, "pydrobert-pytorch_amd"), os.path.join(ROOT, 
     sys.path.insert(0, p)
 import numpy as np, torch, warnings
 import oracle
-from pydrobert_amd import functional as F
+from pydrobert_amd import _decoding as D, functional as F
 warnings.simplefilter("ignore")
 dev = "cuda"
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 bad = n_cases = 0
+t_say = time.time()
 def T(a): return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 def cmp_step(act, exp):
     (y, last, lens, (nb, b), isp, src, non) = [tuple(z.cpu().numpy() for z in x) if isinstance(x, tuple) else x.cpu().numpy() for x in act]
@@ -27,11 +28,19 @@ def cmp_step(act, exp):
     return None
 while time.time() < t_end:
     n_cases += 1
+    if time.time() - t_say > 45.0:  # (a line a minute: a silent run is taken for a hung one)
+        t_say = time.time(); print("cases", n_cases, "mismatches", bad, flush=True)
     kind = rng.integers(0, 5)
     if kind == 0:  # teacher-forced CTC step
         V, W, N, Tn = int(rng.integers(1, 50)), int(rng.integers(1, 33)), int(rng.integers(1, 4)), int(rng.integers(1, 16))
         if rng.random() < 0.2:  # more than 32 prefixes: the radix-select form (csrc/advance_wide.hip)
             W = int(rng.integers(33, 120)); V = W + int(rng.integers(0, 60)); Tn = int(rng.integers(1, 8))
+        # round 5: prefixes sharing one expand()ed row (one list for all), and the step that mixes a language
+        # model's scores itself (pdt_ctc_prefix_search_advance_lm) -- both also with rows of hundreds of tokens
+        form = "dense" if W > 32 else ["dense", "shared", "mixed"][int(rng.integers(0, 3))]
+        if form != "dense" and rng.random() < 0.4:
+            V = int(rng.integers(50, 700))
+        beta, vmix = float(rng.random() * 0.9 + 0.05), bool(rng.random() < 0.5)
         if W > V + 1: continue
         nb, b = np.zeros((N, 1), np.float32), np.ones((N, 1), np.float32)
         y = np.zeros((0, N, 1), np.int64); last = lens = np.zeros((N, 1), np.int64); isp = np.ones((N, 1, 1), bool)
@@ -41,8 +50,27 @@ while time.time() < t_end:
             nonext, blank = np.ascontiguousarray(p[:, :V]), np.ascontiguousarray(p[:, V])
             lm = np.exp(rng.normal(size=(N, Kp, V)) * 0.7).astype(np.float32); lm /= lm.sum(2, keepdims=True)
             ext = (lm ** 0.5 * nonext[:, None]).astype(np.float32)
+            if form == "shared":
+                ext = np.ascontiguousarray(np.broadcast_to(nonext[:, None], (N, Kp, V)))
+            elif form == "mixed":
+                scores = (rng.normal(size=(N, Kp, V)) * 2.0).astype(np.float32)  # any normalisation
+                # (the mix by the package's own fusion_ext kernel -- checked against numpy to 1e-5 -- so that the
+                # oracle ranks the SAME float32 extension probabilities the fused step forms inside itself)
+                lsm = scores - scores.max(2, keepdims=True)
+                lsm = lsm - np.log(np.exp(lsm).sum(2, keepdims=True))
+                ext_np = ((1 - beta) * nonext[:, None] + beta * np.exp(lsm) * (1 - blank[:, None, None]) if vmix
+                          else nonext[:, None] * np.exp(beta * lsm)).astype(np.float32)
+                ext = torch.ops.pydrobert_amd.fusion_ext(T(scores).reshape(N * Kp, V), T(nonext), T(blank), beta, vmix).cpu().numpy()
+                if not np.allclose(ext, ext_np, rtol=1e-5, atol=1e-30):
+                    bad += 1; print("MISMATCH fusion_ext", V, W, N, t, np.abs(ext - ext_np).max())
             exp = oracle.ctc_prefix_search_advance((ext, nonext, blank), W, (nb, b), y, last, lens, isp)
-            act = F.ctc_prefix_search_advance((T(ext), T(nonext), T(blank)), W, (T(nb), T(b)), T(y), T(last), T(lens), T(isp))
+            if form == "mixed":
+                o = D._ctc_step_with_lm_scores(T(scores), beta, vmix, T(nonext), T(blank), W, T(nb), T(b), T(y), T(last), T(lens), T(isp))
+                act = (o[0], o[1], o[2], (o[3], o[4]), o[5], o[6], o[7])
+            elif form == "shared":
+                act = F.ctc_prefix_search_advance((T(nonext).unsqueeze(1).expand(N, Kp, V), T(nonext), T(blank)), W, (T(nb), T(b)), T(y), T(last), T(lens), T(isp))
+            else:
+                act = F.ctc_prefix_search_advance((T(ext), T(nonext), T(blank)), W, (T(nb), T(b)), T(y), T(last), T(lens), T(isp))
             r = cmp_step(act, exp)
             if r:
                 # near-ties between candidate masses are legitimate differences; flag only clear ones
@@ -50,7 +78,7 @@ while time.time() < t_end:
                 srt = np.sort(tot[np.isfinite(tot)])[::-1]
                 gaps = np.abs(np.diff(srt)) / np.maximum(srt[:-1], 1e-30) if srt.size > 1 else np.array([1.0])
                 if gaps.size == 0 or gaps.min() > 1e-5:
-                    bad += 1; print("MISMATCH ctc step", r, V, W, N, t)
+                    bad += 1; print("MISMATCH ctc step", form, r, V, W, N, t)
                 break
             y, last, lens, (nb, b), isp = exp[0], exp[1], exp[2], exp[3], exp[4]
     elif kind == 1:  # spec augment apply

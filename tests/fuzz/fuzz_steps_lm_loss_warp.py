@@ -13,10 +13,13 @@ dev = "cuda"
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 t_end = time.time() + (float(sys.argv[2]) if len(sys.argv) > 2 else 60)
 bad = n_cases = 0
+t_say = time.time()
 def T(a): return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 lms = {}
 while time.time() < t_end:
     n_cases += 1
+    if time.time() - t_say > 45.0:  # (a line a minute: a silent run is taken for a hung one)
+        t_say = time.time(); print("cases", n_cases, "mismatches", bad, flush=True)
     kind = rng.integers(0, 4)
     if kind == 0:  # beam_search_advance
         N, Kp, V, W = int(rng.integers(1, 6)), int(rng.integers(1, 20)), int(rng.integers(1, 60)), int(rng.integers(1, 40))
@@ -24,10 +27,26 @@ while time.time() < t_end:
             Kp, V, W = int(rng.integers(1, 140)), int(rng.integers(1, 300)), int(rng.integers(1, 200))
             if rng.random() < 0.5: Kp = max(Kp, 65)
             else: W = max(W, 65)
+        flat = rng.random() < 0.35  # rows of more than 64 tokens in a workgroup's registers: the flat selection (round 5)
+        if flat:
+            Kp = int(rng.integers(1, 17))
+            V, W = int(rng.integers(65, min(1100, 16384 // Kp) + 1)), int(rng.integers(1, 70))
         S = int(rng.integers(0, 9))
         lpt = rng.normal(size=(N, Kp, V)).astype(np.float32)
         if rng.random() < 0.3: lpt = np.round(lpt * 4) / 4  # exact ties: lowest flat index first
         lpp = rng.normal(size=(N, Kp)).astype(np.float32)
+        if flat:
+            what = rng.integers(0, 5)
+            if what == 1:  # finished beams: -inf but for one token
+                done = rng.random((N, Kp)) < rng.random()
+                row = np.full(V, -np.inf, np.float32); row[int(rng.integers(0, V))] = 0.0
+                lpt[done] = row
+            elif what == 2:  # the best candidates crowd one lane
+                lpt[:, :, int(rng.integers(0, 64))::64] += 25.0
+            elif what == 3:  # -inf sprinkled, or nearly everywhere
+                lpt = np.where(rng.random(lpt.shape) < rng.choice([0.3, 0.999]), -np.inf, lpt).astype(np.float32)
+            elif what == 4:
+                lpp[rng.random((N, Kp)) < 0.3] = -np.inf
         yp = rng.integers(0, V, (S, N, Kp))
         ypl = rng.integers(1 if S else 0, S + 1, (N, Kp)) if (rng.random() < 0.5) else None
         exp = oracle.beam_search_advance(lpt, W, lpp, yp, ypl)

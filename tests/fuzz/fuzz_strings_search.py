@@ -14,9 +14,12 @@ t_end = time.time() + float(sys.argv[2]) if len(sys.argv) > 2 else time.time() +
 bad = 0
 ONLY_CTC = len(sys.argv) > 3
 n_cases = 0
+t_say = time.time()
 def T(a): return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 while time.time() < t_end:
     n_cases += 1
+    if time.time() - t_say > 45.0:  # (a line a minute: a silent run is taken for a hung one)
+        t_say = time.time(); print("cases", n_cases, "mismatches", bad, flush=True)
     kind = 1 if ONLY_CTC else rng.integers(0, 4)
     if kind == 0:  # string ops
         N, R, H, V = int(rng.integers(1, 9)), int(rng.integers(0, 140)), int(rng.integers(0, 140)), int(rng.integers(1, 12))
