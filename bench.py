@@ -626,18 +626,19 @@ def lm_configs(F, M, device, args, ref, hyp, say=lambda msg: None):
         torch.cuda.synchronize()
         table_ms = (time.perf_counter() - t0) * 1e3
         ms = event_ms(lambda: bs(None, N3, 100), reps=3, warm=1)
-    # what an iteration really moves through HBM: the history, copied (t, N, K) -> (t + 1, N, K) int64;
-    # the prefixes' rows come out of the model's 4 MB table (L2 / Infinity Cache), once built
-    hist_bytes = sum(8 * N3 * K * (2 * t + 1) for t in range(100))
+    # what the search really moves through HBM: the model's table once, a (source, token) word per beam entry and
+    # iteration written and read back, the int64 paths written once (the score rows come out of the 4 MB table
+    # in L2 / Infinity Cache; the step-by-step routes copied the (t, N, K) history every iteration)
+    hist_bytes = 2 * 4 * N3 * K * 100 + 8 * N3 * K * 100
     out["BeamSearch_end_to_end"] = {
         "workload": "BeamSearch(LookupLanguageModel bigram, width 16, eos=0), batch 1024, 100 iterations, V=1000",
         "ms": ms, "ms_per_iteration": ms / 100, "paths_per_s": N3 * K / ms * 1e3, "reps": 3,
         "table_build_ms": table_ms,
         "table_build_note": "the model's dense (context, token) table + row statistics, built once per model (not in `ms`)",
         "row_bytes_from_cache": 4.0 * N3 * K * V3 * 100,
-        "roofline": roof(hist_bytes + 4 * (V3 + 1) * V3, ms, "pdt::beam_step_flat_kernel (table form)",
-                         "HBM bytes = the history copies + one read of the table; 6.5 GB of score rows come from the "
-                         "table in cache and are not HBM traffic: the loop is bound by the step kernel's latency"),
+        "roofline": roof(hist_bytes + 4 * (V3 + 1) * V3, ms, "pdt::beam_search_table_kernel<true> + pdt::beam_search_walk_kernel (every iteration in one launch)",
+                         "HBM bytes = one read of the table + the trie + the paths; 6.5 GB of score rows come from the "
+                         "table in cache and are not HBM traffic: the search is bound by the per-iteration chain of a workgroup"),
     }
     return out
 

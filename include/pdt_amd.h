@@ -307,6 +307,27 @@ int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_
  *   width, Kp <= 64.
  * ------------------------------------------------------------------------------------- */
 /* ---------------------------------------------------------------------------------------
+ * BeamSearch.forward over a bigram table, EVERY iteration in one launch (reference _decoding.py:383-504
+ * with the default step hook; the table and its row statistics as for pdt_beam_search_step_table):
+ * a workgroup runs its batch element's iterations back to back and stops at the one that finds the
+ * element finished.  Starts from one empty path whose table row is sos_row.
+ *   trie (N, n_iters, width) uint32: an iteration's (source << 20 | token) per beam entry;
+ *   log_probs_out / lens_out (N, width): the final beam; finish (N,) int32: the iteration that found the
+ *   element finished (n_iters: none); t_stop [1] int32, zeroed by the caller: max over the elements --
+ *   the rows y has (the reference leaves its loop there).
+ * pdt_beam_search_table_paths then writes y (T, N, width) int64 from the trie (T = t_stop): row s of a
+ * path = the token its ancestor chose in iteration s, pad_value from finish[n] on.
+ * PDT_E_UNSUPPORTED for rows of at most 64 tokens, width above 64 or width * ceil(V / 64) above 256: the
+ * per-iteration entry points serve those.
+ * ------------------------------------------------------------------------------------- */
+int pdt_beam_search_table(const float *table, int64_t tb_sr, int64_t tb_sv, int64_t U, const float *row_stats,
+                          int64_t sos_row, int64_t N, int64_t V, int64_t width, int64_t n_iters, int has_eos,
+                          int64_t eos, int finish_all_paths, uint32_t *trie, float *log_probs_out,
+                          int64_t *lens_out, int32_t *finish, int32_t *t_stop, void *stream);
+int pdt_beam_search_table_paths(const uint32_t *trie, const int32_t *finish, int64_t N, int64_t n_iters,
+                                int64_t width, int64_t T, int64_t pad_value, int64_t *y, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * One frame of CTCPrefixSearch with a LookupLanguageModel in the loop as one kernel
  * (_decoding.py:1110-1163 around :636-934; scores: _lm.py:403-515): the back-off n-gram scores of
  * every prefix's context (its last max_ngram - 1 tokens, read from y_prev), shallow fusion

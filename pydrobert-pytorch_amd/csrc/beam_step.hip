@@ -452,6 +452,306 @@ __global__ void __launch_bounds__(64 * kStepFlatWaves, 6) beam_step_flat_kernel(
   }
 }
 
+
+// -------------------------------------------------------------------------------------------
+// The whole search over a bigram table in ONE launch (round 5, pdt_beam_search_table): the batch elements
+// are independent and the model is a table, so a workgroup runs its element's iterations back to back --
+// the beam (log-probability, length, last token = next table row) in LDS, the selection of
+// beam_step_flat_kernel per iteration, NO history copies: an iteration leaves one (source, token) word per
+// beam entry in a trie (N, T, W), and beam_search_walk_kernel reads the final paths off it at the end
+// (row s of a path is the token its ancestor chose in iteration s -- exactly what the copies of the
+// step-by-step form add up to, rows beyond a path's length included).  An element stops at the iteration
+// that finds it finished (:421-424) and records it; the host cuts y at the largest such iteration.
+#ifndef PDT_BS_WAVES  // waves per SIMD the ROWS16 form is compiled for (8: 64 registers, 13 of them spilled; 6: 80)
+#define PDT_BS_WAVES 8
+#endif
+struct BeamSearchArgs {
+  const float *table;  int64_t tb_sr;   // (U, V), token stride 1
+  const float *row_stats;               // (U, 2)
+  int N, V, W, n_iters, sos_row;
+  int has_eos, finish_all, eos;
+  unsigned *trie;       // (N, n_iters, W): source << 20 | token
+  float *lp_out;        // (N, W)
+  int64_t *lens_out;    // (N, W)
+  int32_t *finish;      // (N,): the iteration that found the element finished (n_iters: none did)
+  int32_t *t_stop;      // [1]: max over the elements of finish (atomicMax; the caller zeroes it)
+};
+
+// ROWS16: width <= 16 and V <= 1024 -- a wave owns whole rows (prefix k = wave, wave + 8), sixteen chunk slots
+// each, so every register, offset and guard of the candidate loops is static and a row's pointer, addend and
+// statistics are fetched once per row instead of once per chunk (10 000 -> ~2 000 instructions per
+// element and iteration).  Other shapes: chunks numbered across the rows as in beam_step_flat_kernel.
+template <bool ROWS16>
+__global__ void __launch_bounds__(64 * kStepFlatWaves, ROWS16 ? PDT_BS_WAVES : 6) beam_search_table_kernel(const BeamSearchArgs a) {
+  __shared__ unsigned colmax[kStepFlatWaves * PDT_WAVE];
+  __shared__ u64 surv[PDT_SURV_CAP];
+  __shared__ unsigned ctl[4];  // [0] the threshold (float bits), [1] the survivor cursor
+  __shared__ int srcs[PDT_WAVE], toks[PDT_WAVE];
+  __shared__ int st_row[PDT_WAVE], st_len[PDT_WAVE], st_tok[PDT_WAVE];  // the beam between iterations
+  __shared__ float st_lp[PDT_WAVE];
+  int lane = lane_id();
+  asm volatile("" : "+v"(lane));
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int64_t n = blockIdx.x;
+  const int W = a.W, eos = a.eos;
+  const int CH = (a.V + PDT_WAVE - 1) >> 6;
+  if (threadIdx.x < PDT_WAVE) {  // one empty path
+    st_row[threadIdx.x] = a.sos_row;
+    st_len[threadIdx.x] = 0;
+    st_tok[threadIdx.x] = -1;
+    st_lp[threadIdx.x] = threadIdx.x == 0 ? 0.0f : -PDT_INF;
+  }
+  __syncthreads();
+  int Kp = 1, t = 0;
+  const int lane0 = lane;
+  for (; t < a.n_iters; ++t) {
+    // (laundered per iteration: nothing derived from the lane index or V is loop-invariant to the compiler --
+    // hoisted, the sixteen clamped offsets and guards of the candidate loops are live across the whole loop
+    // and spill: 149 spilled registers before this line)
+    int lane = lane0, V = a.V;
+    asm volatile("" : "+v"(lane), "+s"(V));
+    if (threadIdx.x == 0) ctl[1] = 0u;
+    const int K = min(W, (int)min((int64_t)Kp * V, (int64_t)PDT_WAVE));  // :121
+    // lane k of every wave: prefix k
+    const int len_v = lane < Kp ? st_len[lane] : 0;
+    const int r_v = lane < Kp ? st_row[lane] : 0;
+    const float bias_v = lane < Kp ? st_lp[lane] : 0.0f;
+    const u64 ended_mask = __ballot(lane < Kp && a.has_eos && t > 0 && len_v > 0 && st_tok[lane] == eos);  // :413-420
+    if (a.has_eos && t > 0) {  // :421-424
+      const u64 all = Kp >= 64 ? ~0ull : ((1ull << Kp) - 1ull);
+      if (a.finish_all ? (ended_mask & all) == all : (ended_mask & 1ull) != 0) break;
+    }
+    const float mx_v = lane < Kp ? a.row_stats[2 * (int64_t)r_v] : 0.0f;
+    const float lse_v = lane < Kp ? a.row_stats[2 * (int64_t)r_v + 1] : 0.0f;
+    // ---- 1. the candidates: log_probs_prev[k] + log_softmax(scores[k])[v] (:441, :122) ---------------
+    const int total = Kp * CH;
+    const int per = (total + kStepFlatWaves - 1) / kStepFlatWaves;  // chunks per wave, <= kStepFlatRegs (the launcher)
+    const int c0 = wave * per;
+    const int k0 = c0 / CH, ci0 = c0 - k0 * CH;
+    float x[kStepFlatRegs];
+    float lmax = -PDT_INF;
+    if constexpr (ROWS16) {
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int k = wave + rr * kStepFlatWaves;
+#pragma unroll
+        for (int ci = 0; ci < 16; ++ci) x[rr * 16 + ci] = -PDT_INF;
+        if (k < Kp && !((ended_mask >> k) & 1ull)) {
+          const float *row = a.table + (int64_t)__builtin_amdgcn_readlane(r_v, k) * a.tb_sr + lane;
+          // (straight-line: slots beyond the row re-read its last token and are masked below)
+#pragma unroll
+          for (int ci = 0; ci < 16; ++ci) x[rr * 16 + ci] = row[min(ci * PDT_WAVE, V - 1 - lane)];
+        }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 2; ++rr) {
+        const int k = wave + rr * kStepFlatWaves;
+        if (k < Kp) {
+          const float bias = readlane_f(bias_v, k);
+          if ((ended_mask >> k) & 1ull) {  // eos alone, at no cost (:448-458)
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) x[rr * 16 + ci] = ci * PDT_WAVE + lane == eos ? (bias + 0.0f) + 0.0f : -PDT_INF;
+          } else {
+            const float mx = readlane_f(mx_v, k), lse = readlane_f(lse_v, k);
+#pragma unroll
+            for (int ci = 0; ci < 16; ++ci) {
+              const float val = (bias + ((x[rr * 16 + ci] - mx) - lse)) + 0.0f;
+              x[rr * 16 + ci] = ci * PDT_WAVE + lane < V ? val : -PDT_INF;
+            }
+          }
+#pragma unroll
+          for (int ci = 0; ci < 16; ci += 2) lmax = fmaxf(lmax, fmaxf(x[rr * 16 + ci], x[rr * 16 + ci + 1]));
+        }
+      }
+    } else {
+      int k = k0, ci = ci0;
+#pragma unroll
+      for (int j = 0; j < kStepFlatRegs; ++j) {
+        x[j] = -PDT_INF;  // (beyond a row, beyond the candidates: never a survivor, see the threshold below)
+        if (j < per && c0 + j < total) {
+          const float *row = a.table + (int64_t)__builtin_amdgcn_readlane(r_v, k) * a.tb_sr;
+          const int v = ci * PDT_WAVE + lane;
+          if (ci + 1 < CH || v < V) x[j] = row[v];
+          if (++ci == CH) ci = 0, ++k;
+        }
+      }
+    }
+    if constexpr (!ROWS16) {
+      int k = k0, ci = ci0;
+#pragma unroll
+      for (int j = 0; j < kStepFlatRegs; ++j) {
+        if (j < per && c0 + j < total) {
+          const float bias = readlane_f(bias_v, k);
+          const int v = ci * PDT_WAVE + lane;
+          if ((ended_mask >> k) & 1ull) {
+            x[j] = v == eos ? (bias + 0.0f) + 0.0f : -PDT_INF;  // eos alone, at no cost (:448-458)
+          } else {
+            const float val = (bias + ((x[j] - readlane_f(mx_v, k)) - readlane_f(lse_v, k))) + 0.0f;
+            x[j] = (ci + 1 < CH || v < V) ? val : -PDT_INF;
+          }
+          lmax = fmaxf(lmax, x[j]);
+          if (++ci == CH) ci = 0, ++k;
+        }
+      }
+    }
+    colmax[wave * PDT_WAVE + lane] = fkey(lmax);
+    __syncthreads();
+    if (wave == 0) {
+      unsigned cm = colmax[lane];
+#pragma unroll
+      for (int w = 1; w < kStepFlatWaves; ++w) cm = max(cm, colmax[w * PDT_WAVE + lane]);
+      const unsigned sorted_max = wave_sort_desc<unsigned>(cm);
+      const float tau = fmaxf(fkey_inv((unsigned)__builtin_amdgcn_readlane((int)sorted_max, K - 1)), -3.4028234664e38f);
+      if (lane == 0) ctl[0] = __float_as_uint(tau);
+    }
+    __syncthreads();
+    // ---- 2. survivors ----------------------------------------------------------------------
+    const float tau = __uint_as_float(ctl[0]);
+    if (__ballot(lmax >= tau)) {
+#pragma unroll
+      for (int j = 0; j < kStepFlatRegs; ++j) {
+        const bool pred = x[j] >= tau;
+        if (__ballot(pred)) {
+          int k, ci;
+          if constexpr (ROWS16) {
+            k = wave + (j >> 4) * kStepFlatWaves, ci = j & 15;
+          } else {
+            const int c = c0 + j;
+            k = c / CH, ci = c - k * CH;
+          }
+          if (pred) {
+            const unsigned at = atomicAdd(&ctl[1], 1u);
+            if (at < PDT_SURV_CAP) surv[at] = pack_key(fkey(x[j]), ((unsigned)k << 20) | (unsigned)(ci * PDT_WAVE + lane));
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 3. the winners in order, the new beam ----------------------------------------------------
+    if (wave == 0) {
+      const int count = (int)ctl[1];
+      auto value_at = [&](const int k, const int v) {  // candidate (k, v) of a path that has not ended, from memory
+        const int64_t r = st_row[k];
+        return (st_lp[k] + ((a.table[r * a.tb_sr + v] - a.row_stats[2 * r]) - a.row_stats[2 * r + 1])) + 0.0f;
+      };
+      u64 tk = 0ull;
+      int have = 0;  // winners that are in tk
+      if (count <= PDT_SURV_CAP) {
+        tk = wave_sort_desc<u64>(lane < count ? surv[lane] : 0ull);
+        have = min(count, K);
+      } else {
+        int cands = 0;  // every candidate, -inf ones included, from memory
+        for (int k = 0; k < Kp; ++k) {
+          if ((ended_mask >> k) & 1ull) {
+            const float xv = (st_lp[k] + 0.0f) + 0.0f;
+            tk = wave_merge_top64(tk, lane == 0 ? pack_key(fkey(xv), ((unsigned)k << 20) | (unsigned)eos) : 0ull);
+            cands += 1;
+          } else {
+            for (int v0 = 0; v0 < V; v0 += PDT_WAVE) {
+              const int v = v0 + lane;
+              const float xv = v < V ? value_at(k, v) : 0.0f;
+              tk = wave_merge_top64(tk, v < V ? pack_key(fkey(xv), ((unsigned)k << 20) | (unsigned)v) : 0ull);
+            }
+            cands += V;
+          }
+        }
+        have = min(cands, K);
+      }
+      int new_src = (int)(idx_of(tk) >> 20), new_tok = (int)(idx_of(tk) & 0xfffffu);
+      float new_lp = fkey_inv(key_of(tk));
+      if (have < K && count <= PDT_SURV_CAP) {
+        // fewer than K finite candidates: -inf ones of the paths that have not ended, in flat order, behind them
+        const int filled = have;
+        for (int k = 0; k < Kp && have < K; ++k) {
+          if ((ended_mask >> k) & 1ull) continue;
+          for (int v0 = 0; v0 < V && have < K; v0 += PDT_WAVE) {
+            const int v = v0 + lane;
+            const bool is = v < V && value_at(k, v) == -PDT_INF;
+            const u64 b = __ballot(is);
+            const int rank = have + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0u));
+            if (is && rank < K) {
+              srcs[rank] = k;
+              toks[rank] = v;
+            }
+            have += __popcll(b);
+          }
+        }
+        have = min(have, K);
+        wave_sync();
+        if (lane >= filled && lane < have) {
+          new_src = srcs[lane];
+          new_tok = toks[lane];
+          new_lp = -PDT_INF;
+        }
+        wave_sync();
+      }
+      const bool valid = lane < have;
+      const int src = valid ? new_src : 0;
+      const int src_len = shfl_i(len_v, src);
+      const int grew = 1 - (int)((ended_mask >> (src & 63)) & 1ull);  // ended sources stay as long as they were (:465-468)
+      wave_sync();  // (every lane has read the old beam)
+      if (lane < W) {
+        st_lp[lane] = valid ? new_lp : -PDT_INF;  // :145-153 for the overflow
+        st_len[lane] = valid ? src_len + grew : 0;
+        st_tok[lane] = valid ? new_tok : 0;
+        st_row[lane] = valid ? new_tok : 0;  // the next row of the table: the path's last token
+        a.trie[(n * a.n_iters + t) * W + lane] = valid ? ((unsigned)src << 20) | (unsigned)new_tok : 0u;
+      }
+    }
+    Kp = W;
+    __syncthreads();
+  }
+  // t: the iteration that found the element finished, or n_iters
+  if (threadIdx.x < (unsigned)W) {
+    const bool has = (int)threadIdx.x < Kp;
+    a.lp_out[n * W + threadIdx.x] = has ? st_lp[threadIdx.x] : -PDT_INF;
+    a.lens_out[n * W + threadIdx.x] = has ? st_len[threadIdx.x] : 0;
+  }
+  if (threadIdx.x == 0) {
+    a.finish[n] = t;
+    atomicMax(a.t_stop, t);
+  }
+}
+
+// y[s, n, i] for s < T: the token the ancestor of final path i chose in iteration s; pad_value from the
+// element's finishing iteration on (:479-486).  One workgroup per element; the trie slab goes through LDS
+// in tiles from the end, the paths' ancestors carried in registers across tiles.
+constexpr int kWalkTile = 256;
+__global__ void __launch_bounds__(256) beam_search_walk_kernel(const unsigned *trie, const int32_t *finish, const int N,
+                                                               const int n_iters, const int W, const int T,
+                                                               const int64_t pad_value, int64_t *y) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  unsigned *tile = reinterpret_cast<unsigned *>(smem);  // [kWalkTile x W] trie words, then tokens in place
+  const int64_t n = blockIdx.x;
+  const int tid = (int)threadIdx.x;
+  const int fin = min(finish[n], T);  // rows [0, fin) are paths, [fin, T) padding
+  for (int idx = fin * W + tid; idx < T * W; idx += 256) {
+    const int s = idx / W, i = idx - s * W;
+    y[((int64_t)s * N + n) * W + i] = pad_value;
+  }
+  int anc = tid < W ? tid : 0;  // the ancestor of final path `tid` after the iterations walked so far
+  for (int hi = fin; hi > 0; hi -= kWalkTile) {
+    const int lo = max(0, hi - kWalkTile), rows = hi - lo;
+    for (int idx = tid; idx < rows * W; idx += 256) tile[idx] = trie[(n * n_iters + lo) * W + idx];
+    __syncthreads();
+    if (tid < W) {
+      // (the words of a row are read before they are overwritten with tokens: one lane per column, rows
+      // from the end -- a column's word may be another column's ancestor, so tokens go to the second half)
+      for (int s = rows - 1; s >= 0; --s) {
+        const unsigned w = tile[s * W + anc];
+        tile[kWalkTile * W + s * W + tid] = w & 0xfffffu;
+        anc = (int)(w >> 20);
+      }
+    }
+    __syncthreads();
+    for (int idx = tid; idx < rows * W; idx += 256) {
+      const int s = idx / W, i = idx - s * W;
+      y[((int64_t)(lo + s) * N + n) * W + i] = (int64_t)tile[kWalkTile * W + idx];
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace pdt
 
 namespace pdt {
@@ -549,5 +849,47 @@ extern "C" int pdt_row_log_softmax_stats(const float *table, int64_t tb_sr, int6
   if (!table || !stats) return PDT_E_ARG;
   hipLaunchKernelGGL(pdt::row_stats_kernel, dim3((unsigned)((U + 3) / 4)), dim3(256), 0, (hipStream_t)stream, table,
                      tb_sr, tb_sv, (int)U, (int)V, stats);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pdt_beam_search_table(const float *table, int64_t tb_sr, int64_t tb_sv, int64_t U, const float *row_stats,
+                                     int64_t sos_row, int64_t N, int64_t V, int64_t width, int64_t n_iters, int has_eos,
+                                     int64_t eos, int finish_all_paths, uint32_t *trie, float *log_probs_out,
+                                     int64_t *lens_out, int32_t *finish, int32_t *t_stop, void *stream) {
+  using namespace pdt;
+  if (N < 0 || V < 1 || width < 1 || n_iters < 1 || U < 1 || sos_row < 0 || sos_row >= U) return PDT_E_ARG;
+  if (N == 0) return PDT_OK;
+  if (!table || !row_stats || !trie || !log_probs_out || !lens_out || !finish || !t_stop) return PDT_E_ARG;
+  if (has_eos && (eos < 0 || eos >= V)) return PDT_E_ARG;
+  if (N >= (1ll << 31) || n_iters >= (1 << 24)) return PDT_E_TOO_LONG;
+  if (tb_sv != 1 || V <= PDT_WAVE || V >= (1 << 20) || V > U || width > PDT_WAVE ||
+      width * ((V + PDT_WAVE - 1) / PDT_WAVE) > kStepFlatWaves * kStepFlatRegs)
+    return PDT_E_UNSUPPORTED;  // (the per-iteration entry points serve those)
+  BeamSearchArgs a{};
+  a.table = table; a.tb_sr = tb_sr; a.row_stats = row_stats;
+  a.N = (int)N; a.V = (int)V; a.W = (int)width; a.n_iters = (int)n_iters; a.sos_row = (int)sos_row;
+  a.has_eos = has_eos; a.finish_all = finish_all_paths; a.eos = (int)eos;
+  a.trie = trie; a.lp_out = log_probs_out; a.lens_out = lens_out; a.finish = finish; a.t_stop = t_stop;
+  if (width <= 16 && V <= 16 * PDT_WAVE)
+    hipLaunchKernelGGL(beam_search_table_kernel<true>, dim3((unsigned)N), dim3(64 * kStepFlatWaves), 0, (hipStream_t)stream, a);
+  else
+    hipLaunchKernelGGL(beam_search_table_kernel<false>, dim3((unsigned)N), dim3(64 * kStepFlatWaves), 0, (hipStream_t)stream, a);
+  return (int)hipGetLastError();
+}
+
+extern "C" int pdt_beam_search_table_paths(const uint32_t *trie, const int32_t *finish, int64_t N, int64_t n_iters,
+                                           int64_t width, int64_t T, int64_t pad_value, int64_t *y, void *stream) {
+  using namespace pdt;
+  if (N < 0 || n_iters < 1 || width < 1 || width > PDT_WAVE || T < 0 || T > n_iters) return PDT_E_ARG;
+  if (N == 0 || T == 0) return PDT_OK;
+  if (!trie || !finish || !y) return PDT_E_ARG;
+  const size_t smem = (size_t)2 * kWalkTile * width * 4;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(beam_search_walk_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(beam_search_walk_kernel, dim3((unsigned)N), dim3(256), smem, (hipStream_t)stream, trie, finish, (int)N,
+                     (int)n_iters, (int)width, (int)T, pad_value, y);
   return (int)hipGetLastError();
 }

@@ -70,6 +70,11 @@ SIGNATURES = {
         + [_P, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64, _P, _I64, _I64]
         + [_P, _I64, _I64, _P, _I64, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     ),
+    "pdt_beam_search_table": (
+        _INT,
+        [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _P, _P, _P, _P, _P, _P],
+    ),
+    "pdt_beam_search_table_paths": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "pdt_beam_search_advance": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]

@@ -1171,6 +1171,39 @@ class BeamSearch(torch.nn.Module):
         return table, stats, sos_row
 
     @torch.jit.unused
+    def _table_search(self, dense, N: int, max_iters: int, squeeze: bool):
+        """``pdt_beam_search_table`` + ``pdt_beam_search_table_paths``: the whole search in one launch, the
+        paths written once at the end (one host read in between: the number of rows ``y`` has).  ``None``
+        when the kernel does not take the shape."""
+        table, stats, sos_row = dense
+        device, W, V = table.device, self.width, self.lm.vocab_size
+        L = _cabi.lib()
+        with _cabi.on_device(device):
+            trie = torch.empty((N, max_iters, W), dtype=torch.int32, device=device)
+            lp = torch.empty((N, W), device=device)
+            lens = torch.empty((N, W), dtype=torch.long, device=device)
+            finish = torch.empty((N,), dtype=torch.int32, device=device)
+            t_stop = torch.zeros((1,), dtype=torch.int32, device=device)
+            stream = _cabi.stream_ptr(device)
+            rc = L.pdt_beam_search_table(
+                _cabi.ptr(table), table.stride(0), table.stride(1), table.size(0), _cabi.ptr(stats), int(sos_row),
+                N, V, W, max_iters, int(self.eos is not None), int(self.eos or 0), int(self.finish_all_paths),
+                _cabi.ptr(trie), _cabi.ptr(lp), _cabi.ptr(lens), _cabi.ptr(finish), _cabi.ptr(t_stop), stream,
+            )  # fmt: skip
+            if rc == _cabi.PDT_E_UNSUPPORTED:
+                return None
+            _cabi.check(rc, "pdt_beam_search_table")
+            T = int(t_stop.item())  # the reference leaves its loop at the iteration that finds every element finished
+            y = torch.empty((T, N, W), dtype=torch.long, device=device)
+            rc = L.pdt_beam_search_table_paths(
+                _cabi.ptr(trie), _cabi.ptr(finish), N, max_iters, W, T, int(self.pad_value), _cabi.ptr(y), stream
+            )
+            _cabi.check(rc, "pdt_beam_search_table_paths")
+        if squeeze:
+            y, lens, lp = y.squeeze(1), lens.squeeze(0), lp.squeeze(0)
+        return y, lens, lp
+
+    @torch.jit.unused
     def _forward_fused(
         self, prev: Dict[str, torch.Tensor], batch_size: Optional[int], max_iters: Optional[int]
     ) -> Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]]:
@@ -1228,6 +1261,11 @@ class BeamSearch(torch.nn.Module):
         Kp, t, t_stop = 1, 0, -1
         out_dtype = torch.float
         dense = self._bigram_table(device)
+        if dense is not None and 0 < max_iters <= 4096 and N > 0 and switches.get("PDT_BEAM_SEARCH"):
+            # a bigram table model, a bounded search: every iteration in ONE launch, no history copies
+            done = self._table_search(dense, N, max_iters, batch_size is None)
+            if done is not None:
+                return done
         first_rows = None if dense is None else torch.full((N, 1), dense[2], dtype=torch.long, device=device)
         if dense is not None:  # (what does not change from one iteration to the next, once)
             table, stats, _ = dense

@@ -24,6 +24,7 @@ _HOST_DEFAULTS = {
     "PDT_CTC_LM_TABLE": 1,  # ... a bigram model's factor rows from a table built once per model (csrc/ctc_lm_table.hip)
     "PDT_CTC_STEP_MIX": 1,  # CTCPrefixSearch + any other LM: the step kernel forms the extension probabilities itself (0: fusion_ext first)
     "PDT_BEAM_FUSED": 1,  # BeamSearch: one kernel per iteration
+    "PDT_BEAM_SEARCH": 1,  # ... and every iteration from ONE launch, the paths read off a trie at the end (csrc/beam_step.hip)
     "PDT_BEAM_TABLE": 1,  # BeamSearch over a bigram LookupLanguageModel reads its dense table
     "PDT_CHECK_INVARIANTS": 0,  # BeamSearch's loop checks that the history grows (a host read per iteration)
 }

@@ -207,12 +207,25 @@ def test_beam_search_reads_a_bigram_models_table(sos, switch):
         lm = M.LookupLanguageModel(V, sos if sos < V else 0, dicts, destructive=True).to(DEV)
         search = M.BeamSearch(lm, W, eos=eos).to(DEV)
         outs = []
+        switch("PDT_BEAM_SEARCH", 0)
         for fused, table in (("1", "1"), ("1", "0"), ("0", "0")):
             switch("PDT_BEAM_FUSED", fused)
             switch("PDT_BEAM_TABLE", table)
             outs.append(search(dict(), batch_size=N, max_iters=iters))
         (y, yl, lp), (y1, yl1, lp1), (y2, yl2, lp2) = outs
         what = (sos, V, W, N, eos)
+        # every iteration from one launch, the paths off a trie (PDT_BEAM_SEARCH, round 5; rows of more than 64
+        # tokens -- shorter ones keep the iterations): the same tensors, rows beyond the lengths included
+        switch("PDT_BEAM_FUSED", "1")
+        switch("PDT_BEAM_TABLE", "1")
+        switch("PDT_BEAM_SEARCH", 1)
+        for bs_, it_ in ((N, iters), (N, 1), (None, iters), (N, 3 * iters)):
+            ys, yls, lps = search(dict(), batch_size=bs_, max_iters=it_)
+            switch("PDT_BEAM_SEARCH", 0)
+            yt, ylt, lpt = search(dict(), batch_size=bs_, max_iters=it_)
+            switch("PDT_BEAM_SEARCH", 1)
+            assert ys.shape == yt.shape and torch.equal(ys, yt) and torch.equal(yls, ylt) and torch.equal(lps, lpt), (what, bs_, it_)
+        switch("PDT_BEAM_SEARCH", 0)
         if V > 64:
             switch("PDT_BEAM_FUSED", "1")
             switch("PDT_BEAM_TABLE", "1")
@@ -231,6 +244,44 @@ def test_beam_search_reads_a_bigram_models_table(sos, switch):
         switch("PDT_BEAM_TABLE", "0")
         yb, ylb, lpb = search(dict(), batch_size=N, max_iters=iters)
         assert torch.equal(ya, yb) and torch.equal(yla, ylb) and torch.equal(lpa, lpb), what
+        switch("PDT_BEAM_SEARCH", 1)
+
+
+def test_beam_search_every_iteration_in_one_launch(switch):
+    """`pdt_beam_search_table` (round 5): a bigram-table model's whole search from ONE launch -- the beam in
+    LDS, a (source, token) word per entry and iteration in a trie, the paths read off it at the end -- against
+    the iteration-per-launch table route: the same `y` (rows beyond the lengths and the padding included),
+    lengths and log-probabilities, to the bit.  Rows of 65 .. 1024 tokens with beams up to 16 take the
+    rows-per-wave form, wider beams and longer rows the chunk-numbered one; eos biased so that batch elements
+    finish at different iterations (and some never do)."""
+    rng = np.random.default_rng(5150)
+    switch("PDT_BEAM_FUSED", "1")
+    switch("PDT_BEAM_TABLE", "1")
+    for case in range(24):
+        V = int(rng.choice([65, 66, 100, 128, 129, 300, 640, 1000, 1024, 1025, 1500]))
+        w_max = min(64, 256 // ((V + 63) // 64))  # (beyond: the iterations, by PDT_E_UNSUPPORTED)
+        W = int(rng.integers(1, min(16, w_max) + 1)) if case % 3 or w_max < 17 else int(rng.integers(17, w_max + 1))
+        N, iters = int(rng.integers(1, 7)), int(rng.integers(1, 40))
+        eos = None if case % 5 == 0 else int(rng.integers(0, V))
+        fin = bool(case % 2)
+        sos = -1 if case % 4 == 0 else int(rng.integers(0, V))
+        dicts = random_dicts(rng, V, 2, 4.0 / V, sos if sos < 0 else None)
+        for v in range(V):
+            dicts[0].setdefault(v, (float(rng.normal()), float(rng.normal())))
+        if eos is not None:  # a likely eos: paths end at different iterations
+            lp_, bo_ = dicts[0][eos]
+            dicts[0][eos] = (lp_ + float(rng.uniform(2.0, 6.0)), bo_)
+        lm = M.LookupLanguageModel(V, sos, dicts, destructive=True).to(DEV)
+        search = M.BeamSearch(lm, W, eos=eos, finish_all_paths=fin, pad_value=int(rng.integers(-9, 3))).to(DEV)
+        outs = []
+        for one_launch in (1, 0):
+            switch("PDT_BEAM_SEARCH", one_launch)
+            outs.append(search(dict(), batch_size=N, max_iters=iters))
+        (y, yl, lp), (y0, yl0, lp0) = outs
+        what = (case, V, W, N, iters, eos, fin, sos)
+        assert y.shape == y0.shape, (what, y.shape, y0.shape)
+        assert torch.equal(y, y0) and torch.equal(yl, yl0) and torch.equal(lp, lp0), what
+    switch("PDT_BEAM_SEARCH", 1)
 
 
 def test_shallow_fusion_of_two_models():

@@ -29,8 +29,10 @@ CTC_ROUTES = {"table": dict(PDT_CTC_LM_TABLE=1, PDT_CTC_LM_FUSED=1, PDT_CTC_LM_S
               "search": dict(PDT_CTC_LM_TABLE=0, PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=1),
               "frame": dict(PDT_CTC_LM_TABLE=0, PDT_CTC_LM_FUSED=1, PDT_CTC_LM_SEARCH=0),
               "three": dict(PDT_CTC_LM_TABLE=0, PDT_CTC_LM_FUSED=0)}
-BEAM_ROUTES = {"table": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=1), "fused": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=0),
-               "loop": dict(PDT_BEAM_FUSED=0)}
+# (search: every iteration of a bigram-table model from ONE launch, the paths read off a trie at the end -- round 5)
+BEAM_ROUTES = {"search": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=1, PDT_BEAM_SEARCH=1),
+               "table": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=1, PDT_BEAM_SEARCH=0),
+               "fused": dict(PDT_BEAM_FUSED=1, PDT_BEAM_TABLE=0), "loop": dict(PDT_BEAM_FUSED=0)}
 
 
 def _t(a):
