@@ -1,5 +1,5 @@
 """Fuzz of the two-frames-per-pass producer (V = 256, W = 16; PDT_CTC_PAIR) against the one-frame form
-(torch.equal) and, on tie-free inputs, the oracle:   python profiles/tools/fuzz_pair.py SEED SECONDS"""
+(torch.equal) and, on tie-free inputs, the oracle:   python tests/fuzz/fuzz_pair.py SEED SECONDS"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "pydrobert-pytorch_amd")):

@@ -1,4 +1,4 @@
-"""Fuzz of round 4's two new search kernels (python profiles/tools/fuzz_r04.py [seed] [cases]).
+"""Fuzz of round 4's two new search kernels (python tests/fuzz/fuzz_r04.py [seed] [cases]).
 
 1. ctc_prefix_search without a model: the register-row form (PDT_CTC_ROWREG=1, and =2: from 128 tokens)
    against the LDS / workspace rows (=0) -- torch.equal on all three outputs -- over random vocabularies

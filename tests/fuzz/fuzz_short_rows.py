@@ -1,4 +1,4 @@
-"""Fuzz of the short-row CTC search instances (python profiles/tools/fuzz_short_rows.py [seed] [cases]).
+"""Fuzz of the short-row CTC search instances (python tests/fuzz/fuzz_short_rows.py [seed] [cases]).
 
 The default shape (V = 256, width 16, contiguous rows) and width 16 with V = 256..319 run instantiations
 with those shapes compiled in (ctc_search.hip); the same values through a vocabulary axis with a stride
