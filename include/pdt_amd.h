@@ -273,6 +273,16 @@ int pdt_ctc_prefix_search_advance_lm(
     uint8_t *next_is_prefix, int64_t *next_src, uint8_t *next_is_nonext, void *stream);
 
 /* ---------------------------------------------------------------------------------------
+ * What a caller of pdt_beam_search_advance must know to choose S_out (reference _decoding.py:133-140):
+ * *host_flag (a word in pinned host memory, valid once the stream has been synchronised) = bit 0: some
+ * y_prev_lens[n, k] >= S; bit 1: some length is non-zero; bit 2: written (a system-scope release store: a
+ * host that zeroed the word before the call may poll for it instead of synchronising).  One small kernel
+ * and no device-to-host copy.
+ * ------------------------------------------------------------------------------------- */
+int pdt_lens_reach(const int64_t *lens, int64_t le_sn, int64_t le_sk, int64_t N, int64_t Kp, int64_t S,
+                   int32_t *host_flag, void *stream);
+
+/* ---------------------------------------------------------------------------------------
  * beam_search_advance (reference _decoding.py:41-155): one beam-search step.
  *   log_probs_t (N, Kp, V), log_probs_prev (N, Kp) float32; y_prev (S, N, Kp) int64;
  *   y_prev_lens (N, Kp) int64 or NULL (all S).  S_out = rows of y_next: S + 1 when

@@ -525,6 +525,29 @@ __global__ void __launch_bounds__(64 * kFlatWaves, 6) beam_advance_flat_kernel(c
   }
 }
 
+// What beam_search_advance's caller must know before it can size y_next (reference :133-140): does some path
+// reach the history's S rows (bit 0), is some length non-zero (bit 1: invalid at S = 0).  One workgroup, one
+// plain store to a word in pinned host memory the host reads after synchronising the stream -- instead of a
+// reduction kernel, a device-to-host copy and the synchronisation.
+__global__ void __launch_bounds__(1024) lens_reach_kernel(const int64_t *lens, const int64_t le_sn, const int64_t le_sk,
+                                                         const int N, const int Kp, const int64_t S, int32_t *flag) {
+  __shared__ int any_[2];
+  if (threadIdx.x < 2) any_[threadIdx.x] = 0;
+  __syncthreads();
+  bool reach = false, nonzero = false;
+  for (int64_t i = threadIdx.x; i < (int64_t)N * Kp; i += 1024) {
+    const int64_t n = i / Kp, k = i - n * Kp;
+    const int64_t l = lens[n * le_sn + k * le_sk];
+    reach = reach || l >= S;
+    nonzero = nonzero || l != 0;
+  }
+  if (__ballot(reach) && lane_id() == 0) any_[0] = 1;
+  if (__ballot(nonzero) && lane_id() == 0) any_[1] = 1;
+  __syncthreads();
+  // (bit 2: the word has been written -- a system-scope store the host may poll for instead of synchronising)
+  if (threadIdx.x == 0) __hip_atomic_store(flag, any_[0] | (any_[1] << 1) | 4, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int launch_beam_advance(BeamAdvArgs a, hipStream_t stream) {
   if (a.W < 1 || a.Kp < 1) return PDT_E_ARG;
   const bool force_wide = switches().step_wide != 0;
@@ -614,6 +637,20 @@ int pdt_ctc_prefix_search_advance_lm(
   a.next_src = next_src; a.nb_next = nb_next; a.b_next = b_next;
   a.next_isp = next_is_prefix; a.next_nonext = next_is_nonext;
   return launch_ctc_advance(a, (hipStream_t)stream);
+}
+
+int pdt_lens_reach(const int64_t *lens, int64_t le_sn, int64_t le_sk, int64_t N, int64_t Kp, int64_t S,
+                   int32_t *host_flag, void *stream) {
+  using namespace pdt;
+  if (N < 0 || Kp < 0 || !host_flag || N >= (1ll << 31) || Kp >= (1ll << 31)) return PDT_E_ARG;
+  if (N * Kp == 0) {
+    *host_flag = 4;
+    return PDT_OK;
+  }
+  if (!lens) return PDT_E_ARG;
+  hipLaunchKernelGGL(lens_reach_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lens, le_sn, le_sk, (int)N, (int)Kp, S,
+                     host_flag);
+  return (int)hipGetLastError();
 }
 
 int pdt_beam_search_advance(const float *log_probs_t, int64_t lt_sn, int64_t lt_sk, int64_t lt_sv,

@@ -75,6 +75,7 @@ SIGNATURES = {
         [_P, _I64, _I64, _I64, _P, _I64, _I64, _I64, _I64, _I64, _INT, _I64, _INT, _P, _P, _P, _P, _P, _P],
     ),
     "pdt_beam_search_table_paths": (_INT, [_P, _P, _I64, _I64, _I64, _I64, _I64, _P, _P]),
+    "pdt_lens_reach": (_INT, [_P, _I64, _I64, _I64, _I64, _I64, _P, _P]),
     "pdt_beam_search_advance": (
         _INT,
         [_P, _I64, _I64, _I64, _I64, _I64, _I64, _I64, _P, _I64, _I64, _P, _I64, _I64, _I64, _I64]
@@ -273,6 +274,26 @@ class _NoGuard:
 
 
 _NO_GUARD = _NoGuard()
+
+
+def stream_synchronize(device):
+    """hipStreamSynchronize of the current stream of ``device``."""
+    torch.cuda.current_stream(device).synchronize()
+
+
+def wait_flag(flag, device, spin_seconds=5e-4):
+    """The value of a word a kernel RELEASES at system scope (non-zero once written): polled for half a
+    millisecond -- pinned host memory is coherent by default, and the interrupt behind hipStreamSynchronize
+    costs ~15 us -- then the stream is synchronised (a non-coherent host allocation, a long queue)."""
+    import time
+
+    word = flag._np
+    t_end = time.perf_counter() + spin_seconds
+    while word[0] == 0:
+        if time.perf_counter() > t_end:
+            stream_synchronize(device)
+            break
+    return int(word[0])
 
 
 def on_device(device):

@@ -86,10 +86,19 @@ def _beam_search_advance_impl(
     if grows is not None:
         grow = grows
     elif ypl is not None and N * Kp:
+        # :133-135 don't make y bigger unless we have to; :139-140 -- the reference's own host read
+        # (`y_prev_lens.max()`), as one small kernel that raises a word in pinned host memory
+        flag = _cabi.host_flag()
+        with _cabi.on_device(device):
+            rc = _cabi.lib().pdt_lens_reach(
+                _cabi.ptr(ypl), ypl.stride(0), ypl.stride(1), N, Kp, S, flag.ptr, _cabi.stream_ptr(device)
+            )
+            _cabi.check(rc, "pdt_lens_reach")
+        seen = _cabi.wait_flag(flag, device)
         if S:
-            grow = int(ypl.max().item()) >= S  # :133-135 don't make y bigger unless we have to
-        elif bool((ypl != 0).any()):
-            raise RuntimeError("Invalid lengths for t=0")  # :139-140
+            grow = bool(seen & 1)
+        elif seen & 2:
+            raise RuntimeError("Invalid lengths for t=0")
     S_out = S + (1 if grow else 0)
     with _cabi.on_device(device):
         y_next = torch.empty((S_out, N, width), device=device, dtype=torch.long)
@@ -1261,7 +1270,8 @@ class BeamSearch(torch.nn.Module):
         Kp, t, t_stop = 1, 0, -1
         out_dtype = torch.float
         dense = self._bigram_table(device)
-        if dense is not None and 0 < max_iters <= 4096 and N > 0 and switches.get("PDT_BEAM_SEARCH"):
+        if (dense is not None and 0 < max_iters <= 4096 and N > 0 and 4 * N * max_iters * W <= (1 << 30)
+                and switches.get("PDT_BEAM_SEARCH")):  # (the trie: a word per beam entry and iteration, 1 GiB at most)
             # a bigram table model, a bounded search: every iteration in ONE launch, no history copies
             done = self._table_search(dense, N, max_iters, batch_size is None)
             if done is not None:
